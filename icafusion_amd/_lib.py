@@ -1,0 +1,90 @@
+"""ctypes binding of libicaf.so (C ABI declared in include/icaf.h).
+
+The HIP library is the product: there is no CPU or PyTorch fallback.  `lib()` raises if the shared object is
+missing or does not export every symbol of the header, so a GPU box that silently lost the extension fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libicaf.so")
+
+F32, BF16, F16 = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("res", C.c_void_p),
+        ("x_gs", C.c_longlong), ("w_gs", C.c_longlong), ("bias_gs", C.c_longlong), ("y_gs", C.c_longlong),
+        ("res_gs", C.c_longlong),
+        ("groups", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("ldx", C.c_int),
+        ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int), ("ldy", C.c_int),
+        ("kh", C.c_int), ("kw", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("ph", C.c_int), ("pw", C.c_int),
+        ("ldr", C.c_int), ("Kp", C.c_int), ("act", C.c_int), ("dtype", C.c_int), ("out_dtype", C.c_int),
+        ("alpha_acc", C.c_float * 2), ("alpha_res", C.c_float * 2),
+        ("tile", C.c_int),
+    ]
+
+
+_p, _i, _ll, _f, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+# symbol -> (restype, argtypes); must list every function declared in include/icaf.h
+SIGNATURES = {
+    "icaf_last_error": (C.c_char_p, []),
+    "icaf_version": (_i, []),
+    "icaf_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
+    "icaf_preprocess_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "icaf_conv2d": (_i, [C.POINTER(ConvArgs), _p]),
+    "icaf_conv2d_kernel_name": (_i, [C.POINTER(ConvArgs), C.c_char_p, _i]),
+    "icaf_sppf_pool": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "icaf_upsample_nearest": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "icaf_copy_channels": (_i, [_p, _i, _p, _i, _i, _ll, _i, _p]),
+    "icaf_dmff_pool_tokens": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                   _f, _f, _f, _f, _p]),
+    "icaf_layernorm": (_i, [_p, _p, _p, _p, _p, _p, _i, _ll, _i, _i, _f, _p]),
+    "icaf_cross_attention": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "icaf_dmff_upsample_merge": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "icaf_detect_decode": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _ll, _ll, _f, C.POINTER(_f), _p]),
+    "icaf_nms_workspace_bytes": (_i, [_i, _ll, _i, _i, C.POINTER(_sz)]),
+    "icaf_nms": (_i, [_p, _i, _ll, _i, _f, _f, _i, _i, C.POINTER(_i), _i, _i, _i, _f, _p, _p, _p, _p, _sz, _p]),
+    "icaf_graph_begin": (_i, [_p]),
+    "icaf_graph_end": (_i, [_p, C.POINTER(_p)]),
+    "icaf_graph_launch": (_i, [_p, _p]),
+    "icaf_graph_destroy": (_i, [_p]),
+    "icaf_event_create": (_i, [C.POINTER(_p)]),
+    "icaf_event_record": (_i, [_p, _p]),
+    "icaf_event_elapsed_ms": (_i, [_p, _p, C.POINTER(_f)]),
+    "icaf_event_destroy": (_i, [_p]),
+    "icaf_stream_sync": (_i, [_p]),
+}
+
+_LIB = None
+
+
+class IcafError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libicaf.so once; raise (never fall back) when it is absent or incomplete."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise IcafError(f"{LIB_PATH} not found — build it with `python -m icafusion_amd.build` "
+                            "(hipcc --offload-arch=gfx950); icafusion_amd has no CPU / PyTorch fallback")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise IcafError(f"libicaf.so does not export {name}; rebuild it") from e
+            fn.restype, fn.argtypes = res, args
+        _LIB = handle
+    return _LIB
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().icaf_last_error()
+        raise IcafError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,114 @@
+"""Static execution plan: the host-side runtime that replaces the reference's per-layer Python dispatch.
+
+The reference walks `self.model` in Python on every forward (models/yolo_test.py:136-163) and lets ATen allocate
+each intermediate.  Here a forward for a given (batch, height, width, dtype) is compiled once into a flat list of
+kernel launches over pre-allocated NHWC buffers (concats resolved to channel slices at build time), which is then
+either replayed launch by launch or captured into a hipGraph (icaf_graph_*) and replayed with one call.
+"""
+import torch
+
+from . import ops
+
+
+class ImageIn:
+    """Marks a raw NCHW fp32 network input (the only non-NHWC tensor on the path)."""
+
+    def __init__(self, tensor):
+        assert tensor.dim() == 4
+        self.t = tensor
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+
+class Plan:
+    def __init__(self, device, dtype):
+        self.device, self.dtype = torch.device(device), dtype
+        self.launches = []
+        self.inputs = []        # static input tensors, filled by the caller before run()
+        self.outputs = None
+        self.graph = None
+        self.nbytes = 0
+
+    # -- buffers ------------------------------------------------------------------------------------------
+    def act(self, B, H, W, C, dtype=None):
+        t = torch.zeros((B, H, W, C), dtype=dtype or self.dtype, device=self.device)
+        self.nbytes += t.numel() * t.element_size()
+        return t
+
+    def tokens(self, G, rows, C, dtype=None):
+        t = torch.zeros((G, rows, C), dtype=dtype or self.dtype, device=self.device)
+        self.nbytes += t.numel() * t.element_size()
+        return t
+
+    def empty(self, shape, dtype):
+        t = torch.zeros(shape, dtype=dtype, device=self.device)
+        self.nbytes += t.numel() * t.element_size()
+        return t
+
+    def add(self, launch):
+        self.launches.append(launch)
+        return launch
+
+    # -- execution ----------------------------------------------------------------------------------------
+    def run(self, stream_ptr=None):
+        sp = stream_ptr if stream_ptr is not None else ops.current_stream_ptr()
+        if self.graph is not None:
+            self.graph.launch(sp)
+        else:
+            for l in self.launches:
+                l(sp)
+
+    def capture(self):
+        """Capture the launch list into a hipGraph on a side stream (legacy default stream cannot capture)."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        sp = side.cuda_stream
+        for l in self.launches:          # warm every kernel once outside capture (module load, first-touch)
+            l(sp)
+        side.synchronize()
+        g = ops.Graph()
+        g.capture(sp, lambda: [l(sp) for l in self.launches])
+        side.synchronize()
+        self.graph = g
+        return self
+
+    def timed_run(self, stream_ptr=None):
+        """Run launch by launch with a HIP event pair around every kernel; returns [(name, ms, flops, bytes)]."""
+        sp = stream_ptr if stream_ptr is not None else ops.current_stream_ptr()
+        evs = [ops.Event() for _ in range(len(self.launches) + 1)]
+        evs[0].record(sp)
+        for i, l in enumerate(self.launches):
+            l(sp)
+            evs[i + 1].record(sp)
+        out = []
+        for i, l in enumerate(self.launches):
+            out.append((l.name, evs[i].elapsed_ms(evs[i + 1]), l.flops, l.bytes))
+        return out
+
+
+def concat_view(xs):
+    """If the acts are adjacent channel slices of one buffer (in order), return the covering view, else None."""
+    first = xs[0]
+    es = first.element_size()
+    ptr = first.data_ptr()
+    total = 0
+    for t in xs:
+        if t.data_ptr() != ptr + total * es or t.stride() != first.stride() or t.shape[:3] != first.shape[:3]:
+            return None
+        total += t.shape[3]
+    if total > first.stride(2):
+        return None
+    B, H, W, _ = first.shape
+    return first.as_strided((B, H, W, total), first.stride())
+
+
+def to_act(x, dtype):
+    """NCHW torch tensor -> NHWC act in dtype (boundary plumbing for stand-alone module calls)."""
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype)
+
+
+def from_act(y):
+    """NHWC act -> NCHW-shaped tensor (channels_last memory, no copy)."""
+    return y.permute(0, 3, 1, 2)

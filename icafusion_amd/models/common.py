@@ -1,0 +1,554 @@
+"""Module library of the two-stream detector, MI355X edition.
+
+Same class names, constructor signatures, attribute names and state_dict keys as the reference's
+models/common.py (so `parse_model`'s name lookup, pickled checkpoints and `load_state_dict(strict=True)` keep
+working — SURVEY.md §8b), but the modules do no arithmetic themselves: each one *emits* HIP kernel launches into
+an `engine.Plan` over NHWC buffers.  `forward(x)` on a single module builds and runs a one-module plan, so the
+classes still duck-type as nn.Modules taking/returning NCHW-shaped tensors.
+
+There is deliberately no PyTorch / CPU fallback: calling a module with CPU tensors, in training mode, or without
+libicaf.so raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..engine import ImageIn, Plan, concat_view, from_act, to_act
+
+BN_EPS_DEFAULT = 1e-5
+
+
+def autopad(k, p=None):
+    """'same' padding for odd kernels (reference models/common.py:36-40)."""
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [v // 2 for v in k]
+    return p
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _module_dtype(m, fallback=torch.float32):
+    for p in m.parameters():
+        return p.dtype
+    return fallback
+
+
+class HipModule(nn.Module):
+    """Base: stand-alone execution of `emit` + packed-weight cache."""
+
+    def invalidate(self):
+        for m in self.modules():
+            if hasattr(m, "_cache"):
+                m._cache = {}
+            if hasattr(m, "_plans"):
+                m._plans = {}
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self.__dict__["_cache"] = {}
+        self.__dict__["_plans"] = {}
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.__dict__["_cache"] = {}
+        self.__dict__["_plans"] = {}
+        return r
+
+    def _cached(self, key, make):
+        c = self.__dict__.setdefault("_cache", {})
+        if key not in c:
+            c[key] = make()
+        return c[key]
+
+    # stand-alone call: NCHW tensor(s) in, NCHW-shaped tensor(s) out
+    def forward(self, x):
+        xs = x if isinstance(x, (list, tuple)) else [x]
+        if self.training:
+            raise NotImplementedError("icafusion_amd implements the eval-mode inference path only (call .eval())")
+        for t in xs:
+            if not t.is_cuda:
+                raise RuntimeError("icafusion_amd modules run on the MI355X only: move inputs to cuda "
+                                   "(there is no CPU fallback; the CPU reference lives in oracle/)")
+        dt = _module_dtype(self, xs[0].dtype)
+        key = (tuple(tuple(t.shape) for t in xs), dt, xs[0].device)
+        plans = self.__dict__.setdefault("_plans", {})
+        if key not in plans:
+            plan = Plan(xs[0].device, dt)
+            ins = []
+            for t in xs:
+                if t.shape[1] % ops.VEC[dt] != 0:
+                    buf = torch.zeros(t.shape, dtype=torch.float32, device=t.device)
+                    ins.append(ImageIn(buf))
+                else:
+                    ins.append(plan.act(t.shape[0], t.shape[2], t.shape[3], t.shape[1]))
+            plan.inputs = ins
+            plan.outputs = self.emit(plan, ins if isinstance(x, (list, tuple)) else ins[0])
+            plans[key] = plan
+        plan = plans[key]
+        for src, dst in zip(xs, plan.inputs):
+            if isinstance(dst, ImageIn):
+                dst.t.copy_(src)
+            else:
+                dst.copy_(src.permute(0, 2, 3, 1))
+        plan.run()
+        out = plan.outputs
+        if isinstance(out, torch.Tensor) and out.dim() == 4:
+            return from_act(out).clone(memory_format=torch.preserve_format)
+        return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# convolution family
+# ----------------------------------------------------------------------------------------------------------
+class Conv(HipModule):
+    """Conv2d(bias=False) + BatchNorm2d + SiLU (reference models/common.py:48-60).  On the device this is one
+    implicit-GEMM launch with BN folded into the packed weights (as utils/torch_utils.py:182-202 does offline) and
+    bias + SiLU in the epilogue; `fuse()`d modules (no .bn) are handled identically."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p), groups=g, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
+
+    def fuseforward(self, x):           # kept for API parity with Model.fuse(); same device path
+        return self.forward(x)
+
+    def _act_code(self):
+        if isinstance(self.act, nn.SiLU):
+            return ops.ACT_SILU
+        if isinstance(self.act, nn.Identity):
+            return ops.ACT_NONE
+        if isinstance(self.act, nn.GELU):
+            return ops.ACT_GELU
+        raise NotImplementedError(f"activation {type(self.act).__name__} is outside the hot path")
+
+    def folded(self):
+        """fp32 (weight, bias) with BatchNorm folded in."""
+        w = self.conv.weight.detach().float()
+        b = self.conv.bias.detach().float() if self.conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+        if hasattr(self, "bn"):
+            bn = self.bn
+            scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+            w = w * scale[:, None, None, None]
+            b = (b - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
+        return w, b
+
+    def emit(self, plan, x, out=None, res=None):
+        if self.conv.groups != 1 or self.conv.dilation != (1, 1):
+            raise NotImplementedError("grouped / dilated convolutions are outside the hot path")
+        kh, kw = self.conv.kernel_size
+        sh, sw = self.conv.stride
+        ph, pw = _pair(self.conv.padding)
+        c1, c2 = self.conv.in_channels, self.conv.out_channels
+        vec = ops.VEC[plan.dtype]
+        if isinstance(x, ImageIn):
+            B, _, H, W = x.shape
+            s2d = (kh, kw, sh, sw, ph, pw) == (6, 6, 2, 2, 2, 2) and H % 2 == 0 and W % 2 == 0
+            if s2d:                       # 6x6/s2/p2 over the image == 3x3/s1/p1 over space-to-depth(image)
+                cpad = -(-4 * c1 // vec) * vec
+                pre = plan.act(B, H // 2, W // 2, cpad)
+                plan.add(ops.preprocess(x.t, pre, 1, name="preprocess_s2d"))
+                key = ("s2d", plan.dtype, plan.device)
+
+                def make():
+                    w, b = self.folded()
+                    wp, kp = ops.pack_conv_weight(ops.s2d_conv_weight(w), plan.dtype, cpad)
+                    return wp, kp, ops.pack_bias(b, c2)
+                wp, kp, bp = self._cached(key, make)
+                x, c1, (kh, kw, sh, sw, ph, pw) = pre, cpad, (3, 3, 1, 1, 1, 1)
+            else:
+                cpad = -(-c1 // vec) * vec
+                pre = plan.act(B, H, W, cpad)
+                plan.add(ops.preprocess(x.t, pre, 0, name="preprocess_pad"))
+                key = ("pad", plan.dtype, plan.device)
+
+                def make():
+                    w, b = self.folded()
+                    wp, kp = ops.pack_conv_weight(w, plan.dtype, cpad)
+                    return wp, kp, ops.pack_bias(b, c2)
+                wp, kp, bp = self._cached(key, make)
+                x, c1 = pre, cpad
+        else:
+            if x.shape[3] != c1:
+                raise ValueError(f"Conv expects {c1} input channels, got {x.shape[3]}")
+            if c1 % vec:
+                raise NotImplementedError(f"channel count {c1} must be a multiple of {vec} for dtype {plan.dtype}")
+            key = ("std", plan.dtype, plan.device)
+
+            def make():
+                w, b = self.folded()
+                wp, kp = ops.pack_conv_weight(w, plan.dtype)
+                return wp, kp, ops.pack_bias(b, c2)
+            wp, kp, bp = self._cached(key, make)
+        B, H, W, _ = x.shape
+        Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+        if out is None:
+            out = plan.act(B, Ho, Wo, c2)
+        plan.add(ops.conv2d(x, wp, kp, bp, out, kh, kw, sh, sw, ph, pw, c1, c2, self._act_code(), res=res,
+                            name=f"conv{kh}x{kw}s{sh}"))
+        return out
+
+
+class Bottleneck(HipModule):
+    """1x1 -> 3x3 with optional identity shortcut (reference models/common.py:184-194); the shortcut add is the
+    residual term of the second conv's epilogue."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_, c2, 3, 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def emit(self, plan, x, out=None):
+        t = self.cv1.emit(plan, x)
+        return self.cv2.emit(plan, t, out=out, res=x if self.add else None)
+
+
+class C3(HipModule):
+    """CSP bottleneck with three convs (reference models/common.py:216-227).  The torch.cat is never
+    materialised: both branches write channel slices of one buffer that cv3 reads."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
+
+    def emit(self, plan, x, out=None):
+        B, H, W, _ = x.shape
+        c_ = self.cv1.conv.out_channels
+        cat = plan.act(B, H, W, 2 * c_)
+        n = len(self.m)
+        a = self.cv1.emit(plan, x, out=cat[..., :c_] if n == 0 else None)
+        for j, blk in enumerate(self.m):
+            a = blk.emit(plan, a, out=cat[..., :c_] if j == n - 1 else None)
+        self.cv2.emit(plan, x, out=cat[..., c_:])
+        return self.cv3.emit(plan, cat, out=out)
+
+
+class SPPF(HipModule):
+    """Spatial pyramid pooling - fast (reference models/common.py:252-267): the three chained max pools run as
+    one kernel writing the three extra channel groups of the buffer cv2 reads."""
+
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * 4, c2, 1, 1)
+        self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
+
+    def emit(self, plan, x, out=None):
+        B, H, W, _ = x.shape
+        c_ = self.cv1.conv.out_channels
+        k = self.m.kernel_size if isinstance(self.m.kernel_size, int) else self.m.kernel_size[0]
+        cat = plan.act(B, H, W, 4 * c_)
+        self.cv1.emit(plan, x, out=cat[..., :c_])
+        plan.add(ops.sppf_pool(cat[..., :c_], cat[..., c_:2 * c_], cat[..., 2 * c_:3 * c_], cat[..., 3 * c_:], k))
+        return self.cv2.emit(plan, cat, out=out)
+
+
+class Concat(HipModule):
+    """Channel concatenation (reference models/common.py:313-321).  When the producers already wrote adjacent
+    slices of one buffer (the normal case inside Model) this is free."""
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def emit(self, plan, xs, out=None):
+        if self.d != 1:
+            raise NotImplementedError("only channel concatenation is on the hot path")
+        v = concat_view(xs)
+        if v is not None and out is None:
+            return v
+        B, H, W, _ = xs[0].shape
+        if out is None:
+            out = plan.act(B, H, W, sum(t.shape[3] for t in xs))
+        c0 = 0
+        for t in xs:
+            plan.add(ops.copy_channels(t, out[..., c0:c0 + t.shape[3]]))
+            c0 += t.shape[3]
+        return out
+
+
+def emit_upsample(m, plan, x, out=None):
+    """nn.Upsample(None, 2, 'nearest') rows of the head (yaml rows 24 / 28)."""
+    if m.mode != "nearest" or m.scale_factor is None or float(m.scale_factor) != int(m.scale_factor):
+        raise NotImplementedError("only integer-factor nearest upsampling is on the hot path")
+    s = int(m.scale_factor)
+    B, H, W, C = x.shape
+    if out is None:
+        out = plan.act(B, H * s, W * s, C)
+    plan.add(ops.upsample_nearest(x, out, s))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# DMFF
+# ----------------------------------------------------------------------------------------------------------
+class LearnableCoefficient(nn.Module):
+    """Scalar gain, init 1 (reference models/common.py:569-576); folded into GEMM epilogue alphas."""
+
+    def __init__(self):
+        super().__init__()
+        self.bias = nn.Parameter(torch.FloatTensor([1.0]), requires_grad=True)
+
+
+class LearnableWeights(nn.Module):
+    """Two scalar mixing weights, init 0.5 (reference models/common.py:579-587)."""
+
+    def __init__(self):
+        super().__init__()
+        self.w1 = nn.Parameter(torch.tensor([0.5]), requires_grad=True)
+        self.w2 = nn.Parameter(torch.tensor([0.5]), requires_grad=True)
+
+
+class AdaptivePool2d(nn.Module):
+    """Fixed-output pooling with stride = in // out, kernel = in - (out-1)*stride (reference
+    models/common.py:868-891).  Holds geometry only; the arithmetic is in icaf_dmff_pool_tokens."""
+
+    def __init__(self, output_h, output_w, pool_type="avg"):
+        super().__init__()
+        self.output_h, self.output_w, self.pool_type = output_h, output_w, pool_type
+
+    def window(self, h, w):
+        """-> (out_h, out_w, kh, kw, sh, sw)"""
+        if h > self.output_h or w > self.output_w:
+            sh, sw = h // self.output_h, w // self.output_w
+            if sh == 0 or sw == 0:
+                raise ValueError(f"feature map {h}x{w} too small for {self.output_h}x{self.output_w} anchors")
+            return (self.output_h, self.output_w, h - (self.output_h - 1) * sh, w - (self.output_w - 1) * sw, sh, sw)
+        return h, w, 1, 1, 1, 1
+
+
+class CrossAttention(HipModule):
+    """Bidirectional cross-modal attention parameters (reference models/common.py:590-687)."""
+
+    def __init__(self, d_model, d_k, d_v, h, attn_pdrop=.1, resid_pdrop=.1):
+        super().__init__()
+        assert d_k % h == 0
+        self.d_model, self.h = d_model, h
+        self.d_k = self.d_v = d_model // h
+        for mod in ("vis", "ir"):
+            setattr(self, f"que_proj_{mod}", nn.Linear(d_model, h * self.d_k))
+            setattr(self, f"key_proj_{mod}", nn.Linear(d_model, h * self.d_k))
+            setattr(self, f"val_proj_{mod}", nn.Linear(d_model, h * self.d_v))
+        # registration order of the reference: 6 projections, then the two output projections
+        self.out_proj_vis = nn.Linear(h * self.d_v, d_model)
+        self.out_proj_ir = nn.Linear(h * self.d_v, d_model)
+        self.attn_drop = nn.Dropout(attn_pdrop)
+        self.resid_drop = nn.Dropout(resid_pdrop)
+        self.LN1 = nn.LayerNorm(d_model)
+        self.LN2 = nn.LayerNorm(d_model)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, std=0.001)
+                nn.init.constant_(m.bias, 0)
+
+
+def _mlp(d_model, block_exp, resid_pdrop):
+    return nn.Sequential(nn.Linear(d_model, block_exp * d_model), nn.GELU(),
+                         nn.Linear(block_exp * d_model, d_model), nn.Dropout(resid_pdrop))
+
+
+class CrossTransformerBlock(HipModule):
+    """One parameter-shared iterative cross-attention block (reference models/common.py:690-759).  `ln_input`,
+    `ln_output`, `mlp` and the block-level `LN1` exist only so that reference checkpoints load strictly; the
+    reference never uses them in forward."""
+
+    def __init__(self, d_model, d_k, d_v, h, block_exp, attn_pdrop, resid_pdrop, loops_num=1):
+        super().__init__()
+        self.loops = loops_num
+        self.ln_input = nn.LayerNorm(d_model)
+        self.ln_output = nn.LayerNorm(d_model)
+        self.crossatt = CrossAttention(d_model, d_k, d_v, h, attn_pdrop, resid_pdrop)
+        self.mlp_vis = _mlp(d_model, block_exp, resid_pdrop)
+        self.mlp_ir = _mlp(d_model, block_exp, resid_pdrop)
+        self.mlp = _mlp(d_model, block_exp, resid_pdrop)
+        self.LN1 = nn.LayerNorm(d_model)
+        self.LN2 = nn.LayerNorm(d_model)
+        for i in range(1, 9):
+            setattr(self, f"coefficient{i}", LearnableCoefficient())
+
+    # packed parameters: per-modality weight stacks [2][Np][Kp]
+    def _packed(self, plan):
+        def make():
+            ca = self.crossatt
+            dt, f = plan.dtype, (lambda t: t.detach().float())
+
+            def stack(ws, bs):
+                packs = [ops.pack_matrix(w, dt) for w in ws]
+                wp = torch.stack([p[0] for p in packs]).contiguous()
+                bp = torch.stack([ops.pack_bias(b, b.numel()) for b in bs]).contiguous()
+                return wp, packs[0][1], bp
+            qkv = stack([torch.cat([f(getattr(ca, f"{n}_proj_{m}").weight) for n in ("que", "key", "val")])
+                         for m in ("vis", "ir")],
+                        [torch.cat([f(getattr(ca, f"{n}_proj_{m}").bias) for n in ("que", "key", "val")])
+                         for m in ("vis", "ir")])
+            outp = stack([f(ca.out_proj_vis.weight), f(ca.out_proj_ir.weight)],
+                         [f(ca.out_proj_vis.bias), f(ca.out_proj_ir.bias)])
+            fc1 = stack([f(self.mlp_vis[0].weight), f(self.mlp_ir[0].weight)],
+                        [f(self.mlp_vis[0].bias), f(self.mlp_ir[0].bias)])
+            fc2 = stack([f(self.mlp_vis[2].weight), f(self.mlp_ir[2].weight)],
+                        [f(self.mlp_vis[2].bias), f(self.mlp_ir[2].bias)])
+            ln = {k: f(v).contiguous() for k, v in (("a1w", ca.LN1.weight), ("a1b", ca.LN1.bias),
+                                                    ("a2w", ca.LN2.weight), ("a2b", ca.LN2.bias),
+                                                    ("mw", self.LN2.weight), ("mb", self.LN2.bias))}
+            co = [float(getattr(self, f"coefficient{i}").bias.detach().float().cpu()) for i in range(1, 9)]
+            return dict(qkv=qkv, out=outp, fc1=fc1, fc2=fc2, ln=ln, co=co,
+                        eps=(ca.LN1.eps, ca.LN2.eps, self.LN2.eps))
+        return self._cached(("blk", plan.dtype, plan.device), make)
+
+    @staticmethod
+    def _gemm(plan, x, packed, y, cin, cout, act, res=None, alpha_acc=1.0, alpha_res=1.0, name="linear"):
+        wp, kp, bp = packed
+        rows = x.shape[1]
+        gs = dict(x=x.stride(0), w=wp.stride(0), bias=bp.stride(0), y=y.stride(0),
+                  res=res.stride(0) if res is not None else 0)
+        plan.add(ops.conv2d(x[0].view(rows, 1, 1, cin), wp, kp, bp, y[0].view(rows, 1, 1, cout), 1, 1, 1, 1, 0, 0,
+                            cin, cout, act, res=res[0].view(rows, 1, 1, cout) if res is not None else None,
+                            alpha_acc=alpha_acc, alpha_res=alpha_res, groups=2, group_strides=gs, name=name))
+
+    def emit_tokens(self, plan, tok, B, N):
+        """tok: (2, B*N, C) [0]=RGB [1]=IR -> same shape after `loops` shared-weight iterations."""
+        p = self._packed(plan)
+        C = tok.shape[2]
+        rows = tok.shape[1]
+        co, ln = p["co"], p["ln"]
+        hid = self.mlp_vis[0].out_features
+        for _ in range(int(self.loops)):
+            n1 = plan.tokens(2, rows, C)
+            plan.add(ops.layernorm(tok, n1, ln["a1w"], ln["a1b"], ln["a2w"], ln["a2b"], p["eps"][0], name="ln_attn"))
+            qkv = plan.tokens(2, rows, 3 * C)
+            self._gemm(plan, n1, p["qkv"], qkv, C, 3 * C, ops.ACT_NONE, name="qkv_proj")
+            att = plan.tokens(2, rows, C)
+            plan.add(ops.cross_attention(qkv, att, B, N, self.crossatt.h))
+            xatt = plan.tokens(2, rows, C)
+            self._gemm(plan, att, p["out"], xatt, C, C, ops.ACT_NONE, res=tok, alpha_res=(co[0], co[2]),
+                       alpha_acc=(co[1], co[3]), name="out_proj")
+            n2 = plan.tokens(2, rows, C)
+            plan.add(ops.layernorm(xatt, n2, ln["mw"], ln["mb"], ln["mw"], ln["mb"], p["eps"][2], name="ln_mlp"))
+            h = plan.tokens(2, rows, hid)
+            self._gemm(plan, n2, p["fc1"], h, C, hid, ops.ACT_GELU, name="mlp_fc1")
+            nxt = plan.tokens(2, rows, C)
+            self._gemm(plan, h, p["fc2"], nxt, hid, C, ops.ACT_NONE, res=xatt, alpha_res=(co[4], co[6]),
+                       alpha_acc=(co[5], co[7]), name="mlp_fc2")
+            tok = nxt
+        return tok
+
+
+class TransformerFusionBlock(HipModule):
+    """DMFF: Dual-Modality Feature Fusion (reference models/common.py:762-865).
+
+    Optional `loops_num` (5th positional after h/block_exp/n_layer in the reference's signature order is kept;
+    the yaml passes it as the 4th list element, see models/yolo.py) exposes the iterative parameter-shared loop
+    the reference wires but never surfaces (models/common.py:691,744)."""
+
+    def __init__(self, d_model, vert_anchors=16, horz_anchors=16, h=8, block_exp=4, n_layer=1, embd_pdrop=0.1,
+                 attn_pdrop=0.1, resid_pdrop=0.1, loops_num=1):
+        super().__init__()
+        self.n_embd, self.vert_anchors, self.horz_anchors = d_model, vert_anchors, horz_anchors
+        self.pos_emb_vis = nn.Parameter(torch.zeros(1, vert_anchors * horz_anchors, d_model))
+        self.pos_emb_ir = nn.Parameter(torch.zeros(1, vert_anchors * horz_anchors, d_model))
+        self.avgpool = AdaptivePool2d(vert_anchors, horz_anchors, "avg")
+        self.maxpool = AdaptivePool2d(vert_anchors, horz_anchors, "max")
+        self.vis_coefficient = LearnableWeights()
+        self.ir_coefficient = LearnableWeights()
+        self.crosstransformer = nn.Sequential(*[
+            CrossTransformerBlock(d_model, d_model, d_model, h, block_exp, attn_pdrop, resid_pdrop, loops_num)
+            for _ in range(n_layer)])
+        self.concat = Concat(dimension=1)
+        self.conv1x1_out = Conv(c1=d_model * 2, c2=d_model, k=1, s=1, p=0, g=1, act=True)
+
+    def emit(self, plan, xs, out=None):
+        rgb, ir = xs
+        B, H, W, C = rgb.shape
+        assert ir.shape == rgb.shape and C == self.n_embd
+        th, tw, kh, kw, sh, sw = self.avgpool.window(H, W)
+        N = th * tw
+        if N != self.pos_emb_vis.shape[1]:
+            raise ValueError(f"DMFF: {th}x{tw} tokens do not match the {self.pos_emb_vis.shape[1]} positional "
+                             "embeddings (input feature map smaller than the anchor grid)")
+
+        def make():
+            f = lambda t: t.detach().float().reshape(-1).contiguous()          # noqa: E731
+            wv, wi = self.vis_coefficient, self.ir_coefficient
+            return (f(self.pos_emb_vis), f(self.pos_emb_ir),
+                    (float(wv.w1.detach().float().cpu()), float(wv.w2.detach().float().cpu())),
+                    (float(wi.w1.detach().float().cpu()), float(wi.w2.detach().float().cpu())))
+        pos_v, pos_i, w_v, w_i = self._cached(("dmff", plan.device), make)
+        tok = plan.tokens(2, B * N, C)
+        plan.add(ops.dmff_pool_tokens(rgb, ir, pos_v, pos_i, tok, th, tw, kh, kw, sh, sw, w_v, w_i))
+        for blk in self.crosstransformer:
+            tok = blk.emit_tokens(plan, tok, B, N)
+        merged = plan.act(B, H, W, 2 * C)
+        plan.add(ops.dmff_upsample_merge(tok, rgb, ir, merged, th, tw))
+        return self.conv1x1_out.emit(plan, merged, out=out)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Detect
+# ----------------------------------------------------------------------------------------------------------
+class Detect(HipModule):
+    """Detection head (reference models/yolo_test.py:26-71).  Per level: 1x1 conv (fp32 output) + one decode
+    kernel that writes z / logits / the permuted raw map directly in their final layouts."""
+    stride = None
+    export = False
+
+    def __init__(self, nc=80, anchors=(), ch=()):
+        super().__init__()
+        self.nc, self.no = nc, nc + 5
+        self.nl, self.na = len(anchors), len(anchors[0]) // 2
+        self.grid = [torch.zeros(1)] * self.nl
+        a = torch.tensor(anchors).float().view(self.nl, -1, 2)
+        self.register_buffer("anchors", a)
+        self.register_buffer("anchor_grid", a.clone().view(self.nl, 1, -1, 1, 1, 2))
+        self.m = nn.ModuleList(nn.Conv2d(c, self.no * self.na, 1) for c in ch)
+
+    def emit(self, plan, xs):
+        B = xs[0].shape[0]
+        rows = sum(self.na * t.shape[1] * t.shape[2] for t in xs)
+        z = plan.empty((B, rows, self.no), torch.float32)
+        logits = plan.empty((B, rows, self.nc), torch.float32)
+        raws, off = [], 0
+        ag = self.anchor_grid.detach().float().cpu().view(self.nl, self.na * 2)
+        strides = [float(s) for s in self.stride]
+        for l, x in enumerate(xs):
+            _, ny, nx, c = x.shape
+            conv = self.m[l]
+            nout = self.na * self.no
+
+            def make(conv=conv):
+                wp, kp = ops.pack_conv_weight(conv.weight.detach().float(), plan.dtype)
+                return wp, kp, ops.pack_bias(conv.bias.detach().float(), conv.out_channels)
+            wp, kp, bp = self._cached(("det", l, plan.dtype, plan.device), make)
+            p = plan.act(B, ny, nx, nout, dtype=torch.float32)
+            plan.add(ops.conv2d(x, wp, kp, bp, p, 1, 1, 1, 1, 0, 0, c, nout, ops.ACT_NONE, name="detect_conv"))
+            raw = plan.empty((B, self.na, ny, nx, self.no), torch.float32)
+            plan.add(ops.detect_decode(p, z, logits, raw, self.na, self.no, off, strides[l], ag[l].tolist()))
+            raws.append(raw)
+            off += self.na * ny * nx
+        return z, logits, raws
+
+    def forward(self, xs):
+        if self.training:
+            raise NotImplementedError("Detect: training branch is outside the inference hot path")
+        dt = _module_dtype(self)
+        plan = Plan(xs[0].device, dt)
+        acts = [to_act(t, dt) for t in xs]
+        z, logits, raws = self.emit(plan, acts)
+        plan.run()
+        return z, logits, raws
+
+
+__all__ = ["autopad", "Conv", "Bottleneck", "C3", "SPPF", "Concat", "LearnableCoefficient", "LearnableWeights",
+           "AdaptivePool2d", "CrossAttention", "CrossTransformerBlock", "TransformerFusionBlock", "Detect",
+           "emit_upsample", "HipModule", "math"]

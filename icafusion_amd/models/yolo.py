@@ -1,0 +1,301 @@
+"""Two-stream model assembly: `Model(cfg, ch=3, nc=None, anchors=None)` with the reference's construction API.
+
+Semantics follow the reference's models/yolo_test.py (the file train.py / test.py actually import — the shipped
+models/yolo.py is single-stream and broken): `forward(x, x2, augment=False, profile=False)` returns
+`(z, logits, [raw x3])` in eval mode; layers carry `.i .f .type .np`; `from == -4` feeds the IR image; Detect
+strides are fixed to [8, 16, 32] (models/yolo_test.py:104).
+
+What differs is how a forward executes: the layer graph is compiled once per input shape into an `engine.Plan`
+(flat list of HIP launches over NHWC buffers, Concat inputs written in place, optional hipGraph replay) instead of
+being interpreted layer by layer in Python.
+"""
+import logging
+import math
+from copy import deepcopy
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..engine import ImageIn, Plan
+from .common import (C3, SPPF, Bottleneck, Concat, Conv, Detect, HipModule, TransformerFusionBlock,  # noqa: F401
+                     emit_upsample)
+
+logger = logging.getLogger(__name__)
+_NAMESPACE = {"Conv": Conv, "C3": C3, "SPPF": SPPF, "Bottleneck": Bottleneck, "Concat": Concat, "Detect": Detect,
+              "TransformerFusionBlock": TransformerFusionBlock, "nn": nn}
+
+
+def make_divisible(x, divisor):
+    return math.ceil(x / divisor) * divisor
+
+
+def check_anchor_order(m):
+    """Flip anchor order if it disagrees with stride order (reference utils/autoanchor.py:12-20)."""
+    a = m.anchor_grid.prod(-1).view(-1)
+    da, ds = a[-1] - a[0], m.stride[-1] - m.stride[0]
+    if da.sign() != ds.sign():
+        m.anchors[:] = m.anchors.flip(0)
+        m.anchor_grid[:] = m.anchor_grid.flip(0)
+
+
+def fuse_conv_and_bn(conv, bn):
+    """Offline Conv+BN fold with the reference's signature (utils/torch_utils.py:182-202)."""
+    fused = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                      groups=conv.groups, bias=True).requires_grad_(False).to(conv.weight.device, conv.weight.dtype)
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    fused.weight.copy_(conv.weight * scale[:, None, None, None])
+    b = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+    fused.bias.copy_((b - bn.running_mean) * scale + bn.bias)
+    return fused
+
+
+def parse_model(d, ch):
+    """yaml dict -> (nn.Sequential, save list).  Row format and channel arithmetic as the reference's
+    models/yolo_test.py:216-302, restricted to the module set of the *_Transfusion_* configs."""
+    anchors, nc, gd, gw = d["anchors"], d["nc"], d["depth_multiple"], d["width_multiple"]
+    na = (len(anchors[0]) // 2) if isinstance(anchors, list) else anchors
+    no = na * (nc + 5)
+    scope = dict(_NAMESPACE, nc=nc, anchors=anchors, **{"None": None})
+    layers, save, c2 = [], [], ch[-1]
+    for i, (f, n, m, args) in enumerate(d["backbone"] + d["head"]):
+        if isinstance(m, str):
+            try:
+                m = eval(m, {"__builtins__": {}}, scope)
+            except Exception as e:
+                raise NotImplementedError(f"module '{m}' is not part of the MI355X hot path (SURVEY.md §2)") from e
+        args = list(args)
+        for j, a in enumerate(args):
+            if isinstance(a, str):
+                try:
+                    args[j] = eval(a, {"__builtins__": {}}, scope)
+                except Exception:
+                    pass
+        n = max(round(n * gd), 1) if n > 1 else n
+        if m in (Conv, Bottleneck, SPPF, C3):
+            first_layer = m is Conv and args[0] == 64       # both stream stems take the 3-channel image (:240)
+            c1, c2 = (3 if first_layer else ch[f]), args[0]
+            if c2 != no:
+                c2 = make_divisible(c2 * gw, 8)
+            args = [c1, c2, *args[1:]]
+            if m is C3:
+                args.insert(2, n)
+                n = 1
+        elif m is Concat:
+            c2 = sum(ch[x] for x in f)
+        elif m is Detect:
+            args.append([ch[x] for x in f])
+            if isinstance(args[1], int):
+                args[1] = [list(range(args[1] * 2))] * len(f)
+        elif m is TransformerFusionBlock:
+            c2 = ch[f[0]]
+            extra = {"loops_num": args[3]} if len(args) > 3 else {}
+            args = [c2, *args[1:3]]
+            m_ = m(*args, **extra)
+        else:
+            c2 = ch[f]
+        if m is not TransformerFusionBlock:
+            m_ = nn.Sequential(*[m(*args) for _ in range(n)]) if n > 1 else m(*args)
+        t = str(m)[8:-2].replace("__main__.", "")
+        np_ = sum(x.numel() for x in m_.parameters())
+        m_.i, m_.f, m_.type, m_.np = i, f, t, np_
+        logger.info("%3s%18s%3s%10.0f  %-40s%-30s" % (i, f, n, np_, t, args))
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)
+
+
+def emit_any(m, plan, src, out=None):
+    """Emit one yaml row: our HipModules, torch's nn.Upsample, or an nn.Sequential repeat of either."""
+    if isinstance(m, nn.Upsample):
+        return emit_upsample(m, plan, src, out=out)
+    if isinstance(m, Detect):
+        return m.emit(plan, src)
+    if isinstance(m, nn.Sequential):
+        mods = list(m)
+        for j, sub in enumerate(mods):
+            src = emit_any(sub, plan, src, out if j == len(mods) - 1 else None)
+        return src
+    if not hasattr(m, "emit"):
+        raise NotImplementedError(f"layer type {type(m).__name__} is outside the hot path")
+    return m.emit(plan, src, out=out)
+
+
+class Model(HipModule):
+    def __init__(self, cfg="yolov5s.yaml", ch=3, nc=None, anchors=None):
+        super().__init__()
+        if isinstance(cfg, dict):
+            self.yaml = cfg
+        else:
+            import yaml
+            self.yaml_file = Path(cfg).name
+            with open(cfg) as f:
+                self.yaml = yaml.safe_load(f)
+        ch = self.yaml["ch"] = self.yaml.get("ch", ch)
+        if nc and nc != self.yaml["nc"]:
+            logger.info(f"Overriding model.yaml nc={self.yaml['nc']} with nc={nc}")
+            self.yaml["nc"] = nc
+        if anchors:
+            logger.info(f"Overriding model.yaml anchors with anchors={anchors}")
+            self.yaml["anchors"] = round(anchors)
+        self.model, self.save = parse_model(deepcopy(self.yaml), ch=[ch])
+        self.names = [str(i) for i in range(self.yaml["nc"])]
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            m.stride = torch.Tensor([8.0, 16.0, 32.0])
+            m.anchors /= m.stride.view(-1, 1, 1)
+            check_anchor_order(m)
+            self.stride = m.stride
+        for mod in self.modules():                      # utils/torch_utils.py:144-154 (initialize_weights)
+            if type(mod) is nn.BatchNorm2d:
+                mod.eps, mod.momentum = 1e-3, 0.03
+        self.use_graph = False       # replay each plan as one hipGraph launch
+        self.static_outputs = False  # return views of plan-owned buffers instead of clones
+
+    # -- reference API ----------------------------------------------------------------------------------------
+    def forward(self, x, x2, augment=False, profile=False):
+        if augment:
+            raise NotImplementedError("test-time augmentation is outside the hot path (reference models/yolo_test.py:116-132)")
+        return self.forward_once(x, x2, profile)
+
+    def fuse(self):
+        """Fold BatchNorm into the convs in place (reference models/yolo_test.py:182-190)."""
+        for m in self.model.modules():
+            if type(m) is Conv and hasattr(m, "bn"):
+                with torch.no_grad():
+                    m.conv = fuse_conv_and_bn(m.conv, m.bn)
+                delattr(m, "bn")
+        self.invalidate()
+        return self
+
+    def info(self, verbose=False, img_size=640):
+        n_p = sum(p.numel() for p in self.parameters())
+        logger.info(f"Model Summary: {len(list(self.modules()))} layers, {n_p} parameters")
+
+    # -- plan construction ------------------------------------------------------------------------------------
+    def _layer_shapes(self, B, H, W):
+        """Static (C, H, W) of every layer output, needed to place Concat inputs before they are produced."""
+        shapes, cur = [], None
+        for m in self.model:
+            f = m.f
+            if f == -4 or (f == -1 and m.i == 0):
+                src = (3, H, W)
+            elif f == -1:
+                src = cur
+            elif isinstance(f, int):
+                src = shapes[f]
+            else:
+                src = [cur if j == -1 else shapes[j] for j in f]
+            if isinstance(m, Conv):
+                k, s, p = m.conv.kernel_size[0], m.conv.stride[0], m.conv.padding[0]
+                cur = (m.conv.out_channels, (src[1] + 2 * p - k) // s + 1, (src[2] + 2 * p - k) // s + 1)
+            elif isinstance(m, (C3,)):
+                cur = (m.cv3.conv.out_channels, src[1], src[2])
+            elif isinstance(m, SPPF):
+                cur = (m.cv2.conv.out_channels, src[1], src[2])
+            elif isinstance(m, nn.Upsample):
+                s = int(m.scale_factor)
+                cur = (src[0], src[1] * s, src[2] * s)
+            elif isinstance(m, Concat):
+                cur = (sum(t[0] for t in src), src[0][1], src[0][2])
+            elif isinstance(m, TransformerFusionBlock):
+                cur = src[0]
+            elif isinstance(m, Detect):
+                cur = None
+            else:
+                raise NotImplementedError(f"layer type {type(m).__name__} is outside the hot path")
+            shapes.append(cur)
+        return shapes
+
+    def build_plan(self, B, H, W, device, dtype):
+        plan = Plan(device, dtype)
+        rgb = torch.zeros((B, 3, H, W), dtype=torch.float32, device=device)
+        ir = torch.zeros((B, 3, H, W), dtype=torch.float32, device=device)
+        plan.inputs = [rgb, ir]
+        shapes = self._layer_shapes(B, H, W)
+        # Concat placement: producer layer index -> (concat buffer, channel offset)
+        placement, cat_bufs = {}, {}
+        for m in self.model:
+            if isinstance(m, Concat) and not isinstance(m.f, int):
+                srcs = [m.i - 1 if j == -1 else j for j in m.f]
+                if any(s in placement for s in srcs):
+                    continue                       # a producer can live in only one concat buffer
+                C, h, w = shapes[m.i]
+                buf = plan.act(B, h, w, C)
+                cat_bufs[m.i] = buf
+                off = 0
+                for s in srcs:
+                    placement[s] = (buf, off, shapes[s][0])
+                    off += shapes[s][0]
+        y, x = [], None
+        for m in self.model:
+            f = m.f
+            if f == -4:
+                src = ImageIn(ir)
+            elif f == -1:
+                src = ImageIn(rgb) if m.i == 0 else x
+            elif isinstance(f, int):
+                src = y[f]
+            else:
+                src = [x if j == -1 else y[j] for j in f]
+            out = None
+            if m.i in placement:
+                buf, off, c = placement[m.i]
+                out = buf[..., off:off + c]
+            x = emit_any(m, plan, src, out)
+            y.append(x)
+        plan.outputs = x
+        return plan
+
+    def forward_once(self, x, x2, profile=False):
+        if self.training:
+            raise NotImplementedError("icafusion_amd implements the eval-mode inference path only (call .eval())")
+        if not (x.is_cuda and x2.is_cuda):
+            raise RuntimeError("icafusion_amd.Model runs on the MI355X only: move the model and inputs to cuda "
+                               "(no CPU fallback exists; the CPU reference is oracle/icaf_oracle.py, test-only)")
+        if x.shape != x2.shape:
+            raise ValueError(f"RGB and IR batches must match, got {tuple(x.shape)} vs {tuple(x2.shape)}")
+        dt = next(self.parameters()).dtype
+        B, _, H, W = x.shape
+        if H % 32 or W % 32:
+            raise ValueError(f"input size {H}x{W} must be a multiple of the max stride 32")
+        key = (B, H, W, dt, x.device)
+        plans = self.__dict__.setdefault("_plans", {})
+        if key not in plans:
+            plan = self.build_plan(B, H, W, x.device, dt)
+            if self.use_graph:
+                plan.capture()
+            plans[key] = plan
+        plan = plans[key]
+        if x.data_ptr() != plan.inputs[0].data_ptr():
+            plan.inputs[0].copy_(x)
+        if x2.data_ptr() != plan.inputs[1].data_ptr():
+            plan.inputs[1].copy_(x2)
+        if profile:
+            for name, ms, flops, nbytes in plan.timed_run():
+                logger.info(f"{ms:10.3f} ms {flops / 1e9:10.2f} GFLOP  {name}")
+        else:
+            plan.run()
+        z, logits, raws = plan.outputs
+        if self.static_outputs:
+            return z, logits, raws
+        return z.clone(), logits.clone(), [r.clone() for r in raws]
+
+    def plan_for(self, B, H, W, device="cuda", dtype=None):
+        """Pre-build (and return) the execution plan; its .inputs are the static RGB / IR staging buffers."""
+        dt = dtype or next(self.parameters()).dtype
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        key = (B, H, W, dt, device)
+        plans = self.__dict__.setdefault("_plans", {})
+        if key not in plans:
+            plan = self.build_plan(B, H, W, device, dt)
+            if self.use_graph:
+                plan.capture()
+            plans[key] = plan
+        return plans[key]

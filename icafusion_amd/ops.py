@@ -1,0 +1,319 @@
+"""Thin torch-tensor front end over the C ABI (include/icaf.h).
+
+Activation tensors ("acts") are torch views of shape (B, H, W, C) whose last dim is contiguous and whose pixel
+stride ld = t.stride(2) may exceed C (channel slice of a wider NHWC buffer).  Every function here either launches
+one kernel on a stream or returns a `Launch` record that does so later (used by the static execution plan).
+PyTorch only provides device memory and streams here — none of its operators run on the hot path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvArgs, check, lib, F32, BF16, F16, ACT_NONE, ACT_SILU, ACT_GELU  # noqa: F401
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+VEC = {torch.float32: 4, torch.bfloat16: 8, torch.float16: 8}     # elements per 16-byte vector
+N_ALIGN = 128     # packed-weight rows are padded to this (largest BN tile)
+K_ALIGN_BYTES = 128
+
+
+def dtype_code(dt):
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise _lib.IcafError(f"unsupported dtype {dt}; supported: float32, bfloat16, float16") from None
+
+
+def k_align(dt):
+    return K_ALIGN_BYTES // torch.empty((), dtype=dt).element_size()
+
+
+def current_stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _act_geom(t):
+    assert t.dim() == 4 and t.stride(3) == 1, f"act must be NHWC-contiguous in C, got {t.shape} {t.stride()}"
+    B, H, W, Cc = t.shape
+    ld = t.stride(2)
+    assert t.stride(1) == W * ld and (B == 1 or t.stride(0) == H * W * ld), f"bad act strides {t.stride()}"
+    return B, H, W, Cc, ld
+
+
+class Launch:
+    """One recorded kernel launch: fn(*args, stream)."""
+    __slots__ = ("fn", "args", "keep", "name", "flops", "bytes")
+
+    def __init__(self, fn, args, keep=(), name="", flops=0, nbytes=0):
+        self.fn, self.args, self.keep, self.name, self.flops, self.bytes = fn, args, keep, name, flops, nbytes
+
+    def __call__(self, stream_ptr):
+        st = self.fn(*self.args, stream_ptr)
+        if st != 0:
+            check(st, self.name)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# weight packing (one-time, at plan build; not on the hot path)
+# ------------------------------------------------------------------------------------------------------------
+def pack_matrix(w2d, dt):
+    """[Cout][K] fp32 -> zero-padded [Np][Kp] in dtype dt (K-major rows)."""
+    n, k = w2d.shape
+    ka = k_align(dt)
+    np_, kp = -(-n // N_ALIGN) * N_ALIGN, -(-k // ka) * ka
+    out = torch.zeros((np_, kp), dtype=dt, device=w2d.device)
+    out[:n, :k] = w2d.to(dt)
+    return out, kp
+
+
+def pack_bias(b, n):
+    np_ = -(-n // N_ALIGN) * N_ALIGN
+    out = torch.zeros((np_,), dtype=torch.float32, device=b.device)
+    out[:n] = b.float()
+    return out
+
+
+def pack_conv_weight(w4d, dt, cin_pad=None):
+    """[Cout][Cin][kh][kw] -> [Np][Kp] with k = (kh, kw, cin) and cin padded to cin_pad."""
+    co, ci, kh, kw = w4d.shape
+    w = w4d.permute(0, 2, 3, 1)
+    if cin_pad is not None and cin_pad != ci:
+        w = torch.nn.functional.pad(w, (0, cin_pad - ci))
+    return pack_matrix(w.reshape(co, -1).contiguous(), dt)
+
+
+def s2d_conv_weight(w4d):
+    """6x6/s2/p2 kernel over C channels -> equivalent 3x3/s1/p1 kernel over the 4C space-to-depth channels
+    ordered (dy, dx, c):  W3[co][(dy*2+dx)*C + c][ty][tx] = W[co][c][2ty+dy][2tx+dx]."""
+    co, ci, kh, kw = w4d.shape
+    assert kh == 6 and kw == 6
+    w = w4d.reshape(co, ci, 3, 2, 3, 2)                  # co, c, ty, dy, tx, dx
+    return w.permute(0, 3, 5, 1, 2, 4).reshape(co, 4 * ci, 3, 3).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# launches
+# ------------------------------------------------------------------------------------------------------------
+def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res=None, alpha_acc=1.0,
+           alpha_res=1.0, groups=1, group_strides=None, tile=0, name="conv2d"):
+    """Record an implicit-GEMM conv / linear.  x, y, res are acts; for groups=2 they are the group-0 views and
+    group_strides = dict(x=, w=, bias=, y=, res=) gives element strides to group 1."""
+    B, H, W, cx, ldx = _act_geom(x)
+    By, Ho, Wo, cy, ldy = _act_geom(y)
+    assert cx >= cin and cy >= cout and By == B
+    assert Ho == (H + 2 * ph - kh) // sh + 1 and Wo == (W + 2 * pw - kw) // sw + 1, "conv geometry mismatch"
+    a = ConvArgs()
+    a.x, a.w, a.y = x.data_ptr(), w_packed.data_ptr(), y.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.res = res.data_ptr() if res is not None else None
+    gs = group_strides or {}
+    a.x_gs, a.w_gs, a.bias_gs = gs.get("x", 0), gs.get("w", 0), gs.get("bias", 0)
+    a.y_gs, a.res_gs = gs.get("y", 0), gs.get("res", 0)
+    a.groups = groups
+    a.B, a.H, a.W, a.Cin, a.ldx = B, H, W, cin, ldx
+    a.Ho, a.Wo, a.Cout, a.ldy = Ho, Wo, cout, ldy
+    a.kh, a.kw, a.sh, a.sw, a.ph, a.pw = kh, kw, sh, sw, ph, pw
+    a.ldr = _act_geom(res)[4] if res is not None else 0
+    a.Kp, a.act = kp, act
+    a.dtype, a.out_dtype = dtype_code(x.dtype), dtype_code(y.dtype)
+    assert w_packed.dtype == x.dtype and (res is None or res.dtype == x.dtype)
+    aa = alpha_acc if isinstance(alpha_acc, (tuple, list)) else (alpha_acc, alpha_acc)
+    ar = alpha_res if isinstance(alpha_res, (tuple, list)) else (alpha_res, alpha_res)
+    a.alpha_acc[0], a.alpha_acc[1] = float(aa[0]), float(aa[1])
+    a.alpha_res[0], a.alpha_res[1] = float(ar[0]), float(ar[1])
+    a.tile = tile
+    m = B * Ho * Wo
+    flops = 2.0 * m * cout * kh * kw * cin * groups
+    es, eo = x.element_size(), y.element_size()
+    nbytes = groups * (B * H * W * cin * es + cout * kh * kw * cin * es + m * cout * eo
+                       + (m * cout * es if res is not None else 0))
+    return Launch(lib().icaf_conv2d, (C.byref(a),), keep=(a, x, w_packed, bias, y, res), name=name, flops=flops,
+                  nbytes=nbytes)
+
+
+def conv_kernel_name(launch):
+    buf = C.create_string_buffer(256)
+    check(lib().icaf_conv2d_kernel_name(launch.args[0], buf, 256), "icaf_conv2d_kernel_name")
+    return buf.value.decode()
+
+
+def preprocess(img, out, mode, name="preprocess"):
+    """img: (B, C, H, W) fp32 NCHW contiguous; out: act (B, H', W', Cpad)."""
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    B, Cc, H, W = img.shape
+    Bo, Ho, Wo, cpad, ldo = _act_geom(out)
+    assert ldo == cpad and Bo == B
+    assert (Ho, Wo) == ((H // 2, W // 2) if mode == 1 else (H, W))
+    nb = img.numel() * 4 + out.numel() * out.element_size()
+    return Launch(lib().icaf_preprocess_nchw, (img.data_ptr(), out.data_ptr(), dtype_code(out.dtype), B, Cc, H, W,
+                                               cpad, mode), keep=(img, out), name=name, nbytes=nb)
+
+
+def sppf_pool(x, y1, y2, y3, k, name="sppf_pool"):
+    B, H, W, Cc, ldx = _act_geom(x)
+    ldy = _act_geom(y1)[4]
+    assert _act_geom(y2)[4] == ldy and _act_geom(y3)[4] == ldy
+    nb = 4 * x.numel() * x.element_size()
+    return Launch(lib().icaf_sppf_pool, (x.data_ptr(), ldx, y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), ldy,
+                                         dtype_code(x.dtype), B, H, W, Cc, k), keep=(x, y1, y2, y3), name=name,
+                  nbytes=nb)
+
+
+def upsample_nearest(x, y, scale, name="upsample_nearest"):
+    B, H, W, Cc, ldx = _act_geom(x)
+    By, Hy, Wy, Cy, ldy = _act_geom(y)
+    assert (Hy, Wy, Cy) == (H * scale, W * scale, Cc)
+    nb = (x.numel() + y.numel()) * x.element_size()
+    return Launch(lib().icaf_upsample_nearest, (x.data_ptr(), ldx, y.data_ptr(), ldy, dtype_code(x.dtype), B, H, W,
+                                                Cc, scale), keep=(x, y), name=name, nbytes=nb)
+
+
+def copy_channels(x, y, name="copy_channels"):
+    B, H, W, Cc, ldx = _act_geom(x)
+    ldy = _act_geom(y)[4]
+    assert y.shape == x.shape
+    nb = 2 * x.numel() * x.element_size()
+    return Launch(lib().icaf_copy_channels, (x.data_ptr(), ldx, y.data_ptr(), ldy, dtype_code(x.dtype),
+                                             B * H * W, Cc), keep=(x, y), name=name, nbytes=nb)
+
+
+def dmff_pool_tokens(fea_rgb, fea_ir, pos_rgb, pos_ir, tokens, th, tw, kh, kw, sh, sw, w_rgb, w_ir,
+                     name="dmff_pool_tokens"):
+    B, H, W, Cc, ld0 = _act_geom(fea_rgb)
+    ld1 = _act_geom(fea_ir)[4]
+    assert tokens.shape == (2, B * th * tw, Cc) and tokens.is_contiguous()
+    assert pos_rgb.dtype == torch.float32 and pos_rgb.numel() == th * tw * Cc
+    nb = 2 * fea_rgb.numel() * fea_rgb.element_size() + tokens.numel() * tokens.element_size()
+    return Launch(lib().icaf_dmff_pool_tokens,
+                  (fea_rgb.data_ptr(), ld0, fea_ir.data_ptr(), ld1, pos_rgb.data_ptr(), pos_ir.data_ptr(),
+                   tokens.data_ptr(), dtype_code(tokens.dtype), B, H, W, Cc, th, tw, kh, kw, sh, sw,
+                   float(w_rgb[0]), float(w_rgb[1]), float(w_ir[0]), float(w_ir[1])),
+                  keep=(fea_rgb, fea_ir, pos_rgb, pos_ir, tokens), name=name, nbytes=nb)
+
+
+def layernorm(x, y, g0, b0, g1, b1, eps=1e-5, name="layernorm"):
+    """x, y: (G, rows, C) contiguous; group g normalised with (g_g, b_g) fp32 vectors."""
+    G, rows, Cc = x.shape
+    assert x.is_contiguous() and y.is_contiguous() and y.shape == x.shape
+    nb = 2 * x.numel() * x.element_size()
+    return Launch(lib().icaf_layernorm, (x.data_ptr(), y.data_ptr(), g0.data_ptr(), b0.data_ptr(), g1.data_ptr(),
+                                         b1.data_ptr(), dtype_code(x.dtype), rows, Cc, G, float(eps)),
+                  keep=(x, y, g0, b0, g1, b1), name=name, nbytes=nb)
+
+
+def cross_attention(qkv, out, B, N, heads, name="cross_attention"):
+    """qkv: (2, B*N, 3C); out: (2, B*N, C)."""
+    G, rows, c3 = qkv.shape
+    Cc = c3 // 3
+    assert G == 2 and rows == B * N and out.shape == (2, rows, Cc) and qkv.is_contiguous() and out.is_contiguous()
+    flops = 2 * B * heads * 4.0 * N * N * (Cc // heads)
+    nb = (qkv.numel() + out.numel()) * qkv.element_size()
+    return Launch(lib().icaf_cross_attention, (qkv.data_ptr(), out.data_ptr(), dtype_code(qkv.dtype), B, N, Cc,
+                                               heads), keep=(qkv, out), name=name, flops=flops, nbytes=nb)
+
+
+def dmff_upsample_merge(tokens, fea_rgb, fea_ir, out, th, tw, name="dmff_upsample_merge"):
+    B, H, W, Cc, ld0 = _act_geom(fea_rgb)
+    ld1 = _act_geom(fea_ir)[4]
+    Bo, Ho, Wo, Co, ldo = _act_geom(out)
+    assert (Bo, Ho, Wo, Co) == (B, H, W, 2 * Cc) and tokens.shape == (2, B * th * tw, Cc)
+    nb = (2 * fea_rgb.numel() + out.numel()) * out.element_size()
+    return Launch(lib().icaf_dmff_upsample_merge,
+                  (tokens.data_ptr(), fea_rgb.data_ptr(), ld0, fea_ir.data_ptr(), ld1, out.data_ptr(), ldo,
+                   dtype_code(out.dtype), B, H, W, Cc, th, tw), keep=(tokens, fea_rgb, fea_ir, out), name=name,
+                  nbytes=nb)
+
+
+def detect_decode(p, z, logits, raw, na, no, row_offset, stride, anchors_px, name="detect_decode"):
+    """p: fp32 act (B, ny, nx, >=na*no); z: (B, rows_total, no); raw: (B, na, ny, nx, no)."""
+    B, ny, nx, cp, ldp = _act_geom(p)
+    assert p.dtype == torch.float32 and z.dtype == torch.float32 and z.is_contiguous()
+    arr = (C.c_float * (2 * na))(*[float(v) for v in anchors_px])
+    nb = p.numel() * 4 + 3 * B * na * ny * nx * no * 4
+    return Launch(lib().icaf_detect_decode,
+                  (p.data_ptr(), ldp, z.data_ptr(), logits.data_ptr() if logits is not None else None,
+                   raw.data_ptr() if raw is not None else None, B, ny, nx, na, no, z.shape[1], row_offset,
+                   float(stride), arr), keep=(p, z, logits, raw, arr), name=name, nbytes=nb)
+
+
+class NmsRunner:
+    """Pre-allocated NMS launch for a fixed (B, rows, nc) — graph-capturable; results stay on the device."""
+
+    def __init__(self, B, rows, nc, device, multi_label=False, max_det=300):
+        self.B, self.rows, self.nc, self.max_det = B, rows, nc, max_det
+        self.multi_label = bool(multi_label) and nc > 1
+        sz = C.c_size_t(0)
+        check(lib().icaf_nms_workspace_bytes(B, rows, nc, int(self.multi_label), C.byref(sz)), "nms_workspace")
+        self.ws = torch.empty((max(sz.value, 16),), dtype=torch.uint8, device=device)
+        self.det = torch.zeros((B, max_det, 6), dtype=torch.float32, device=device)
+        self.count = torch.zeros((B,), dtype=torch.int32, device=device)
+        self.keep = torch.zeros((B, max_det), dtype=torch.int32, device=device)
+
+    def launch(self, pred, conf_thres, iou_thres, agnostic=False, classes=None, max_nms=30000, max_wh=4096.0,
+               stream_ptr=None):
+        assert pred.dtype == torch.float32 and pred.is_contiguous() and pred.shape == (self.B, self.rows, 5 + self.nc)
+        cls_arr, ncls = None, 0
+        if classes is not None:
+            ncls = len(classes)
+            cls_arr = (C.c_int * max(ncls, 1))(*[int(c) for c in classes])
+        st = lib().icaf_nms(pred.data_ptr(), self.B, self.rows, self.nc, float(conf_thres), float(iou_thres),
+                            int(self.multi_label), int(bool(agnostic)), cls_arr, ncls, self.max_det, int(max_nms),
+                            float(max_wh), self.det.data_ptr(), self.count.data_ptr(), self.keep.data_ptr(),
+                            self.ws.data_ptr(), self.ws.numel(),
+                            stream_ptr if stream_ptr is not None else current_stream_ptr())
+        check(st, "icaf_nms")
+        return self.det, self.count, self.keep
+
+
+# ------------------------------------------------------------------------------------------------------------
+# graph capture + events
+# ------------------------------------------------------------------------------------------------------------
+class Graph:
+    def __init__(self):
+        self.exec = C.c_void_p(None)
+
+    def capture(self, stream_ptr, fn):
+        check(lib().icaf_graph_begin(stream_ptr), "graph_begin")
+        try:
+            fn()
+        finally:
+            st = lib().icaf_graph_end(stream_ptr, C.byref(self.exec))
+        check(st, "graph_end")
+
+    def launch(self, stream_ptr):
+        check(lib().icaf_graph_launch(self.exec, stream_ptr), "graph_launch")
+
+    def __del__(self):
+        try:
+            if self.exec:
+                lib().icaf_graph_destroy(self.exec)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.ev = C.c_void_p(None)
+        check(lib().icaf_event_create(C.byref(self.ev)), "event_create")
+
+    def record(self, stream_ptr):
+        check(lib().icaf_event_record(self.ev, stream_ptr), "event_record")
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float(0)
+        check(lib().icaf_event_elapsed_ms(self.ev, stop.ev, C.byref(ms)), "event_elapsed")
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().icaf_event_destroy(self.ev)
+        except Exception:
+            pass
+
+
+def device_info():
+    cu, lds = C.c_int(0), C.c_int(0)
+    buf = C.create_string_buffer(64)
+    check(lib().icaf_device_info(C.byref(cu), C.byref(lds), buf, 64), "device_info")
+    return {"cu_count": cu.value, "lds_bytes": lds.value, "arch": buf.value.decode()}

@@ -1,0 +1,164 @@
+/*
+ * icaf.h — C ABI of libicaf.so, the MI355X (gfx950) implementation of ICAFusion's inference hot path.
+ *
+ * The reference (chanchanchan97/ICAFusion) is pure Python on PyTorch: it has no FFI / plugin layer to mirror
+ * (SURVEY.md §8b).  Its "operator interface" for this path is the set of nn.Module forwards in
+ * models/common.py and models/yolo_test.py plus utils/general.non_max_suppression; each entry point below
+ * replaces the arithmetic of one of those (file:line cited per function, paths relative to the reference root).
+ * The host side (icafusion_amd/models/*.py) keeps the reference's Python class names and constructor signatures
+ * and calls these functions through ctypes — see INTEGRATION.md for the binding stub.
+ *
+ * Conventions
+ *   - every pointer named x/y/w/... is a DEVICE pointer unless the comment says "host";
+ *   - activations are NHWC ("channels-last"): element (b,h,w,c) lives at ((b*H + h)*W + w)*ld + c, where the
+ *     pixel stride `ld` >= C lets a tensor be a channel slice of a wider buffer (this is how Concat, C3's
+ *     torch.cat and SPPF's torch.cat are eliminated);
+ *   - dtype codes select the storage/compute type of activations and packed weights; accumulation, bias,
+ *     normalisation statistics, softmax and the Detect/NMS arithmetic are always fp32;
+ *   - kernels are enqueued on the caller's HIP stream (hipStream_t passed as void*), never synchronise, never
+ *     allocate;
+ *   - return value 0 = ok, negative = error; icaf_last_error() returns a thread-local message.
+ */
+#ifndef ICAF_H
+#define ICAF_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* icaf_stream_t; /* hipStream_t */
+
+enum { ICAF_F32 = 0, ICAF_BF16 = 1, ICAF_F16 = 2 };
+enum { ICAF_ACT_NONE = 0, ICAF_ACT_SILU = 1, ICAF_ACT_GELU = 2 };
+enum { ICAF_OK = 0, ICAF_ERR_ARG = -1, ICAF_ERR_HIP = -2, ICAF_ERR_UNSUPPORTED = -3 };
+
+const char* icaf_last_error(void);
+int icaf_version(void);
+/* device facts used by the host for grid sizing / reporting: CU count, LDS bytes per workgroup, gcnArchName */
+int icaf_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* ---- input staging -------------------------------------------------------------------------------------
+ * Reference: detect_twostream.py:70-80 / test.py:116-123 hand the model NCHW float tensors in [0,1].
+ * mode 0: NCHW fp32 -> NHWC `dtype`, channels zero-padded from C to Cpad.
+ * mode 1: NCHW fp32 -> space-to-depth NHWC: out[b][h/2][w/2][(dy*2+dx)*C + c] = in[b][c][h][w], padded to
+ *         Cpad.  A 6x6 / stride-2 / pad-2 convolution over the image (first layer of each stream,
+ *         models/transformer/*.yaml row 0 and 10) equals a 3x3 / stride-1 / pad-1 convolution over this tensor.
+ */
+int icaf_preprocess_nchw(const float* img, void* out, int dtype, int B, int C, int H, int W, int Cpad, int mode,
+                         icaf_stream_t s);
+
+/* ---- implicit-GEMM convolution / linear ------------------------------------------------------------------
+ * Replaces Conv.forward / fuseforward (models/common.py:48-60: SiLU(BN(Conv2d))) with BN folded into the
+ * weights (utils/torch_utils.py:182-202), nn.Linear (+GELU) inside CrossAttention / CrossTransformerBlock
+ * (models/common.py:607-618,704-709), the residual add of Bottleneck (models/common.py:194) and the
+ * LearnableCoefficient mixes (models/common.py:746-750), and Detect's 1x1 output convs (models/yolo_test.py:50).
+ *
+ *   y[m][n] = alpha_res * res[m][n] + alpha_acc * act( sum_k A[m][k] * Wp[n][k] + bias[n] )
+ *
+ * m = (b, ho, wo) output pixel, k = (kh, kw, cin) gathered on the fly from x (zero outside the image),
+ * Wp = packed weights [Np][Kp] (K-major, Np = Cout rounded up to 128, Kp = K rounded up to 64 elements, zero
+ * padded).  `groups` > 1 batches independent problems (the two modalities of DMFF) in gridDim.z; the *_gs
+ * fields are the per-group strides in ELEMENTS (bytes/sizeof for x,w,y,res; floats for bias).
+ */
+typedef struct icaf_conv_args {
+    const void* x;
+    const void* w;
+    const float* bias; /* may be NULL */
+    void* y;
+    const void* res; /* may be NULL */
+    long long x_gs, w_gs, bias_gs, y_gs, res_gs;
+    int groups;
+    int B, H, W, Cin, ldx;
+    int Ho, Wo, Cout, ldy;
+    int kh, kw, sh, sw, ph, pw;
+    int ldr;
+    int Kp;
+    int act;
+    int dtype;     /* x, w, res */
+    int out_dtype; /* y: same as dtype, or ICAF_F32 */
+    float alpha_acc[2];
+    float alpha_res[2];
+    int tile; /* 0 = auto; otherwise force a tile config id (tuning / tests) */
+} icaf_conv_args;
+
+int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s);
+/* name of the kernel instantiation icaf_conv2d would launch for these args (host string, for profiling) */
+int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int buf_len);
+
+/* ---- SPPF / upsample / copy ------------------------------------------------------------------------------
+ * icaf_sppf_pool: the three chained k x k stride-1 max pools of SPPF.forward (models/common.py:262-267);
+ *   y1 = mp(x), y2 = mp(y1), y3 = mp(y2) computed in one pass (-inf padding semantics).
+ * icaf_upsample_nearest: nn.Upsample(None, scale, 'nearest') rows of the head (yaml rows 24, 28).
+ * icaf_copy_channels: generic channel-slice copy (fallback for Concat, models/common.py:313-321).
+ */
+int icaf_sppf_pool(const void* x, int ldx, void* y1, void* y2, void* y3, int ldy, int dtype, int B, int H, int W,
+                   int C, int k, icaf_stream_t s);
+int icaf_upsample_nearest(const void* x, int ldx, void* y, int ldy, int dtype, int B, int H, int W, int C,
+                          int scale, icaf_stream_t s);
+int icaf_copy_channels(const void* x, int ldx, void* y, int ldy, int dtype, long long rows, int C,
+                       icaf_stream_t s);
+
+/* ---- DMFF (TransformerFusionBlock, models/common.py:762-865) ---------------------------------------------
+ * icaf_dmff_pool_tokens: AdaptivePool2d avg + max (models/common.py:868-891), LearnableWeights mix
+ *   (:579-587) and positional embedding add (:817-823) for both modalities.
+ *   tokens[g][b][n][c] = w1_g*avg + w2_g*max + pos_g[n][c],  g = 0 (RGB) / 1 (IR),  n = th*W' + tw.
+ * icaf_layernorm: nn.LayerNorm(C), eps 1e-5 over the last dim; group g uses (gamma_g, beta_g)
+ *   (CrossAttention.LN1/LN2 :646,:651; CrossTransformerBlock.LN2 applied to both groups :749-750).
+ * icaf_cross_attention: the two crossed softmax(QK^T/sqrt(dk))V products of CrossAttention.forward (:670-685).
+ *   qkv[g][row][3C] holds [q | k | v] of modality g; out[0] = softmax(q_1 k_0^T) v_0, out[1] = softmax(q_0 k_1^T) v_1
+ *   with heads laid out as in .view(b, n, h, dk) (:647-649).
+ * icaf_dmff_upsample_merge: eval-mode F.interpolate(bilinear, align_corners=False) of the token maps back to
+ *   (H, W), residual add of the original features and channel concat (:827-840):
+ *   out[b][h][w][g*C + c] = bilinear(tokens[g])[b][h][w][c] + fea_g[b][h][w][c].
+ */
+int icaf_dmff_pool_tokens(const void* fea_rgb, int ld_rgb, const void* fea_ir, int ld_ir, const float* pos_rgb,
+                          const float* pos_ir, void* tokens, int dtype, int B, int H, int W, int C, int th, int tw,
+                          int kh, int kw, int sh, int sw, float w1_rgb, float w2_rgb, float w1_ir, float w2_ir,
+                          icaf_stream_t s);
+int icaf_layernorm(const void* x, void* y, const float* gamma0, const float* beta0, const float* gamma1,
+                   const float* beta1, int dtype, long long rows_per_group, int C, int groups, float eps,
+                   icaf_stream_t s);
+int icaf_cross_attention(const void* qkv, void* out, int dtype, int B, int N, int C, int heads, icaf_stream_t s);
+int icaf_dmff_upsample_merge(const void* tokens, const void* fea_rgb, int ld_rgb, const void* fea_ir, int ld_ir,
+                             void* out, int ldo, int dtype, int B, int H, int W, int C, int th, int tw,
+                             icaf_stream_t s);
+
+/* ---- Detect decode (models/yolo_test.py:43-65, eval branch) -----------------------------------------------
+ * p: fp32 output of the level's 1x1 conv, NHWC [B][ny][nx][ldp] with channel = a*no + o.
+ * Writes z[b][row_offset + (a*ny + y)*nx + x][o] (sigmoid + grid/anchor decode), logits (raw class scores,
+ * may be NULL) and raw[b][a][y][x][o] (the permuted pre-sigmoid map the reference also returns, may be NULL).
+ * anchors_px: host pointer to na*2 floats = anchor sizes in pixels (anchor_grid).
+ */
+int icaf_detect_decode(const float* p, int ldp, float* z, float* logits, float* raw, int B, int ny, int nx, int na,
+                       int no, long long rows_total, long long row_offset, float stride, const float* anchors_px,
+                       icaf_stream_t s);
+
+/* ---- NMS (utils/general.py:518-607 + torchvision.ops.nms semantics) ----------------------------------------
+ * pred: [B][rows][5+nc] fp32 (cx, cy, w, h, obj, cls...).  Per image: obj > conf filter, conf = obj*cls, best
+ * class or multi-label expansion, optional class filter (host int array), top max_nms by score (stable),
+ * class-offset boxes, greedy IoU suppression in descending score order, first max_det survivors.
+ * det: [B][max_det][6] (x1,y1,x2,y2,conf,cls), count: [B], keep_idx: [B][max_det] = indices into the image's
+ * candidate list exactly as torchvision.ops.nms would return them (may be NULL).
+ */
+int icaf_nms_workspace_bytes(int B, long long rows, int nc, int multi_label, size_t* bytes);
+int icaf_nms(const float* pred, int B, long long rows, int nc, float conf_thres, float iou_thres, int multi_label,
+             int agnostic, const int* classes_host, int n_classes, int max_det, int max_nms, float max_wh,
+             float* det, int* count, int* keep_idx, void* workspace, size_t workspace_bytes, icaf_stream_t s);
+
+/* ---- HIP graph capture / events (so the Python host never needs a tracing compiler) ------------------------ */
+int icaf_graph_begin(icaf_stream_t s);
+int icaf_graph_end(icaf_stream_t s, void** graph_exec);
+int icaf_graph_launch(void* graph_exec, icaf_stream_t s);
+int icaf_graph_destroy(void* graph_exec);
+int icaf_event_create(void** ev);
+int icaf_event_record(void* ev, icaf_stream_t s);
+int icaf_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int icaf_event_destroy(void* ev);
+int icaf_stream_sync(icaf_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICAF_H */

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (read-only at /root/reference) on the CPU.
+
+Runs only in the build container (the reference cannot travel to the GPU box).  The reference has no tests,
+golden vectors or fixtures of its own, so these files are the pin for oracle/icaf_oracle.py:
+    python tests/golden/make_golden.py            # rewrites every fixture
+
+What is recorded per model case: the full Detect output z, class logits, and 2048 seeded samples of every layer's
+output (enough to localise a divergence to one layer without shipping MBs of activations).  Weights and inputs
+are NOT stored: they are regenerated from icafusion_amd.synth (numpy PCG64 streams keyed by state_dict name).
+
+Third-party modules that are missing here and unused on the forward path (cv2, timm, torchvision, seaborn, thop)
+are stubbed; torchvision.ops.nms — used by the reference's non_max_suppression (utils/general.py:591) — is
+stubbed with the oracle's greedy core, so the NMS fixtures pin the reference's wrapper logic (candidate
+filtering, multi-label expansion, class offsets, max_det) but NOT the greedy core itself ("parity unpinned").
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+import numpy as np
+import torch
+import yaml
+
+sys.path.insert(0, REPO)
+from icafusion_amd.synth import synth_state_dict, synth_images, synth_tensor      # noqa: E402
+from oracle import icaf_oracle as oracle                                             # noqa: E402
+
+
+class _Dummy:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return None
+
+    def __getattr__(self, k):
+        return _Dummy()
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _tv_nms(boxes, scores, thr):
+    return torch.from_numpy(oracle.nms_greedy(boxes.numpy(), scores.numpy(), float(thr)))
+
+
+def import_reference():
+    _stub("cv2", setNumThreads=lambda *a: None, ocl=_Dummy())
+    _stub("seaborn")
+    _stub("thop")
+    _stub("timm"); _stub("timm.models"); _stub("timm.models.layers", DropPath=_Dummy)
+    tv = _stub("torchvision")
+    tv.ops = _stub("torchvision.ops", nms=_tv_nms)
+    tv.transforms = _stub("torchvision.transforms")
+    tv.utils = _stub("torchvision.utils", save_image=None)
+    tv.models = _stub("torchvision.models")
+    # the reference's `models` / `utils` packages must win over this repo's drop-in packages of the same name
+    sys.path.insert(0, REF)
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "utils" or k.startswith("utils.")]:
+        del sys.modules[k]
+    import models.yolo_test as yt          # noqa
+    import models.common as common         # noqa
+    import utils.general as general        # noqa
+    import utils.metrics as metrics        # noqa
+    assert yt.__file__.startswith(REF) and general.__file__.startswith(REF)
+    return yt, common, general, metrics
+
+
+def sample_idx(numel, tag, n=2048):
+    g = np.random.default_rng([0x5A3917, tag])
+    return g.integers(0, numel, size=min(n, numel))
+
+
+def model_case(yt, name, yaml_name, batch, h, w, seed, loops=None):
+    ref_cfg = os.path.join(REF, "models", "transformer", yaml_name)
+    ours = yaml.safe_load(open(os.path.join(REPO, "models", "transformer", yaml_name)))
+    assert ours == yaml.safe_load(open(ref_cfg)), "config surface drifted from the reference"
+    model = yt.Model(ref_cfg).eval()
+    model.load_state_dict(synth_state_dict(model, seed))
+    if loops is not None:
+        for i in (20, 21, 22):
+            model.model[i].crosstransformer[0].loops = loops          # SURVEY §0.2 / models/common.py:744
+    rgb, ir = synth_images(batch, h, w, seed)
+    rec = {}
+    hooks = []
+    for i, layer in enumerate(model.model):
+        def hook(mod, inp, out, i=i):
+            if torch.is_tensor(out):
+                flat = out.detach().reshape(-1)
+                rec[f"layer{i}"] = flat[torch.from_numpy(sample_idx(flat.numel(), i))].numpy().copy()
+                rec[f"layer{i}_shape"] = np.asarray(out.shape)
+        hooks.append(layer.register_forward_hook(hook))
+    with torch.no_grad():
+        z, logits, raws = model(rgb, ir)
+    for hk in hooks:
+        hk.remove()
+    rec.update(z=z.numpy(), logits=logits.numpy())
+    for l, r in enumerate(raws):
+        flat = r.reshape(-1)
+        rec[f"raw{l}"] = flat[torch.from_numpy(sample_idx(flat.numel(), 100 + l))].numpy().copy()
+        rec[f"raw{l}_shape"] = np.asarray(r.shape)
+    rec["meta"] = np.asarray([batch, h, w, seed, -1 if loops is None else loops])
+    rec["yaml"] = np.asarray(yaml_name)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print(name, "z", tuple(z.shape), "saved")
+    return z
+
+
+def dmff_case(common, name, c, va, ha, batch, h, w, seed, loops):
+    blk = common.TransformerFusionBlock(c, va, ha).eval()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps = 1e-3                                              # what initialize_weights does in Model()
+    sd = {k: (v if k.endswith("num_batches_tracked") else synth_tensor("model.20." + k, v.shape, seed=seed))
+          for k, v in blk.state_dict().items()}
+    blk.load_state_dict(sd)
+    blk.crosstransformer[0].loops = loops
+    g = np.random.default_rng([seed, 77, c, h, w])
+    rgb = torch.from_numpy(g.normal(0, 1, (batch, c, h, w)).astype(np.float32))
+    ir = torch.from_numpy(g.normal(0, 1, (batch, c, h, w)).astype(np.float32))
+    with torch.no_grad():
+        out = blk([rgb, ir])
+        # also record the token tensors that enter / leave the cross transformer (layer-local checkpoints)
+        tv = blk.vis_coefficient(blk.avgpool(rgb), blk.maxpool(rgb))
+        tok_in = tv.contiguous().view(batch, c, -1).permute(0, 2, 1) + blk.pos_emb_vis
+        ti = blk.ir_coefficient(blk.avgpool(ir), blk.maxpool(ir))
+        tok_in_ir = ti.contiguous().view(batch, c, -1).permute(0, 2, 1) + blk.pos_emb_ir
+        tok_out, tok_out_ir = blk.crosstransformer([tok_in, tok_in_ir])
+        att_v, att_i = blk.crosstransformer[0].crossatt([tok_in, tok_in_ir])
+    rec = {}
+    for j, (k, t) in enumerate([("out", out), ("tok_in", tok_in), ("tok_in_ir", tok_in_ir), ("tok_out", tok_out),
+                                ("tok_out_ir", tok_out_ir), ("att_v", att_v), ("att_i", att_i)]):
+        flat = t.reshape(-1)
+        rec[k] = flat[torch.from_numpy(sample_idx(flat.numel(), 200 + j, 8192))].numpy().copy()
+        rec[k + "_shape"] = np.asarray(t.shape)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=np.asarray([c, va, ha, batch, h, w, seed, loops]),
+                        **rec)
+    print(name, tuple(out.shape), "saved")
+
+
+def nms_case(general, name, z, **kw):
+    pred = torch.from_numpy(z.copy())
+    out = general.non_max_suppression(pred, **kw)
+    rec = {f"det{i}": o.numpy() for i, o in enumerate(out)}
+    rec["n"] = np.asarray(len(out))
+    rec["kw"] = np.asarray(repr(sorted(kw.items())))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print(name, [tuple(o.shape) for o in out])
+
+
+def metrics_case(general, metrics, name):
+    g = np.random.default_rng(42)
+    n, nc = 400, 3
+    tp = g.random((n, 10)) < np.linspace(0.7, 0.1, 10)[None]
+    tp = np.logical_and.accumulate(tp, 1)                    # a hit at IoU t implies hits at lower thresholds
+    conf = g.random(n).astype(np.float32)
+    pcls = g.integers(0, nc, n).astype(np.float32)
+    tcls = g.integers(0, nc, 150).astype(np.float32)
+    r = metrics.ap_per_class(tp, conf, pcls, tcls)
+    a = torch.from_numpy(g.uniform(0, 100, (7, 2)).astype(np.float32))
+    b = torch.from_numpy(g.uniform(0, 100, (5, 2)).astype(np.float32))
+    box1 = torch.cat((a, a + torch.from_numpy(g.uniform(5, 60, (7, 2)).astype(np.float32))), 1)
+    box2 = torch.cat((b, b + torch.from_numpy(g.uniform(5, 60, (5, 2)).astype(np.float32))), 1)
+    iou = general.box_iou(box1, box2).numpy()
+    coords = torch.from_numpy(g.uniform(-20, 700, (9, 4)).astype(np.float32))
+    scaled = general.scale_coords((512, 640), coords.clone(), (480, 720)).numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), tp=tp, conf=conf, pcls=pcls, tcls=tcls, ap=r[5],
+                        p=r[3], r=r[4], classes=r[7], box1=box1.numpy(), box2=box2.numpy(), iou=iou,
+                        coords=coords.numpy(), scaled=scaled)
+    print(name, "ap50", r[5][:, 0])
+
+
+def main():
+    torch.set_num_threads(os.cpu_count())
+    yt, common, general, metrics = import_reference()
+    z_s = model_case(yt, "model_s_kaist_320_b2", "yolov5s_Transfusion_kaist.yaml", 2, 320, 320, seed=1)
+    model_case(yt, "model_s_kaist_640_b1", "yolov5s_Transfusion_kaist.yaml", 1, 640, 640, seed=0)
+    model_case(yt, "model_s_kaist_384x320_loops3", "yolov5s_Transfusion_kaist.yaml", 1, 384, 320, seed=2, loops=3)
+    z_l = model_case(yt, "model_l_vedai_320_b1", "yolov5l_Transfusion_VEDAI.yaml", 1, 320, 320, seed=3)
+    dmff_case(common, "dmff_c128_20x20_in40x40", 128, 20, 20, 2, 40, 40, seed=5, loops=1)
+    dmff_case(common, "dmff_c256_16x16_in40x40_overlap", 256, 16, 16, 1, 40, 40, seed=6, loops=1)
+    dmff_case(common, "dmff_c128_20x20_in64x80_rect_loops3", 128, 20, 20, 1, 64, 80, seed=7, loops=3)
+    dmff_case(common, "dmff_c512_10x10_in10x10_identity", 512, 10, 10, 2, 10, 10, seed=8, loops=1)
+    nms_case(general, "nms_s_conf25", z_s.numpy(), conf_thres=0.25, iou_thres=0.45)
+    nms_case(general, "nms_s_conf97", z_s.numpy(), conf_thres=0.97, iou_thres=0.3)
+    nms_case(general, "nms_s_conf001_iou5", z_s.numpy(), conf_thres=0.001, iou_thres=0.5)
+    nms_case(general, "nms_l_multilabel", z_l.numpy(), conf_thres=0.001, iou_thres=0.5, multi_label=True)
+    nms_case(general, "nms_l_agnostic_classes", z_l.numpy(), conf_thres=0.3, iou_thres=0.6, agnostic=True,
+             classes=[0, 2, 5])
+    metrics_case(general, metrics, "metrics_ap")
+
+
+if __name__ == "__main__":
+    main()
