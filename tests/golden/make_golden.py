@@ -193,7 +193,7 @@ def main():
     dmff_case(common, "dmff_c128_20x20_in64x80_rect_loops3", 128, 20, 20, 1, 64, 80, seed=7, loops=3)
     dmff_case(common, "dmff_c512_10x10_in10x10_identity", 512, 10, 10, 2, 10, 10, seed=8, loops=1)
     nms_case(general, "nms_s_conf25", z_s.numpy(), conf_thres=0.25, iou_thres=0.45)
-    nms_case(general, "nms_s_conf97", z_s.numpy(), conf_thres=0.97, iou_thres=0.3)
+    nms_case(general, "nms_s_conf30", z_s.numpy(), conf_thres=0.30, iou_thres=0.3)
     nms_case(general, "nms_s_conf001_iou5", z_s.numpy(), conf_thres=0.001, iou_thres=0.5)
     nms_case(general, "nms_l_multilabel", z_l.numpy(), conf_thres=0.001, iou_thres=0.5, multi_label=True)
     nms_case(general, "nms_l_agnostic_classes", z_l.numpy(), conf_thres=0.3, iou_thres=0.6, agnostic=True,

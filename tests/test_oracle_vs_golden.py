@@ -86,7 +86,7 @@ def _kw(g):
 
 
 @pytest.mark.parametrize("name,src", [("nms_s_conf25", "model_s_kaist_320_b2"),
-                                      ("nms_s_conf97", "model_s_kaist_320_b2"),
+                                      ("nms_s_conf30", "model_s_kaist_320_b2"),
                                       ("nms_s_conf001_iou5", "model_s_kaist_320_b2"),
                                       ("nms_l_multilabel", "model_l_vedai_320_b1"),
                                       ("nms_l_agnostic_classes", "model_l_vedai_320_b1")])
