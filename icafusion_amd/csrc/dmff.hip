@@ -1,0 +1,466 @@
+// DMFF (Dual-Modality Feature Fusion / TransformerFusionBlock, reference models/common.py:762-865) kernels for gfx950:
+//   pool_tokens      AdaptivePool2d avg+max, LearnableWeights mix, + positional embedding     (HBM-bound)
+//   layernorm        per-token LayerNorm over C                                               (HBM-bound)
+//   cross_attention  the two crossed softmax(Q K^T / sqrt(dk)) V products, all heads          (MFMA + VALU)
+//   upsample_merge   bilinear resize of the token maps + residual + channel concat            (HBM-bound)
+// The Linear layers around them (QKV / out-proj / MLP) run on the implicit-GEMM kernel (igemm.hip) with the
+// LearnableCoefficient mixes folded into its epilogue.
+#include "icaf_common.h"
+
+namespace icaf {
+
+static inline unsigned grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tokens[g][b][n][c] = w1_g * avgpool + w2_g * maxpool + pos_g[n][c]     (reference models/common.py:817-823,868-891)
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void pool_tokens_kernel(const typename Elem<DT>::type* __restrict__ f0, int ld0,
+                                                          const typename Elem<DT>::type* __restrict__ f1, int ld1,
+                                                          const float* __restrict__ pos0, const float* __restrict__ pos1,
+                                                          typename Elem<DT>::type* __restrict__ tok, int B, int H, int W, int C, int th,
+                                                          int tw, int kh, int kw, int sh, int sw, float w1_0, float w2_0, float w1_1,
+                                                          float w2_1) {
+    using E = Elem<DT>;
+    const int nv = C / E::VEC, N = th * tw;
+    const long long per_g = (long long)B * N * nv, total = 2 * per_g;
+    const float inv_area = 1.0f / (float)(kh * kw);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int g = idx >= per_g;
+        const long long r = idx - (g ? per_g : 0);
+        const int v = (int)(r % nv);
+        const long long bn = r / nv;
+        const int n = (int)(bn % N), b = (int)(bn / N);
+        const int oy = n / tw, ox = n - oy * tw;
+        const typename E::type* f = g ? f1 : f0;
+        const int ld = g ? ld1 : ld0;
+        float sum[E::VEC], mx[E::VEC];
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) { sum[j] = 0.0f; mx[j] = -INFINITY; }
+        for (int dy = 0; dy < kh; ++dy)
+            for (int dx = 0; dx < kw; ++dx) {
+                float t[E::VEC];
+                unpack16<DT>(*(const u32x4*)(f + (((long long)b * H + oy * sh + dy) * W + ox * sw + dx) * ld + v * E::VEC), t);
+#pragma unroll
+                for (int j = 0; j < E::VEC; ++j) { sum[j] += t[j]; mx[j] = fmaxf(mx[j], t[j]); }
+            }
+        const float w1 = g ? w1_1 : w1_0, w2 = g ? w2_1 : w2_0;
+        const float* pos = (g ? pos1 : pos0) + (long long)n * C + v * E::VEC;
+        float o[E::VEC];
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) o[j] = (sum[j] * inv_area) * w1 + mx[j] * w2 + pos[j];
+        *(u32x4*)(tok + (((long long)g * B + b) * N + n) * C + v * E::VEC) = pack16<DT>(o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim: one wavefront per token row, values held in registers, two-pass statistics
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const typename Elem<DT>::type* __restrict__ x, typename Elem<DT>::type* __restrict__ y,
+                                                        const float* __restrict__ g0, const float* __restrict__ b0,
+                                                        const float* __restrict__ g1, const float* __restrict__ b1,
+                                                        long long rows_per_group, int C, int groups, float eps) {
+    using E = Elem<DT>;
+    constexpr int MAXV = 4;                                   // vectors per lane: C <= 64 * MAXV * VEC
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows_per_group * groups) return;
+    const int grp = (int)(row / rows_per_group);
+    const float* gam = grp ? g1 : g0;
+    const float* bet = grp ? b1 : b0;
+    const int nv = C / E::VEC;
+    float val[MAXV][E::VEC];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < nv) {
+            unpack16<DT>(*(const u32x4*)(x + row * C + v * E::VEC), val[i]);
+#pragma unroll
+            for (int j = 0; j < E::VEC; ++j) s += val[i][j];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < nv) {
+#pragma unroll
+            for (int j = 0; j < E::VEC; ++j) { const float d = val[i][j] - mean; q += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < nv) {
+            float o[E::VEC];
+#pragma unroll
+            for (int j = 0; j < E::VEC; ++j) o[j] = (val[i][j] - mean) * rstd * gam[v * E::VEC + j] + bet[v * E::VEC + j];
+            *(u32x4*)(y + row * C + v * E::VEC) = pack16<DT>(o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Cross attention (reference models/common.py:670-685)
+//   out[dir] = softmax( Q_{1-dir} K_dir^T / sqrt(dk) ) V_dir          per (batch, head), dir = 0 (RGB) / 1 (IR)
+//
+// One workgroup = (q-split, head, batch*dir); its 4 wavefronts each own 32-query tiles.  N <= 400 tokens, so the whole
+// K and V^T of the head live in LDS for the workgroup's lifetime (<= ~115 KB even for the fp32 build).
+//   S^T = K Q^T     MFMA A operand = K rows from LDS (padded row stride, conflict-free ds_read_b128),
+//                   B operand = the lane's own query row, loaded once from HBM into registers.
+//                   -> every lane holds 16 of the 32 key scores of ONE query: the softmax row reduction is 15 in-lane
+//                      max/adds plus one cross-half __shfl_xor(.., 32) — no LDS round trip, no serial lanes.
+//   O^T = V^T P^T   the exponentiated scores feed the MFMA B operand straight from the accumulator registers (packed
+//                   to bf16/f16 in-lane); V^T is stored in LDS with the key order permuted inside each 16-key group so
+//                   that the A-operand fragment is again one 16-byte read.
+// Online softmax (running max / sum, rescale of O per key tile) keeps registers independent of N.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT> __device__ __forceinline__ int vt_phys(int key) {
+    if constexpr (DT == ICAF_F32) return key;
+    else {
+        const int k16 = key & 15;
+        return (key & ~15) + (((k16 >> 2) & 1) << 3) + (k16 & 3) + ((k16 >> 3) << 2);
+    }
+}
+
+template <int DT> __device__ __forceinline__ u32x4 pack_p(const f32x16& s, int st);
+template <> __device__ __forceinline__ u32x4 pack_p<ICAF_F32>(const f32x16& s, int st) {
+    u32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(s[4 * st + e]);
+    return v;
+}
+template <> __device__ __forceinline__ u32x4 pack_p<ICAF_BF16>(const f32x16& s, int st) {
+    u32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        v[e] = (unsigned)f32_to_bf16(s[8 * st + 2 * e]) | ((unsigned)f32_to_bf16(s[8 * st + 2 * e + 1]) << 16);
+    return v;
+}
+template <> __device__ __forceinline__ u32x4 pack_p<ICAF_F16>(const f32x16& s, int st) {
+    u32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        v[e] = (unsigned)f32_to_f16(s[8 * st + 2 * e]) | ((unsigned)f32_to_f16(s[8 * st + 2 * e + 1]) << 16);
+    return v;
+}
+
+template <int DT, int DKP>
+__global__ __launch_bounds__(256) void cross_attn_kernel(const typename Elem<DT>::type* __restrict__ qkv,
+                                                         typename Elem<DT>::type* __restrict__ out, int B, int N, int C, int DK,
+                                                         int NP, float scale_l2e) {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    constexpr int VEC = E::VEC, EB = E::BYTES;
+    constexpr int KSTEP = 2 * VEC;              // reduction elements consumed per mma_step
+    constexpr int QSTEPS = DKP / KSTEP;         // steps over d for S^T = K Q^T
+    constexpr int TD = (DKP + 31) / 32;         // 32-row d tiles of O^T
+    constexpr int PSTEPS = 32 / KSTEP;          // steps over the 32 keys of a tile for O^T += V^T P^T
+    constexpr int KS = DKP * EB + 16;           // K row stride (bytes), odd multiple of 16 -> conflict-free b128 reads
+    const int VS = NP * EB + 16;                // V^T row stride (bytes)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;
+    unsigned char* Vt = smem + (size_t)NP * KS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y;
+    const int dir = blockIdx.z / B, b = blockIdx.z - dir * B;
+    const long long row3 = 3LL * C;
+    const T* kvbase = qkv + ((long long)(dir * B + b) * N) * row3 + (long long)h * DK;
+    const T* qbase = qkv + ((long long)((1 - dir) * B + b) * N) * row3 + (long long)h * DK;
+
+    // ---- stage K (row-major) and V^T (key-permuted) of this head into LDS ----------------------------------------
+    constexpr int NVK = DKP / VEC;
+    for (int idx = tid; idx < NP * NVK; idx += 256) {
+        const int key = idx / NVK, v = idx - key * NVK;
+        u32x4 kvv = {0u, 0u, 0u, 0u}, vvv = {0u, 0u, 0u, 0u};
+        if (key < N && v * VEC < DK) {
+            kvv = *(const u32x4*)(kvbase + key * row3 + C + v * VEC);
+            vvv = *(const u32x4*)(kvbase + key * row3 + 2 * C + v * VEC);
+        }
+        *(u32x4*)(Ks + (size_t)key * KS + v * 16) = kvv;
+        const int pk = vt_phys<DT>(key);
+        if constexpr (EB == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(unsigned int*)(Vt + (size_t)(v * 4 + j) * VS + pk * 4) = vvv[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *(unsigned short*)(Vt + (size_t)(v * 8 + j) * VS + pk * 2) = (unsigned short)((vvv[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+        }
+    }
+    __syncthreads();
+
+    const int nqt = NP >> 5;
+    for (int qt = blockIdx.x + wave * gridDim.x; qt < nqt; qt += 4 * gridDim.x) {
+        const int q = qt * 32 + l31;
+        const bool qok = q < N;
+        u32x4 qf[QSTEPS];
+#pragma unroll
+        for (int st = 0; st < QSTEPS; ++st) {
+            const int off = st * KSTEP + hi * VEC;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (qok && off < DK) v = *(const u32x4*)(qbase + q * row3 + off);
+            qf[st] = v;
+        }
+        float m = -INFINITY, l = 0.0f;
+        f32x16 o[TD];
+#pragma unroll
+        for (int td = 0; td < TD; ++td)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[td][r] = 0.0f;
+
+        for (int kt = 0; kt < nqt; ++kt) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+            for (int st = 0; st < QSTEPS; ++st) {
+                const u32x4 kf = *(const u32x4*)(Ks + (size_t)(kt * 32 + l31) * KS + st * 32 + hi * 16);
+                mma_step<DT>(s, kf, qf[st]);
+            }
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float v = key < N ? s[r] * scale_l2e : -INFINITY;
+                s[r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            float psum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[r] - m_new);
+                s[r] = pv;
+                psum += pv;
+            }
+            l = l * alpha + psum;
+            m = m_new;
+#pragma unroll
+            for (int td = 0; td < TD; ++td)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
+#pragma unroll
+            for (int st = 0; st < PSTEPS; ++st) {
+                const u32x4 pf = pack_p<DT>(s, st);
+#pragma unroll
+                for (int td = 0; td < TD; ++td) {
+                    int drow = td * 32 + l31;
+                    drow = drow < DKP ? drow : DKP - 1;
+                    const u32x4 vf = *(const u32x4*)(Vt + (size_t)drow * VS + (size_t)(kt * 32 + st * KSTEP + hi * VEC) * EB);
+                    mma_step<DT>(o[td], vf, pf);
+                }
+            }
+        }
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        if (qok) {
+            T* orow = out + ((long long)(dir * B + b) * N + q) * C + (long long)h * DK;
+#pragma unroll
+            for (int td = 0; td < TD; ++td)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d0 = td * 32 + 8 * g4 + 4 * hi;
+                    if (d0 < DK) {
+                        const float v0 = o[td][4 * g4] * inv, v1 = o[td][4 * g4 + 1] * inv, v2 = o[td][4 * g4 + 2] * inv,
+                                    v3 = o[td][4 * g4 + 3] * inv;
+                        if constexpr (EB == 4) {
+                            *(f32x4*)(orow + d0) = f32x4{v0, v1, v2, v3};
+                        } else if constexpr (DT == ICAF_BF16) {
+                            u32x2 pk;
+                            pk[0] = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+                            pk[1] = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
+                            *(u32x2*)(orow + d0) = pk;
+                        } else {
+                            u32x2 pk;
+                            pk[0] = (unsigned)f32_to_f16(v0) | ((unsigned)f32_to_f16(v1) << 16);
+                            pk[1] = (unsigned)f32_to_f16(v2) | ((unsigned)f32_to_f16(v3) << 16);
+                            *(u32x2*)(orow + d0) = pk;
+                        }
+                    }
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// out[b][h][w][g*C + c] = bilinear(tokens[g])(h, w)[c] + fea_g[b][h][w][c]      (reference models/common.py:827-840)
+// align_corners=False: src = max(0, (dst + 0.5) * in/out - 0.5), neighbours clamped to the last row / column.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void upsample_merge_kernel(const typename Elem<DT>::type* __restrict__ tok,
+                                                             const typename Elem<DT>::type* __restrict__ f0, int ld0,
+                                                             const typename Elem<DT>::type* __restrict__ f1, int ld1,
+                                                             typename Elem<DT>::type* __restrict__ out, int ldo, int B, int H, int W, int C,
+                                                             int th, int tw) {
+    using E = Elem<DT>;
+    const int nv = C / E::VEC, N = th * tw;
+    const long long total = (long long)B * H * W * 2 * nv;
+    const float sy = (float)th / (float)H, sx = (float)tw / (float)W;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(idx % nv);
+        long long t = idx / nv;
+        const int g = (int)(t & 1);
+        t >>= 1;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H), b = (int)(t / H);
+        float fy = ((float)h + 0.5f) * sy - 0.5f, fx = ((float)w + 0.5f) * sx - 0.5f;
+        fy = fy < 0.0f ? 0.0f : fy;
+        fx = fx < 0.0f ? 0.0f : fx;
+        int y0 = (int)fy, x0 = (int)fx;
+        y0 = y0 < th - 1 ? y0 : th - 1;
+        x0 = x0 < tw - 1 ? x0 : tw - 1;
+        const int y1 = y0 < th - 1 ? y0 + 1 : y0, x1 = x0 < tw - 1 ? x0 + 1 : x0;
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const typename E::type* tb = tok + (((long long)g * B + b) * N) * C + v * E::VEC;
+        float a00[E::VEC], a01[E::VEC], a10[E::VEC], a11[E::VEC], r[E::VEC], o[E::VEC];
+        unpack16<DT>(*(const u32x4*)(tb + (long long)(y0 * tw + x0) * C), a00);
+        unpack16<DT>(*(const u32x4*)(tb + (long long)(y0 * tw + x1) * C), a01);
+        unpack16<DT>(*(const u32x4*)(tb + (long long)(y1 * tw + x0) * C), a10);
+        unpack16<DT>(*(const u32x4*)(tb + (long long)(y1 * tw + x1) * C), a11);
+        const typename E::type* f = g ? f1 : f0;
+        const int ld = g ? ld1 : ld0;
+        const long long pix = ((long long)b * H + h) * W + w;
+        unpack16<DT>(*(const u32x4*)(f + pix * ld + v * E::VEC), r);
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) {
+            const float top = a00[j] * (1.0f - lx) + a01[j] * lx;
+            const float bot = a10[j] * (1.0f - lx) + a11[j] * lx;
+            o[j] = (top * (1.0f - ly) + bot * ly) + r[j];
+        }
+        *(u32x4*)(out + pix * ldo + (long long)g * C + v * E::VEC) = pack16<DT>(o);
+    }
+}
+
+template <int DT, int DKP>
+static int launch_attn(const void* qkv, void* out, int B, int N, int C, int DK, int heads, hipStream_t s) {
+    using T = typename Elem<DT>::type;
+    constexpr int EB = Elem<DT>::BYTES;
+    const int NP = (N + 31) & ~31;
+    const size_t lds = (size_t)NP * (DKP * EB + 16) + (size_t)DKP * ((size_t)NP * EB + 16);
+    if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "icaf_cross_attention: %zu bytes of LDS needed (N=%d, dk=%d) exceed 160 KiB", lds, N, DK);
+    static bool attr_set = false;          // per instantiation
+    if (lds > 64 * 1024 && !attr_set) {
+        ICAF_HIP(hipFuncSetAttribute((const void*)cross_attn_kernel<DT, DKP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int nqt = NP / 32;
+    int qsplit = (nqt + 3) / 4;
+    // small batches: fewer workgroups exist, keep the split; large batches already fill the chip, so let every
+    // workgroup amortise its K/V staging over two query tiles per wavefront
+    if ((long long)2 * B * heads * qsplit >= 4096 && qsplit > 1) qsplit = (qsplit + 1) / 2;
+    const float scale_l2e = (float)((1.0 / sqrt((double)DK)) * 1.4426950408889634);
+    dim3 grid((unsigned)qsplit, (unsigned)heads, (unsigned)(2 * B));
+    hipLaunchKernelGGL((cross_attn_kernel<DT, DKP>), grid, dim3(256), lds, s, (const T*)qkv, (T*)out, B, N, C, DK, NP, scale_l2e);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+template <int DT>
+static int dispatch_attn(const void* qkv, void* out, int B, int N, int C, int DK, int heads, hipStream_t s) {
+    if (DK <= 16) return launch_attn<DT, 16>(qkv, out, B, N, C, DK, heads, s);
+    if (DK <= 32) return launch_attn<DT, 32>(qkv, out, B, N, C, DK, heads, s);
+    if (DK <= 48) return launch_attn<DT, 48>(qkv, out, B, N, C, DK, heads, s);
+    if (DK <= 64) return launch_attn<DT, 64>(qkv, out, B, N, C, DK, heads, s);
+    if (DK <= 96) return launch_attn<DT, 96>(qkv, out, B, N, C, DK, heads, s);
+    if (DK <= 128) return launch_attn<DT, 128>(qkv, out, B, N, C, DK, heads, s);
+    return fail(ICAF_ERR_UNSUPPORTED, "icaf_cross_attention: head dim %d > 128", DK);
+}
+
+}  // namespace icaf
+
+using namespace icaf;
+
+namespace {
+template <int DT>
+int run_pool_tokens(const void* f0, int ld0, const void* f1, int ld1, const float* p0, const float* p1, void* tok, int B, int H, int W, int C,
+                    int th, int tw, int kh, int kw, int sh, int sw, float a0, float b0, float a1, float b1, hipStream_t s) {
+    using T = typename Elem<DT>::type;
+    const long long total = 2LL * B * th * tw * (C / Elem<DT>::VEC);
+    pool_tokens_kernel<DT><<<dim3(grid_for(total)), dim3(256), 0, s>>>((const T*)f0, ld0, (const T*)f1, ld1, p0, p1, (T*)tok, B, H, W, C, th,
+                                                                        tw, kh, kw, sh, sw, a0, b0, a1, b1);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+template <int DT>
+int run_layernorm(const void* x, void* y, const float* g0, const float* b0, const float* g1, const float* b1, long long rpg, int C, int groups,
+                  float eps, hipStream_t s) {
+    using T = typename Elem<DT>::type;
+    const long long rows = rpg * groups;
+    layernorm_kernel<DT><<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s>>>((const T*)x, (T*)y, g0, b0, g1, b1, rpg, C, groups, eps);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+template <int DT>
+int run_upsample_merge(const void* tok, const void* f0, int ld0, const void* f1, int ld1, void* out, int ldo, int B, int H, int W, int C, int th,
+                       int tw, hipStream_t s) {
+    using T = typename Elem<DT>::type;
+    const long long total = 2LL * B * H * W * (C / Elem<DT>::VEC);
+    upsample_merge_kernel<DT><<<dim3(grid_for(total)), dim3(256), 0, s>>>((const T*)tok, (const T*)f0, ld0, (const T*)f1, ld1, (T*)out, ldo, B,
+                                                                           H, W, C, th, tw);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+}  // namespace
+
+#define DISPATCH_DT(dtype, FN, ...)                                  \
+    switch (dtype) {                                                 \
+        case ICAF_F32: return FN<ICAF_F32>(__VA_ARGS__);             \
+        case ICAF_BF16: return FN<ICAF_BF16>(__VA_ARGS__);           \
+        case ICAF_F16: return FN<ICAF_F16>(__VA_ARGS__);             \
+        default: return fail(ICAF_ERR_ARG, "bad dtype %d", dtype);   \
+    }
+
+extern "C" int icaf_dmff_pool_tokens(const void* fea_rgb, int ld_rgb, const void* fea_ir, int ld_ir, const float* pos_rgb,
+                                     const float* pos_ir, void* tokens, int dtype, int B, int H, int W, int C, int th, int tw, int kh,
+                                     int kw, int sh, int sw, float w1_rgb, float w2_rgb, float w1_ir, float w2_ir, icaf_stream_t s) {
+    if (!fea_rgb || !fea_ir || !pos_rgb || !pos_ir || !tokens) return fail(ICAF_ERR_ARG, "icaf_dmff_pool_tokens: null pointer");
+    const int vec = dtype == ICAF_F32 ? 4 : 8;
+    if (C % vec || ld_rgb % vec || ld_ir % vec) return fail(ICAF_ERR_ARG, "icaf_dmff_pool_tokens: C/ld must be multiples of %d", vec);
+    if ((th - 1) * sh + kh > H || (tw - 1) * sw + kw > W || kh < 1 || kw < 1) return fail(ICAF_ERR_ARG, "icaf_dmff_pool_tokens: window exceeds the feature map");
+    DISPATCH_DT(dtype, run_pool_tokens, fea_rgb, ld_rgb, fea_ir, ld_ir, pos_rgb, pos_ir, tokens, B, H, W, C, th, tw, kh, kw, sh, sw, w1_rgb,
+                w2_rgb, w1_ir, w2_ir, S(s));
+}
+
+extern "C" int icaf_layernorm(const void* x, void* y, const float* gamma0, const float* beta0, const float* gamma1, const float* beta1,
+                              int dtype, long long rows_per_group, int C, int groups, float eps, icaf_stream_t s) {
+    if (!x || !y || !gamma0 || !beta0) return fail(ICAF_ERR_ARG, "icaf_layernorm: null pointer");
+    if (groups < 1 || groups > 2 || (groups == 2 && (!gamma1 || !beta1))) return fail(ICAF_ERR_ARG, "icaf_layernorm: bad groups");
+    const int vec = dtype == ICAF_F32 ? 4 : 8;
+    if (C % vec || C > 64 * 4 * vec) return fail(ICAF_ERR_ARG, "icaf_layernorm: C=%d must be a multiple of %d and <= %d", C, vec, 64 * 4 * vec);
+    DISPATCH_DT(dtype, run_layernorm, x, y, gamma0, beta0, gamma1 ? gamma1 : gamma0, beta1 ? beta1 : beta0, rows_per_group, C, groups, eps, S(s));
+}
+
+extern "C" int icaf_cross_attention(const void* qkv, void* out, int dtype, int B, int N, int C, int heads, icaf_stream_t s) {
+    if (!qkv || !out) return fail(ICAF_ERR_ARG, "icaf_cross_attention: null pointer");
+    if (heads < 1 || C % heads) return fail(ICAF_ERR_ARG, "icaf_cross_attention: C=%d not divisible by heads=%d", C, heads);
+    const int DK = C / heads, vec = dtype == ICAF_F32 ? 4 : 8;
+    if (DK % vec) return fail(ICAF_ERR_UNSUPPORTED, "icaf_cross_attention: head dim %d must be a multiple of %d for this dtype", DK, vec);
+    if (B < 1 || N < 1 || 2LL * B > 65535) return fail(ICAF_ERR_ARG, "icaf_cross_attention: bad B/N");
+    DISPATCH_DT(dtype, dispatch_attn, qkv, out, B, N, C, DK, heads, S(s));
+}
+
+extern "C" int icaf_dmff_upsample_merge(const void* tokens, const void* fea_rgb, int ld_rgb, const void* fea_ir, int ld_ir, void* out,
+                                        int ldo, int dtype, int B, int H, int W, int C, int th, int tw, icaf_stream_t s) {
+    if (!tokens || !fea_rgb || !fea_ir || !out) return fail(ICAF_ERR_ARG, "icaf_dmff_upsample_merge: null pointer");
+    const int vec = dtype == ICAF_F32 ? 4 : 8;
+    if (C % vec || ld_rgb % vec || ld_ir % vec || ldo % vec || ldo < 2 * C) return fail(ICAF_ERR_ARG, "icaf_dmff_upsample_merge: bad strides");
+    DISPATCH_DT(dtype, run_upsample_merge, tokens, fea_rgb, ld_rgb, fea_ir, ld_ir, out, ldo, B, H, W, C, th, tw, S(s));
+}

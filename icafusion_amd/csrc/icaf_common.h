@@ -1,0 +1,137 @@
+// Shared device/host helpers for libicaf.so (gfx950 / CDNA4 only — no other target is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <cstdio>
+#include <cstdarg>
+#include "../../include/icaf.h"
+
+namespace icaf {
+
+// ---- error plumbing -------------------------------------------------------------------------------------
+std::string& last_error();
+int fail(int code, const char* fmt, ...);
+
+#define ICAF_HIP(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return icaf::fail(ICAF_ERR_HIP, "%s -> %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                              __FILE__, __LINE__);                                            \
+    } while (0)
+
+#define ICAF_LAUNCH_CHECK() ICAF_HIP(hipGetLastError())
+
+// ---- vector / element types ---------------------------------------------------------------------------------
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                                  // round to nearest even
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float f16_to_f32(unsigned short h) {
+    _Float16 v = __builtin_bit_cast(_Float16, h);
+    return (float)v;
+}
+__device__ __forceinline__ unsigned short f32_to_f16(float f) {
+    _Float16 v = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, v);
+}
+
+// Element traits: DT = ICAF_F32 / ICAF_BF16 / ICAF_F16.  VEC = elements per 16-byte vector.
+template <int DT> struct Elem;
+template <> struct Elem<ICAF_F32> {
+    using type = float;
+    static constexpr int VEC = 4;
+    static constexpr int BYTES = 4;
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<ICAF_BF16> {
+    using type = unsigned short;
+    static constexpr int VEC = 8;
+    static constexpr int BYTES = 2;
+    static __device__ __forceinline__ float ld(const unsigned short* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void st(unsigned short* p, float v) { *p = f32_to_bf16(v); }
+};
+template <> struct Elem<ICAF_F16> {
+    using type = unsigned short;
+    static constexpr int VEC = 8;
+    static constexpr int BYTES = 2;
+    static __device__ __forceinline__ float ld(const unsigned short* p) { return f16_to_f32(*p); }
+    static __device__ __forceinline__ void st(unsigned short* p, float v) { *p = f32_to_f16(v); }
+};
+
+// unpack / pack one 16-byte vector <-> VEC floats
+template <int DT> __device__ __forceinline__ void unpack16(const u32x4& v, float* f);
+template <> __device__ __forceinline__ void unpack16<ICAF_F32>(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
+}
+template <> __device__ __forceinline__ void unpack16<ICAF_BF16>(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+template <> __device__ __forceinline__ void unpack16<ICAF_F16>(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = f16_to_f32((unsigned short)(v[i] & 0xffffu));
+        f[2 * i + 1] = f16_to_f32((unsigned short)(v[i] >> 16));
+    }
+}
+template <int DT> __device__ __forceinline__ u32x4 pack16(const float* f);
+template <> __device__ __forceinline__ u32x4 pack16<ICAF_F32>(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __float_as_uint(f[i]);
+    return v;
+}
+template <> __device__ __forceinline__ u32x4 pack16<ICAF_BF16>(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (unsigned int)f32_to_bf16(f[2 * i]) | ((unsigned int)f32_to_bf16(f[2 * i + 1]) << 16);
+    return v;
+}
+template <> __device__ __forceinline__ u32x4 pack16<ICAF_F16>(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (unsigned int)f32_to_f16(f[2 * i]) | ((unsigned int)f32_to_f16(f[2 * i + 1]) << 16);
+    return v;
+}
+
+// ---- MFMA step: consumes one 16-byte K-slice per lane of each operand ------------------------------------------
+// Operand convention (both operands K-major in memory): for the step's 2*VEC consecutive K elements, lane-half
+// hi = lane>>5 supplies elements [hi*VEC, hi*VEC+VEC) of row (lane&31).  D[i][j] += sum_k A[i][k] * B[j][k];
+// D layout: j = lane&31, i = (r&3) + 8*(r>>2) + 4*hi for accumulator register r.
+template <int DT> __device__ __forceinline__ void mma_step(f32x16& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mma_step<ICAF_BF16>(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma_step<ICAF_F16>(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma_step<ICAF_F32>(f32x16& acc, const u32x4& a, const u32x4& b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[e]), __uint_as_float(b[e]), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+inline hipStream_t S(icaf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace icaf

@@ -1,0 +1,370 @@
+// Implicit-GEMM convolution / linear layer for gfx950 (MI355X).
+//
+//   y[m][n] = alpha_res * res[m][n] + alpha_acc * act( sum_k A[m][k] * Wp[n][k] + bias[n] )
+//
+// m = output pixel (b, ho, wo) of an NHWC tensor, k = (kh, kw, cin) gathered on the fly from the NHWC input (no
+// im2col buffer), Wp = packed K-major weights.  Replaces reference models/common.py:48-60 (Conv), :184-194
+// (Bottleneck shortcut), nn.Linear layers of :607-618 / :704-709 and models/yolo_test.py:50 (Detect convs).
+//
+// Structure (per 256-thread workgroup = 4 wavefronts of 64):
+//   * BM x BN output tile, K walked in 64-byte slices (32 bf16 / 16 fp32 elements) through double-buffered LDS;
+//     global -> register -> LDS staging with 16-byte vectors (a slice of one pixel's channels is contiguous in
+//     NHWC, zero-filled outside the image), row stride padded to 80 B so the ds_read_b128 fragment reads of a
+//     16-lane group hit 16 distinct 16-byte slots;
+//   * v_mfma_f32_32x32x16_{bf16,f16} (or v_mfma_f32_32x32x2_f32 x4 in the fp32 parity build): the weight rows are
+//     the MFMA A operand and the pixel rows the B operand, so each lane's accumulator registers hold 4 consecutive
+//     output channels of ONE pixel — bias/activation are applied in registers, the tile is staged through LDS
+//     (reusing the operand buffers) and written back as whole 16-byte channel vectors, fully coalesced, with the
+//     residual read the same way;
+//   * blockIdx -> tile mapping is XCD-aware: tiles that share an input tile (same pixels, different channel
+//     block) and neighbouring pixel tiles (3x3 halos) are placed on the same XCD so re-reads hit its private L2.
+#include "icaf_common.h"
+
+static_assert(sizeof(icaf_conv_args) == 184, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
+
+namespace icaf {
+
+struct ConvP {
+    const void* x; const void* w; const float* bias; void* y; const void* res;
+    long long x_gs, w_gs, bias_gs, y_gs, res_gs;
+    int B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, sh, sw, ph, pw, ldr, Kp, act;
+    int M, K, nchunks, mtiles, ntiles;
+    int vec_y, vec_r;
+    float alpha_acc[2], alpha_res[2];
+};
+
+constexpr int ROWB = 64;        // bytes of K per LDS row per chunk
+constexpr int ROWS = 80;        // padded LDS row stride in bytes
+constexpr int NTHREADS = 256;
+
+template <int ACT> __device__ __forceinline__ float apply_act(float v) {
+    if constexpr (ACT == ICAF_ACT_SILU) return silu_f(v);
+    else if constexpr (ACT == ICAF_ACT_GELU) return gelu_f(v);
+    else return v;
+}
+
+template <int DT, int ODT, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
+    using E = Elem<DT>;
+    using EO = Elem<ODT>;
+    constexpr int VEC = E::VEC;              // elements per 16-byte vector
+    constexpr int BK = ROWB / E::BYTES;      // K elements per chunk
+    constexpr int NA = BM * 4 / NTHREADS;    // 16-byte vectors of the pixel tile per thread
+    constexpr int NB = BN * 4 / NTHREADS;    // ... of the weight tile per thread (may be 0 -> handled by predicate)
+    constexpr int NBv = (BN * 4 + NTHREADS - 1) / NTHREADS;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_M = BM / WM;
+    constexpr int VO = 16 / EO::BYTES;       // output elements per 16-byte vector
+    constexpr int SO = BN * EO::BYTES + 16;  // staging row stride (bytes)
+    constexpr int AB_BYTES = 2 * (BM + BN) * ROWS;
+    constexpr int OUT_BYTES = BM * SO;
+    constexpr int LDS_BYTES = AB_BYTES > OUT_BYTES ? AB_BYTES : OUT_BYTES;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    static_assert(LDS_BYTES <= 65536, "static LDS limit");
+    static_assert(NB * NTHREADS == BN * 4 || NB == 0, "weight tile vectors");
+    (void)NB;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int g = blockIdx.z;
+
+    // ---- XCD-aware tile id (bijective remap: consecutive logical tiles stay on one XCD) ---------------------
+    const int ntile_total = p.mtiles * p.ntiles;
+    int tile;
+    {
+        const int bid = blockIdx.x, q = ntile_total >> 3, r = ntile_total & 7, xcd = bid & 7, idx = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const typename E::type* __restrict__ xg = (const typename E::type*)p.x + g * p.x_gs;
+    const typename E::type* __restrict__ wg = (const typename E::type*)p.w + g * p.w_gs;
+
+    // ---- per-thread gather state for the pixel (A) tile ---------------------------------------------------------
+    long long a_base[NA];
+    int a_h0[NA], a_w0[NA];
+    bool a_ok[NA];
+    const int kv = tid & 3;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (tid >> 2) + i * (NTHREADS / 4);
+        const int m = m0 + row;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, b = t / p.Ho;
+        a_h0[i] = ho * p.sh - p.ph;
+        a_w0[i] = wo * p.sw - p.pw;
+        a_base[i] = (long long)b * p.H * p.W * p.ldx;
+    }
+    // k-position of this thread's vector: channel c inside tap (ky, kx); advanced by BK per chunk
+    int kc = kv * VEC, ky = 0, kx = 0;
+    while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.kw) { kx = 0; ++ky; } }
+
+    const long long w_row = (long long)(n0 + (tid >> 2)) * p.Kp + kv * VEC;
+
+    u32x4 ra[NA], rb[NBv];
+    auto load_tiles = [&](int chunk) {
+        const bool kvalid = ky < p.kh;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int h = a_h0[i] + ky, w = a_w0[i] + kx;
+            const bool ok = a_ok[i] && kvalid && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *(const u32x4*)(xg + a_base[i] + ((long long)h * p.W + w) * p.ldx + kc);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NBv; ++i) {
+            const int row = (tid >> 2) + i * (NTHREADS / 4);
+            if (row < BN) rb[i] = *(const u32x4*)(wg + w_row + (long long)i * (NTHREADS / 4) * p.Kp + (long long)chunk * BK);
+        }
+        kc += BK;
+        while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.kw) { kx = 0; ++ky; } }
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned char* a_s = lds + buf * (BM + BN) * ROWS;
+        unsigned char* b_s = a_s + BM * ROWS;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = (tid >> 2) + i * (NTHREADS / 4);
+            *(u32x4*)(a_s + row * ROWS + kv * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NBv; ++i) {
+            const int row = (tid >> 2) + i * (NTHREADS / 4);
+            if (row < BN) *(u32x4*)(b_s + row * ROWS + kv * 16) = rb[i];
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int c = 0; c < p.nchunks; ++c) {
+        const bool more = c + 1 < p.nchunks;
+        if (more) load_tiles(c + 1);
+        const unsigned char* a_s = lds + (c & 1) * (BM + BN) * ROWS;
+        const unsigned char* b_s = a_s + BM * ROWS;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 fp[TM], fw[TN];
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+                fp[b] = *(const u32x4*)(a_s + (wm * WM + b * 32 + l31) * ROWS + s * 32 + hi * 16);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+                fw[a] = *(const u32x4*)(b_s + (wn * WN + a * 32 + l31) * ROWS + s * 32 + hi * 16);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) mma_step<DT>(acc[a][b], fw[a], fp[b]);
+        }
+        if (more) store_tiles((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + activation in registers, stage through LDS, coalesced 16-byte write-back ------------
+    const float alpha_acc = p.alpha_acc[g], alpha_res = p.alpha_res[g];
+    const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;      // tile-local channel of this register quad
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+                const f32x4 t = *(const f32x4*)(bias + n0 + nl);
+                bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
+            }
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int ml = wm * WM + b * 32 + l31;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = acc[a][b][4 * q + j] + bv[j];
+                    if (p.act == ICAF_ACT_SILU) t = silu_f(t);
+                    else if (p.act == ICAF_ACT_GELU) t = gelu_f(t);
+                    v[j] = t * alpha_acc;
+                }
+                unsigned char* dst = lds + ml * SO + nl * EO::BYTES;
+                if constexpr (EO::BYTES == 4) {
+                    *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    u32x2 pk;
+                    if constexpr (ODT == ICAF_BF16) {
+                        pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                        pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    } else {
+                        pk[0] = (unsigned)f32_to_f16(v[0]) | ((unsigned)f32_to_f16(v[1]) << 16);
+                        pk[1] = (unsigned)f32_to_f16(v[2]) | ((unsigned)f32_to_f16(v[3]) << 16);
+                    }
+                    *(u32x2*)dst = pk;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    typename EO::type* __restrict__ yg = (typename EO::type*)p.y + g * p.y_gs;
+    const typename E::type* __restrict__ rg = p.res ? (const typename E::type*)p.res + g * p.res_gs : nullptr;
+    constexpr int VPR = BN / VO;                       // 16-byte vectors per staged row
+    constexpr int NVEC = BM * VPR;
+    for (int idx = tid; idx < NVEC; idx += NTHREADS) {
+        const int row = idx / VPR, cv = idx - row * VPR;
+        const int m = m0 + row, n = n0 + cv * VO;
+        if (m >= p.M || n >= p.Cout) continue;
+        const u32x4 sv = *(const u32x4*)(lds + row * SO + cv * 16);
+        float v[VO];
+        unpack16<ODT>(sv, v);
+        const int nvalid = (p.Cout - n) < VO ? (p.Cout - n) : VO;
+        if (rg) {
+            const typename E::type* rp = rg + (long long)m * p.ldr + n;
+            if (p.vec_r && nvalid == VO) {
+                if constexpr (VO == E::VEC) {
+                    float r[VO];
+                    unpack16<DT>(*(const u32x4*)rp, r);
+#pragma unroll
+                    for (int j = 0; j < VO; ++j) v[j] += alpha_res * r[j];
+                } else {            // fp32 output of a 16-bit residual: two half vectors
+#pragma unroll
+                    for (int j = 0; j < VO; ++j) v[j] += alpha_res * E::ld(rp + j);
+                }
+            } else {
+                for (int j = 0; j < nvalid; ++j) v[j] += alpha_res * E::ld(rp + j);
+            }
+        }
+        typename EO::type* yp = yg + (long long)m * p.ldy + n;
+        if (p.vec_y && nvalid == VO) {
+            *(u32x4*)yp = pack16<ODT>(v);
+        } else {
+            for (int j = 0; j < nvalid; ++j) EO::st(yp + j, v[j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+struct TileCfg { int id, bm, bn; const char* tag; };
+static const TileCfg kTiles[] = {{1, 128, 128, "128x128"}, {2, 128, 64, "128x64"}, {3, 256, 32, "256x32"}, {4, 64, 64, "64x64"}};
+
+static int pick_tile(const icaf_conv_args* a, long long M) {
+    if (a->tile) return a->tile;
+    const bool f32 = a->dtype == ICAF_F32 || a->out_dtype == ICAF_F32;
+    const int N = a->Cout;
+    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * a->groups; };
+    int t;
+    if (N > 64 && !f32) t = 1;
+    else if (N > 32) t = 2;
+    else t = 3;
+    // small problems: prefer more, smaller workgroups so every CU gets work
+    const int bm = kTiles[t - 1].bm, bn = kTiles[t - 1].bn;
+    if (blocks(bm, bn) < 256 && blocks(64, 64) > blocks(bm, bn)) t = 4;
+    return t;
+}
+
+template <int DT, int ODT, int BM, int BN, int WM, int WN>
+static int launch_cfg(const ConvP& p, int groups, hipStream_t s) {
+    ConvP q = p;
+    q.mtiles = (p.M + BM - 1) / BM;
+    q.ntiles = (p.Cout + BN - 1) / BN;
+    dim3 grid((unsigned)(q.mtiles * q.ntiles), 1, (unsigned)groups);
+    hipLaunchKernelGGL((igemm_kernel<DT, ODT, BM, BN, WM, WN>), grid, dim3(NTHREADS), 0, s, q);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+template <int DT, int ODT>
+static int launch_tile(const ConvP& p, int groups, int tile, hipStream_t s) {
+    switch (tile) {
+        case 1:
+            if constexpr (ODT == ICAF_F32) return fail(ICAF_ERR_UNSUPPORTED, "tile 128x128 has no fp32-output build");
+            else return launch_cfg<DT, ODT, 128, 128, 64, 64>(p, groups, s);
+        case 2: return launch_cfg<DT, ODT, 128, 64, 64, 32>(p, groups, s);
+        case 3: return launch_cfg<DT, ODT, 256, 32, 64, 32>(p, groups, s);
+        case 4: return launch_cfg<DT, ODT, 64, 64, 32, 32>(p, groups, s);
+        default: return fail(ICAF_ERR_ARG, "unknown tile id %d", tile);
+    }
+}
+
+static int validate(const icaf_conv_args* a) {
+    if (!a || !a->x || !a->w || !a->y) return fail(ICAF_ERR_ARG, "icaf_conv2d: null pointer");
+    if (a->groups < 1 || a->groups > 2) return fail(ICAF_ERR_ARG, "icaf_conv2d: groups must be 1 or 2");
+    const int vec = a->dtype == ICAF_F32 ? 4 : 8;
+    if (a->dtype < 0 || a->dtype > 2) return fail(ICAF_ERR_ARG, "icaf_conv2d: bad dtype %d", a->dtype);
+    if (a->out_dtype != a->dtype && a->out_dtype != ICAF_F32) return fail(ICAF_ERR_ARG, "icaf_conv2d: out_dtype must equal dtype or be fp32");
+    if (a->Cin % vec || a->ldx % vec) return fail(ICAF_ERR_ARG, "icaf_conv2d: Cin (%d) and ldx (%d) must be multiples of %d", a->Cin, a->ldx, vec);
+    if (((uintptr_t)a->x & 15) || ((uintptr_t)a->w & 15)) return fail(ICAF_ERR_ARG, "icaf_conv2d: x / w must be 16-byte aligned");
+    if (a->B < 1 || a->Ho < 1 || a->Wo < 1 || a->Cout < 1 || a->kh < 1 || a->kw < 1 || a->sh < 1 || a->sw < 1)
+        return fail(ICAF_ERR_ARG, "icaf_conv2d: bad geometry");
+    if (a->Ho != (a->H + 2 * a->ph - a->kh) / a->sh + 1 || a->Wo != (a->W + 2 * a->pw - a->kw) / a->sw + 1)
+        return fail(ICAF_ERR_ARG, "icaf_conv2d: output size does not match input/kernel/stride/padding");
+    const int ka = a->dtype == ICAF_F32 ? 32 : 64;
+    if (a->Kp % ka || a->Kp < a->kh * a->kw * a->Cin) return fail(ICAF_ERR_ARG, "icaf_conv2d: Kp=%d must be a multiple of %d covering K=%d", a->Kp, ka, a->kh * a->kw * a->Cin);
+    if (a->ldy < a->Cout) return fail(ICAF_ERR_ARG, "icaf_conv2d: ldy < Cout");
+    if (a->res && a->ldr < a->Cout) return fail(ICAF_ERR_ARG, "icaf_conv2d: ldr < Cout");
+    if ((long long)a->B * a->Ho * a->Wo > 0x7fffffffLL) return fail(ICAF_ERR_ARG, "icaf_conv2d: too many output pixels");
+    return ICAF_OK;
+}
+
+static void fill(const icaf_conv_args* a, ConvP& p) {
+    p.x = a->x; p.w = a->w; p.bias = a->bias; p.y = a->y; p.res = a->res;
+    p.x_gs = a->x_gs; p.w_gs = a->w_gs; p.bias_gs = a->bias_gs; p.y_gs = a->y_gs; p.res_gs = a->res_gs;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.ldx = a->ldx; p.Ho = a->Ho; p.Wo = a->Wo; p.Cout = a->Cout;
+    p.ldy = a->ldy; p.kh = a->kh; p.kw = a->kw; p.sh = a->sh; p.sw = a->sw; p.ph = a->ph; p.pw = a->pw; p.ldr = a->ldr;
+    p.Kp = a->Kp; p.act = a->act;
+    p.M = a->B * a->Ho * a->Wo;
+    p.K = a->kh * a->kw * a->Cin;
+    const int bk = a->dtype == ICAF_F32 ? 16 : 32;
+    p.nchunks = (p.K + bk - 1) / bk;
+    const int vo = a->out_dtype == ICAF_F32 ? 4 : 8, vi = a->dtype == ICAF_F32 ? 4 : 8;
+    const int yb = a->out_dtype == ICAF_F32 ? 4 : 2, rb = a->dtype == ICAF_F32 ? 4 : 2;
+    p.vec_y = (a->ldy % vo == 0) && (((uintptr_t)a->y & 15) == 0) && ((a->y_gs * yb) % 16 == 0);
+    p.vec_r = a->res && (a->ldr % vi == 0) && (((uintptr_t)a->res & 15) == 0) && ((a->res_gs * rb) % 16 == 0);
+    for (int i = 0; i < 2; ++i) { p.alpha_acc[i] = a->alpha_acc[i]; p.alpha_res[i] = a->alpha_res[i]; }
+}
+
+}  // namespace icaf
+
+using namespace icaf;
+
+extern "C" int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s) {
+    int st = validate(a);
+    if (st) return st;
+    ConvP p;
+    fill(a, p);
+    const int tile = pick_tile(a, p.M);
+    hipStream_t hs = S(s);
+    if (a->dtype == ICAF_BF16)
+        return a->out_dtype == ICAF_F32 ? launch_tile<ICAF_BF16, ICAF_F32>(p, a->groups, tile, hs)
+                                        : launch_tile<ICAF_BF16, ICAF_BF16>(p, a->groups, tile, hs);
+    if (a->dtype == ICAF_F16)
+        return a->out_dtype == ICAF_F32 ? launch_tile<ICAF_F16, ICAF_F32>(p, a->groups, tile, hs)
+                                        : launch_tile<ICAF_F16, ICAF_F16>(p, a->groups, tile, hs);
+    return launch_tile<ICAF_F32, ICAF_F32>(p, a->groups, tile, hs);
+}
+
+extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int buf_len) {
+    int st = validate(a);
+    if (st) return st;
+    ConvP p;
+    fill(a, p);
+    const int tile = pick_tile(a, p.M);
+    static const char* dn[] = {"f32", "bf16", "f16"};
+    snprintf(buf, buf_len, "igemm_%s_%s_%s", dn[a->dtype], dn[a->out_dtype], kTiles[tile - 1].tag);
+    return ICAF_OK;
+}

@@ -1,0 +1,178 @@
+// Bandwidth-bound layout / pooling kernels (HBM roofline): input staging, SPPF max pools, nearest upsample, channel
+// copy.  All use 16-byte vectors along the contiguous NHWC channel axis; one thread = one (pixel, channel-vector).
+#include "icaf_common.h"
+
+namespace icaf {
+
+// ---- NCHW fp32 image -> NHWC (mode 0) or space-to-depth NHWC (mode 1) ------------------------------------------
+// Consecutive threads own consecutive output pixels of one row, so the per-channel-plane reads are coalesced along
+// W; each thread writes whole 16-byte channel vectors of its pixel.
+template <int DT>
+__global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict__ img, typename Elem<DT>::type* __restrict__ out,
+                                                         int B, int C, int H, int W, int Cpad, int mode) {
+    using E = Elem<DT>;
+    const int Ho = mode ? H / 2 : H, Wo = mode ? W / 2 : W;
+    const long long npix = (long long)B * Ho * Wo;
+    const int nv = Cpad / E::VEC;
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long long)gridDim.x * blockDim.x) {
+        const int wo = (int)(pix % Wo);
+        const long long t = pix / Wo;
+        const int ho = (int)(t % Ho), b = (int)(t / Ho);
+        for (int v = 0; v < nv; ++v) {
+            float f[E::VEC];
+#pragma unroll
+            for (int j = 0; j < E::VEC; ++j) {
+                const int ch = v * E::VEC + j;
+                float val = 0.0f;
+                if (mode == 0) {
+                    if (ch < C) val = img[(((long long)b * C + ch) * H + ho) * W + wo];
+                } else if (ch < 4 * C) {
+                    const int sub = ch / C, c = ch - sub * C, dy = sub >> 1, dx = sub & 1;
+                    val = img[(((long long)b * C + c) * H + 2 * ho + dy) * W + 2 * wo + dx];
+                }
+                f[j] = val;
+            }
+            *(u32x4*)(out + pix * Cpad + v * E::VEC) = pack16<DT>(f);
+        }
+    }
+}
+
+// ---- SPPF: y1 = maxpool_k(x), y2 = maxpool_k(y1), y3 = maxpool_k(y2), stride 1, -inf padding ----------------------
+// Chained k-pools equal direct pools with windows k, 2k-1, 3k-2 clipped at the border, so one pass over the
+// (3k-2)^2 neighbourhood produces all three outputs (the feature map is tiny and L2-resident).
+template <int DT>
+__global__ __launch_bounds__(256) void sppf_kernel(const typename Elem<DT>::type* __restrict__ x, int ldx,
+                                                   typename Elem<DT>::type* __restrict__ y1, typename Elem<DT>::type* __restrict__ y2,
+                                                   typename Elem<DT>::type* __restrict__ y3, int ldy, int B, int H, int W, int C, int k) {
+    using E = Elem<DT>;
+    const int nv = C / E::VEC;
+    const long long total = (long long)B * H * W * nv;
+    const int r1 = k / 2, r2 = 2 * r1, r3 = 3 * r1;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(idx % nv);
+        const long long pix = idx / nv;
+        const int w = (int)(pix % W);
+        const long long t = pix / W;
+        const int h = (int)(t % H), b = (int)(t / H);
+        float m1[E::VEC], m2[E::VEC], m3[E::VEC];
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) m1[j] = m2[j] = m3[j] = -INFINITY;
+        for (int dy = -r3; dy <= r3; ++dy) {
+            const int hh = h + dy;
+            if ((unsigned)hh >= (unsigned)H) continue;
+            const int ady = dy < 0 ? -dy : dy;
+            for (int dx = -r3; dx <= r3; ++dx) {
+                const int ww = w + dx;
+                if ((unsigned)ww >= (unsigned)W) continue;
+                const int adx = dx < 0 ? -dx : dx;
+                const int rad = ady > adx ? ady : adx;
+                float f[E::VEC];
+                unpack16<DT>(*(const u32x4*)(x + (((long long)b * H + hh) * W + ww) * ldx + v * E::VEC), f);
+#pragma unroll
+                for (int j = 0; j < E::VEC; ++j) {
+                    m3[j] = fmaxf(m3[j], f[j]);
+                    if (rad <= r2) m2[j] = fmaxf(m2[j], f[j]);
+                    if (rad <= r1) m1[j] = fmaxf(m1[j], f[j]);
+                }
+            }
+        }
+        const long long o = pix * ldy + v * E::VEC;
+        *(u32x4*)(y1 + o) = pack16<DT>(m1);
+        *(u32x4*)(y2 + o) = pack16<DT>(m2);
+        *(u32x4*)(y3 + o) = pack16<DT>(m3);
+    }
+}
+
+// ---- nearest-neighbour integer upsample (writes a channel slice of the consumer's concat buffer) ---------------
+__global__ __launch_bounds__(256) void upsample_kernel(const u32x4* __restrict__ x, int ldxv, u32x4* __restrict__ y, int ldyv,
+                                                       int B, int H, int W, int nv, int scale) {
+    const int Ho = H * scale, Wo = W * scale;
+    const long long total = (long long)B * Ho * Wo * nv;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(idx % nv);
+        const long long pix = idx / nv;
+        const int wo = (int)(pix % Wo);
+        const long long t = pix / Wo;
+        const int ho = (int)(t % Ho), b = (int)(t / Ho);
+        y[pix * ldyv + v] = x[(((long long)b * H + ho / scale) * W + wo / scale) * ldxv + v];
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(const u32x4* __restrict__ x, int ldxv, u32x4* __restrict__ y, int ldyv,
+                                                   long long rows, int nv) {
+    const long long total = rows * nv;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(idx % nv);
+        const long long r = idx / nv;
+        y[r * ldyv + v] = x[r * ldxv + v];
+    }
+}
+
+static inline unsigned grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;       // cap and grid-stride: 16 workgroups per CU keeps HBM queues full
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+static inline int vec_of(int dtype) { return dtype == ICAF_F32 ? 4 : 8; }
+
+}  // namespace icaf
+
+using namespace icaf;
+
+extern "C" int icaf_preprocess_nchw(const float* img, void* out, int dtype, int B, int C, int H, int W, int Cpad, int mode,
+                                    icaf_stream_t s) {
+    if (!img || !out) return fail(ICAF_ERR_ARG, "icaf_preprocess_nchw: null pointer");
+    if (dtype < 0 || dtype > 2) return fail(ICAF_ERR_ARG, "icaf_preprocess_nchw: bad dtype");
+    const int vec = vec_of(dtype);
+    if (Cpad % vec) return fail(ICAF_ERR_ARG, "icaf_preprocess_nchw: Cpad %d must be a multiple of %d", Cpad, vec);
+    if (mode == 1 && ((H | W) & 1)) return fail(ICAF_ERR_ARG, "icaf_preprocess_nchw: space-to-depth needs even H, W");
+    if (mode == 1 ? Cpad < 4 * C : Cpad < C) return fail(ICAF_ERR_ARG, "icaf_preprocess_nchw: Cpad too small");
+    const long long total = (long long)B * (mode ? H / 2 : H) * (mode ? W / 2 : W);
+    dim3 grid(grid_for(total)), block(256);
+    if (dtype == ICAF_F32) hipLaunchKernelGGL(preprocess_kernel<ICAF_F32>, grid, block, 0, S(s), img, (float*)out, B, C, H, W, Cpad, mode);
+    else if (dtype == ICAF_BF16) hipLaunchKernelGGL(preprocess_kernel<ICAF_BF16>, grid, block, 0, S(s), img, (unsigned short*)out, B, C, H, W, Cpad, mode);
+    else hipLaunchKernelGGL(preprocess_kernel<ICAF_F16>, grid, block, 0, S(s), img, (unsigned short*)out, B, C, H, W, Cpad, mode);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+extern "C" int icaf_sppf_pool(const void* x, int ldx, void* y1, void* y2, void* y3, int ldy, int dtype, int B, int H, int W, int C,
+                              int k, icaf_stream_t s) {
+    if (!x || !y1 || !y2 || !y3) return fail(ICAF_ERR_ARG, "icaf_sppf_pool: null pointer");
+    if (dtype < 0 || dtype > 2) return fail(ICAF_ERR_ARG, "icaf_sppf_pool: bad dtype");
+    const int vec = vec_of(dtype);
+    if (C % vec || ldx % vec || ldy % vec || !(k & 1)) return fail(ICAF_ERR_ARG, "icaf_sppf_pool: C/ld must be multiples of %d and k odd", vec);
+    const long long total = (long long)B * H * W * (C / vec);
+    dim3 grid(grid_for(total)), block(256);
+    if (dtype == ICAF_F32) hipLaunchKernelGGL(sppf_kernel<ICAF_F32>, grid, block, 0, S(s), (const float*)x, ldx, (float*)y1, (float*)y2, (float*)y3, ldy, B, H, W, C, k);
+    else if (dtype == ICAF_BF16) hipLaunchKernelGGL(sppf_kernel<ICAF_BF16>, grid, block, 0, S(s), (const unsigned short*)x, ldx, (unsigned short*)y1, (unsigned short*)y2, (unsigned short*)y3, ldy, B, H, W, C, k);
+    else hipLaunchKernelGGL(sppf_kernel<ICAF_F16>, grid, block, 0, S(s), (const unsigned short*)x, ldx, (unsigned short*)y1, (unsigned short*)y2, (unsigned short*)y3, ldy, B, H, W, C, k);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+extern "C" int icaf_upsample_nearest(const void* x, int ldx, void* y, int ldy, int dtype, int B, int H, int W, int C, int scale,
+                                     icaf_stream_t s) {
+    if (!x || !y) return fail(ICAF_ERR_ARG, "icaf_upsample_nearest: null pointer");
+    if (dtype < 0 || dtype > 2) return fail(ICAF_ERR_ARG, "icaf_upsample_nearest: bad dtype");
+    const int vec = vec_of(dtype);
+    if (C % vec || ldx % vec || ldy % vec || scale < 1) return fail(ICAF_ERR_ARG, "icaf_upsample_nearest: bad geometry");
+    const long long total = (long long)B * H * scale * W * scale * (C / vec);
+    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, S(s), (const u32x4*)x, ldx / vec, (u32x4*)y, ldy / vec, B, H, W,
+                       C / vec, scale);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+extern "C" int icaf_copy_channels(const void* x, int ldx, void* y, int ldy, int dtype, long long rows, int C, icaf_stream_t s) {
+    if (!x || !y) return fail(ICAF_ERR_ARG, "icaf_copy_channels: null pointer");
+    if (dtype < 0 || dtype > 2) return fail(ICAF_ERR_ARG, "icaf_copy_channels: bad dtype");
+    const int vec = vec_of(dtype);
+    if (C % vec || ldx % vec || ldy % vec) return fail(ICAF_ERR_ARG, "icaf_copy_channels: C/ld must be multiples of %d", vec);
+    hipLaunchKernelGGL(copy_kernel, dim3(grid_for(rows * (C / vec))), dim3(256), 0, S(s), (const u32x4*)x, ldx / vec, (u32x4*)y, ldy / vec,
+                       rows, C / vec);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}

@@ -32,6 +32,9 @@ def _pair(v):
 
 
 def _module_dtype(m, fallback=torch.float32):
+    forced = getattr(m, "compute_dtype", None)
+    if forced is not None:
+        return forced
     for p in m.parameters():
         return p.dtype
     return fallback
@@ -512,6 +515,17 @@ class Detect(HipModule):
         self.register_buffer("anchors", a)
         self.register_buffer("anchor_grid", a.clone().view(self.nl, 1, -1, 1, 1, 2))
         self.m = nn.ModuleList(nn.Conv2d(c, self.no * self.na, 1) for c in ch)
+
+    def _apply(self, fn, *a, **k):
+        """Anchors stay fp32 whatever the model is cast to: pixel sizes such as 373 are not representable in bf16
+        and the decode runs in fp32 anyway."""
+        keep = {n: getattr(self, n).detach().float().clone() for n in ("anchors", "anchor_grid")}
+        r = super()._apply(fn, *a, **k)
+        for n, v in keep.items():
+            cur = getattr(self, n)
+            if cur.dtype != torch.float32:
+                setattr(self, n, v.to(cur.device))
+        return r
 
     def emit(self, plan, xs):
         B = xs[0].shape[0]

@@ -153,6 +153,8 @@ class Model(HipModule):
         for mod in self.modules():                      # utils/torch_utils.py:144-154 (initialize_weights)
             if type(mod) is nn.BatchNorm2d:
                 mod.eps, mod.momentum = 1e-3, 0.03
+        self.compute_dtype = None    # None: the parameters' dtype (.half() / .bfloat16() as in the reference);
+        #                              set to torch.bfloat16 / float16 to keep fp32 masters and only pack in 16 bit
         self.use_graph = False       # replay each plan as one hipGraph launch
         self.static_outputs = False  # return views of plan-owned buffers instead of clones
 
@@ -259,7 +261,7 @@ class Model(HipModule):
                                "(no CPU fallback exists; the CPU reference is oracle/icaf_oracle.py, test-only)")
         if x.shape != x2.shape:
             raise ValueError(f"RGB and IR batches must match, got {tuple(x.shape)} vs {tuple(x2.shape)}")
-        dt = next(self.parameters()).dtype
+        dt = self.compute_dtype or next(self.parameters()).dtype
         B, _, H, W = x.shape
         if H % 32 or W % 32:
             raise ValueError(f"input size {H}x{W} must be a multiple of the max stride 32")
@@ -287,7 +289,7 @@ class Model(HipModule):
 
     def plan_for(self, B, H, W, device="cuda", dtype=None):
         """Pre-build (and return) the execution plan; its .inputs are the static RGB / IR staging buffers."""
-        dt = dtype or next(self.parameters()).dtype
+        dt = dtype or self.compute_dtype or next(self.parameters()).dtype
         device = torch.device(device)
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())

@@ -1,0 +1,93 @@
+"""Post-processing with the reference's function names (utils/general.py): NMS runs on the device in HIP kernels,
+the small coordinate helpers are plain tensor code on whatever device their inputs live on."""
+import math
+import time
+
+import numpy as np
+import torch
+
+from .. import ops
+
+_RUNNERS = {}
+
+
+def make_divisible(x, divisor):
+    return math.ceil(x / divisor) * divisor
+
+
+def xyxy2xywh(x):
+    """[x1, y1, x2, y2] -> [cx, cy, w, h] (reference utils/general.py:322-329)."""
+    y = x.clone() if isinstance(x, torch.Tensor) else np.copy(x)
+    y[:, 0] = (x[:, 0] + x[:, 2]) / 2
+    y[:, 1] = (x[:, 1] + x[:, 3]) / 2
+    y[:, 2] = x[:, 2] - x[:, 0]
+    y[:, 3] = x[:, 3] - x[:, 1]
+    return y
+
+
+def xywh2xyxy(x):
+    """[cx, cy, w, h] -> [x1, y1, x2, y2] (reference utils/general.py:332-339)."""
+    y = x.clone() if isinstance(x, torch.Tensor) else np.copy(x)
+    y[:, 0] = x[:, 0] - x[:, 2] / 2
+    y[:, 1] = x[:, 1] - x[:, 3] / 2
+    y[:, 2] = x[:, 0] + x[:, 2] / 2
+    y[:, 3] = x[:, 1] + x[:, 3] / 2
+    return y
+
+
+def clip_coords(boxes, img_shape):
+    """Clip xyxy boxes to (height, width) in place (reference utils/general.py:402-407)."""
+    boxes[:, 0].clamp_(0, img_shape[1])
+    boxes[:, 1].clamp_(0, img_shape[0])
+    boxes[:, 2].clamp_(0, img_shape[1])
+    boxes[:, 3].clamp_(0, img_shape[0])
+
+
+def scale_coords(img1_shape, coords, img0_shape, ratio_pad=None):
+    """Map xyxy boxes from the letterboxed network input back to the native image (reference :386-399)."""
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    else:
+        gain, pad = ratio_pad[0][0], ratio_pad[1]
+    coords[:, [0, 2]] -= pad[0]
+    coords[:, [1, 3]] -= pad[1]
+    coords[:, :4] /= gain
+    clip_coords(coords, img0_shape)
+    return coords
+
+
+def box_iou(box1, box2):
+    """Pairwise IoU of xyxy boxes, (N,4) x (M,4) -> (N,M) (reference utils/general.py:455-477)."""
+    a1 = (box1[:, 2] - box1[:, 0]) * (box1[:, 3] - box1[:, 1])
+    a2 = (box2[:, 2] - box2[:, 0]) * (box2[:, 3] - box2[:, 1])
+    inter = (torch.min(box1[:, None, 2:], box2[:, 2:]) - torch.max(box1[:, None, :2], box2[:, :2])).clamp(0).prod(2)
+    return inter / (a1[:, None] + a2 - inter)
+
+
+def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+               max_det=300, max_nms=30000, max_wh=4096.0):
+    """Device-resident NMS: returns (det (B,max_det,6), count (B,), keep_idx (B,max_det)) without any host sync."""
+    if not prediction.is_cuda:
+        raise RuntimeError("non_max_suppression runs on the MI355X only (no CPU fallback; see oracle/ for the "
+                           "CPU reference used by the tests)")
+    pred = prediction.float().contiguous()
+    B, rows, no = pred.shape
+    nc = no - 5
+    ml = bool(multi_label) and nc > 1
+    key = (B, rows, nc, ml, max_det, pred.device)
+    if key not in _RUNNERS:
+        _RUNNERS[key] = ops.NmsRunner(B, rows, nc, pred.device, ml, max_det)
+    return _RUNNERS[key].launch(pred, conf_thres, iou_thres, agnostic, classes, max_nms, max_wh)
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                        labels=()):
+    """Drop-in for the reference's non_max_suppression (utils/general.py:518-607): list of (n,6) tensors
+    [x1, y1, x2, y2, conf, cls] per image.  The 10 s wall-clock bail-out of the reference (:603-605) does not exist
+    here; apriori `labels` (autolabelling) are outside the inference hot path."""
+    if labels:
+        raise NotImplementedError("apriori labels (autolabelling) are outside the inference hot path")
+    det, count, _ = nms_device(prediction, conf_thres, iou_thres, classes, agnostic, multi_label)
+    counts = count.tolist()                           # the one device->host sync of post-processing
+    return [det[i, :n].clone() for i, n in enumerate(counts)]

@@ -5,7 +5,7 @@
  * (SURVEY.md §8b).  Its "operator interface" for this path is the set of nn.Module forwards in
  * models/common.py and models/yolo_test.py plus utils/general.non_max_suppression; each entry point below
  * replaces the arithmetic of one of those (file:line cited per function, paths relative to the reference root).
- * The host side (icafusion_amd/models/*.py) keeps the reference's Python class names and constructor signatures
+ * The host side (the icafusion_amd/models package) keeps the reference's Python class names and constructor signatures
  * and calls these functions through ctypes — see INTEGRATION.md for the binding stub.
  *
  * Conventions
@@ -44,7 +44,7 @@ int icaf_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
  * mode 0: NCHW fp32 -> NHWC `dtype`, channels zero-padded from C to Cpad.
  * mode 1: NCHW fp32 -> space-to-depth NHWC: out[b][h/2][w/2][(dy*2+dx)*C + c] = in[b][c][h][w], padded to
  *         Cpad.  A 6x6 / stride-2 / pad-2 convolution over the image (first layer of each stream,
- *         models/transformer/*.yaml row 0 and 10) equals a 3x3 / stride-1 / pad-1 convolution over this tensor.
+ *         rows 0 and 10 of the Transfusion yaml files) equals a 3x3 / stride-1 / pad-1 convolution over this tensor.
  */
 int icaf_preprocess_nchw(const float* img, void* out, int dtype, int B, int C, int H, int W, int Cpad, int mode,
                          icaf_stream_t s);

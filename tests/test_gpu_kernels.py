@@ -1,0 +1,359 @@
+"""Kernel-level parity on the MI355X: every C-ABI entry point vs the CPU oracle / plain fp32 torch on the same seeded
+inputs.  fp32 builds are held to 1e-3 relative (they land around 1e-6); bf16 / f16 builds carry their own tolerance,
+stated next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from icafusion_amd import ops            # noqa: E402
+from icafusion_amd.engine import Plan    # noqa: E402
+from oracle import icaf_oracle as oracle  # noqa: E402
+
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2, torch.float16: 3e-3}   # relative to max |ref|
+
+
+def rnd(shape, seed, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy((g.normal(0, scale, shape)).astype(np.float32))
+
+
+def to_act(x_nchw, dt, pad_to=None):
+    """CPU NCHW fp32 -> GPU NHWC act (optionally a channel slice of a wider buffer to exercise ld > C)."""
+    t = x_nchw.permute(0, 2, 3, 1).contiguous().to(DEV).to(dt)
+    if pad_to:
+        buf = torch.full((*t.shape[:3], pad_to), 7.0, dtype=dt, device=DEV)
+        off = (pad_to - t.shape[3]) // 2 // 8 * 8
+        buf[..., off:off + t.shape[3]] = t
+        return buf[..., off:off + t.shape[3]]
+    return t
+
+
+def from_act(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+def run(launch):
+    launch(ops.current_stream_ptr())
+    torch.cuda.synchronize()
+
+
+def close(got, ref, dt, what="", factor=1.0):
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max()) / scale
+    assert err <= TOL[dt] * factor, f"{what}: rel err {err:.3e} > {TOL[dt] * factor:.1e} ({dt})"
+
+
+def q(x, dt):
+    """Round-trip through the storage dtype (what the kernel actually sees)."""
+    return x.to(dt).float()
+
+
+CONV_CASES = [
+    # B, H, W, cin, cout, k, s, p, act, res, tile
+    (2, 20, 24, 32, 64, 1, 1, 0, ops.ACT_SILU, False, 0),
+    (1, 33, 17, 64, 96, 3, 1, 1, ops.ACT_SILU, True, 0),
+    (2, 32, 32, 32, 64, 3, 2, 1, ops.ACT_SILU, False, 0),
+    (1, 16, 16, 16, 32, 3, 1, 1, ops.ACT_SILU, False, 3),      # Cin < BK: two taps per K slice
+    (1, 40, 40, 128, 256, 1, 1, 0, ops.ACT_NONE, False, 1),
+    (1, 40, 40, 128, 256, 1, 1, 0, ops.ACT_GELU, True, 2),
+    (3, 10, 10, 256, 128, 3, 1, 1, ops.ACT_SILU, True, 4),
+    (1, 13, 13, 72, 40, 3, 2, 1, ops.ACT_SILU, False, 0),      # ragged channel counts (not multiples of the tile)
+    (1, 8, 8, 512, 18, 1, 1, 0, ops.ACT_NONE, False, 0),       # Detect-like head
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case, dt):
+    B, H, W, cin, cout, k, s, p, act, use_res, tile = case
+    if tile == 1 and dt == torch.float32:
+        tile = 2
+    x = rnd((B, cin, H, W), 1)
+    w = rnd((cout, cin, k, k), 2, 1.0 / math.sqrt(cin * k * k))
+    bias = rnd((cout,), 3, 0.2)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = rnd((B, cout, Ho, Wo), 4) if use_res else None
+    xa = to_act(x, dt, pad_to=cin + 16)
+    wp, kp = ops.pack_conv_weight(w.to(DEV), dt)
+    bp = ops.pack_bias(bias.to(DEV), cout)
+    vec = ops.VEC[dt]
+    ldy = -(-cout // vec) * vec + vec
+    ybuf = torch.zeros((B, Ho, Wo, ldy), dtype=dt, device=DEV)
+    y = ybuf[..., :cout]
+    ra = to_act(res, dt) if use_res else None
+    run(ops.conv2d(xa, wp, kp, bp, y, k, k, s, s, p, p, cin, cout, act, res=ra, alpha_acc=0.75, alpha_res=1.25, tile=tile))
+    ref = F.conv2d(q(x, dt), q(w, dt), bias, s, p)
+    ref = {ops.ACT_NONE: lambda t: t, ops.ACT_SILU: F.silu, ops.ACT_GELU: F.gelu}[act](ref) * 0.75
+    if use_res:
+        ref = ref + 1.25 * q(res, dt)
+    close(from_act(y), ref, dt, f"conv {case}")
+    assert float(ybuf[..., cout:].abs().max()) == 0.0, "conv wrote outside its channel slice"
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv2d_fp32_output_and_groups(dt):
+    rows, cin, cout = 300, 64, 192
+    x = rnd((2, rows, cin), 5)
+    w = rnd((2, cout, cin), 6, 1.0 / math.sqrt(cin))
+    b = rnd((2, cout), 7, 0.1)
+    res = rnd((2, rows, cout), 8)
+    xg = x.to(DEV).to(dt).contiguous()
+    rg = res.to(DEV).to(dt).contiguous()
+    packs = [ops.pack_matrix(w[g].to(DEV), dt) for g in range(2)]
+    wp = torch.stack([p_[0] for p_ in packs]).contiguous()
+    bp = torch.stack([ops.pack_bias(b[g].to(DEV), cout) for g in range(2)]).contiguous()
+    y = torch.zeros((2, rows, cout), dtype=dt, device=DEV)
+    gs = dict(x=xg.stride(0), w=wp.stride(0), bias=bp.stride(0), y=y.stride(0), res=rg.stride(0))
+    run(ops.conv2d(xg[0].view(rows, 1, 1, cin), wp, packs[0][1], bp, y[0].view(rows, 1, 1, cout), 1, 1, 1, 1, 0, 0, cin,
+                   cout, ops.ACT_GELU, res=rg[0].view(rows, 1, 1, cout), alpha_acc=(0.5, 2.0), alpha_res=(1.5, -1.0),
+                   groups=2, group_strides=gs))
+    for g, (aa, ar) in enumerate(((0.5, 1.5), (2.0, -1.0))):
+        ref = aa * F.gelu(q(x[g], dt) @ q(w[g], dt).t() + b[g]) + ar * q(res[g], dt)
+        close(y[g].float().cpu(), ref, dt, f"grouped linear g={g}")
+    # fp32 output from a 16-bit compute type (Detect convs)
+    y32 = torch.zeros((rows, 1, 1, 20), dtype=torch.float32, device=DEV)
+    w2 = rnd((18, cin), 9, 0.2)
+    wp2, kp2 = ops.pack_matrix(w2.to(DEV), dt)
+    run(ops.conv2d(xg[0].view(rows, 1, 1, cin), wp2, kp2, None, y32[..., :18], 1, 1, 1, 1, 0, 0, cin, 18, ops.ACT_NONE))
+    close(y32[:, 0, 0, :18].cpu(), q(x[0], dt) @ q(w2, dt).t(), dt, "fp32-out linear")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_first_layer_space_to_depth(dt):
+    """6x6/s2/p2 conv over the image == preprocess(mode 1) + 3x3/s1/p1 conv with re-indexed weights."""
+    B, H, W, cout = 2, 64, 96, 32
+    img = torch.from_numpy(np.random.default_rng(1).random((B, 3, H, W), dtype=np.float32))
+    w = rnd((cout, 3, 6, 6), 2, 0.1)
+    bias = rnd((cout,), 3, 0.1)
+    vec = ops.VEC[dt]
+    cpad = -(-12 // vec) * vec
+    pre = torch.zeros((B, H // 2, W // 2, cpad), dtype=dt, device=DEV)
+    run(ops.preprocess(img.to(DEV), pre, 1))
+    wp, kp = ops.pack_conv_weight(ops.s2d_conv_weight(w.to(DEV)), dt, cpad)
+    y = torch.zeros((B, H // 2, W // 2, cout), dtype=dt, device=DEV)
+    run(ops.conv2d(pre, wp, kp, ops.pack_bias(bias.to(DEV), cout), y, 3, 3, 1, 1, 1, 1, cpad, cout, ops.ACT_SILU))
+    ref = F.silu(F.conv2d(q(img, dt), q(w, dt), bias, 2, 2))
+    close(from_act(y), ref, dt, "stem conv")
+    # mode 0 (plain pad)
+    pad = torch.zeros((B, H, W, vec), dtype=dt, device=DEV)
+    run(ops.preprocess(img.to(DEV), pad, 0))
+    assert torch.equal(pad[..., :3].float().cpu(), q(img, dt).permute(0, 2, 3, 1))
+    assert float(pad[..., 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_sppf_upsample_copy(dt):
+    x = rnd((2, 64, 20, 12), 11)
+    cat = torch.zeros((2, 20, 12, 256), dtype=dt, device=DEV)
+    cat[..., :64] = to_act(x, dt)
+    run(ops.sppf_pool(cat[..., :64], cat[..., 64:128], cat[..., 128:192], cat[..., 192:], 5))
+    y1 = F.max_pool2d(q(x, dt), 5, 1, 2); y2 = F.max_pool2d(y1, 5, 1, 2); y3 = F.max_pool2d(y2, 5, 1, 2)
+    assert torch.equal(from_act(cat), torch.cat((q(x, dt), y1, y2, y3), 1))
+    up = torch.zeros((2, 40, 24, 96), dtype=dt, device=DEV)
+    run(ops.upsample_nearest(cat[..., :64], up[..., 32:], 2))
+    assert torch.equal(from_act(up[..., 32:]), F.interpolate(q(x, dt), scale_factor=2, mode="nearest"))
+    assert float(up[..., :32].abs().max()) == 0.0
+    cp = torch.zeros((2, 20, 12, 80), dtype=dt, device=DEV)
+    run(ops.copy_channels(cat[..., 64:128], cp[..., 16:]))
+    assert torch.equal(from_act(cp[..., 16:]), y1)
+
+
+POOL_CASES = [(2, 128, 40, 40, 20, 20), (1, 64, 40, 40, 16, 16), (1, 64, 64, 80, 20, 20), (2, 32, 10, 10, 10, 10),
+              (1, 64, 68, 84, 20, 20)]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", POOL_CASES)
+def test_dmff_pool_tokens_and_upsample_merge(case, dt):
+    B, C, H, W, va, ha = case
+    rgb, ir = rnd((B, C, H, W), 21), rnd((B, C, H, W), 22)
+    pos_v, pos_i = rnd((1, va * ha, C), 23, 0.3), rnd((1, va * ha, C), 24, 0.3)
+    w_v, w_i = (0.4, 0.7), (0.55, 0.35)
+    from icafusion_amd.models.common import AdaptivePool2d
+    th, tw, kh, kw, sh, sw = AdaptivePool2d(va, ha).window(H, W)
+    ra, ia = to_act(rgb, dt, pad_to=C + 16), to_act(ir, dt)
+    tok = torch.zeros((2, B * th * tw, C), dtype=dt, device=DEV)
+    run(ops.dmff_pool_tokens(ra, ia, pos_v.reshape(-1).to(DEV), pos_i.reshape(-1).to(DEV), tok, th, tw, kh, kw, sh, sw, w_v, w_i))
+    ref_v = oracle.pooled_tokens(q(rgb, dt), va, ha, torch.tensor(w_v[0]), torch.tensor(w_v[1]), pos_v)
+    ref_i = oracle.pooled_tokens(q(ir, dt), va, ha, torch.tensor(w_i[0]), torch.tensor(w_i[1]), pos_i)
+    close(tok[0].float().cpu().reshape(B, -1, C), ref_v, dt, "pool tokens rgb")
+    close(tok[1].float().cpu().reshape(B, -1, C), ref_i, dt, "pool tokens ir")
+    # bilinear back-projection + residual + concat, fed with the kernel's own (rounded) tokens
+    out = torch.zeros((B, H, W, 2 * C), dtype=dt, device=DEV)
+    run(ops.dmff_upsample_merge(tok, ra, ia, out, th, tw))
+    tv = tok[0].float().cpu().reshape(B, th, tw, C).permute(0, 3, 1, 2)
+    ti = tok[1].float().cpu().reshape(B, th, tw, C).permute(0, 3, 1, 2)
+    ref = torch.cat((oracle.bilinear_resize(tv, H, W) + q(rgb, dt), oracle.bilinear_resize(ti, H, W) + q(ir, dt)), 1)
+    close(from_act(out), ref, dt, "upsample merge")
+    if dt == torch.float32:   # the oracle's bilinear itself equals torch's
+        assert torch.allclose(oracle.bilinear_resize(tv, H, W), F.interpolate(tv, size=(H, W), mode="bilinear"), atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C", [64, 128, 512, 1024])
+def test_layernorm(C, dt):
+    rows = 37
+    x = rnd((2, rows, C), 31, 2.0) + 0.5
+    g, b = rnd((2, C), 32, 0.2) + 1.0, rnd((2, C), 33, 0.1)
+    xg = x.to(DEV).to(dt)
+    y = torch.zeros_like(xg)
+    gg, bb = g.to(DEV), b.to(DEV)
+    run(ops.layernorm(xg, y, gg[0].contiguous(), bb[0].contiguous(), gg[1].contiguous(), bb[1].contiguous()))
+    for k in range(2):
+        close(y[k].float().cpu(), oracle.layer_norm(q(x[k], dt), g[k], b[k]), dt, f"layernorm g{k}", factor=2)
+
+
+ATT_CASES = [(2, 400, 128), (1, 256, 256), (2, 100, 512), (1, 100, 1024), (1, 77, 128), (1, 400, 256), (1, 256, 384),
+             (1, 36, 64)]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", ATT_CASES)
+def test_cross_attention(case, dt):
+    B, N, C = case
+    heads, dk = 8, case[2] // 8
+    if dk % ops.VEC[dt]:
+        pytest.skip("head dim not a multiple of the 16-byte vector for this dtype")
+    qkv = rnd((2, B * N, 3 * C), 41, 1.0)
+    qkv[:, :, :2 * C] *= 1.5                      # sharpen the softmax a little
+    qg = qkv.to(DEV).to(dt).contiguous()
+    out = torch.zeros((2, B * N, C), dtype=dt, device=DEV)
+    run(ops.cross_attention(qg, out, B, N, heads))
+    f = q(qkv, dt).reshape(2, B, N, 3, heads, dk)
+    for d in range(2):
+        qq = f[1 - d, :, :, 0].permute(0, 2, 1, 3)          # queries come from the OTHER modality
+        kk = f[d, :, :, 1].permute(0, 2, 1, 3)
+        vv = f[d, :, :, 2].permute(0, 2, 1, 3)
+        att = torch.softmax(qq @ kk.transpose(-1, -2) / math.sqrt(dk), -1)
+        ref = (att @ vv).permute(0, 2, 1, 3).reshape(B * N, C)
+        close(out[d].float().cpu(), ref, dt, f"cross attention dir {d} {case}", factor=2)
+
+
+def test_cross_attention_softmax_spike():
+    """Force the online-softmax rescale branch: one key dominates late in the key order."""
+    B, N, C, heads = 1, 256, 128, 8
+    qkv = rnd((2, B * N, 3 * C), 43, 0.3)
+    qkv[0, 200, C:2 * C] = 6.0
+    qkv[1, :, :C] = qkv[1, :, :C].abs() + 0.5
+    qg = qkv.to(DEV).contiguous()
+    out = torch.zeros((2, B * N, C), dtype=torch.float32, device=DEV)
+    run(ops.cross_attention(qg, out, B, N, heads))
+    f = qkv.reshape(2, B, N, 3, heads, 16)
+    qq, kk, vv = (f[1, :, :, 0].permute(0, 2, 1, 3), f[0, :, :, 1].permute(0, 2, 1, 3), f[0, :, :, 2].permute(0, 2, 1, 3))
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2) / 4.0, -1) @ vv).permute(0, 2, 1, 3).reshape(B * N, C)
+    close(out[0].cpu(), ref, torch.float32, "spiked softmax")
+
+
+@pytest.mark.parametrize("nc", [1, 9])
+def test_detect_decode(nc):
+    B, na, no = 2, 3, nc + 5
+    anchors = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+    dims = [(12, 20), (6, 10), (3, 5)]
+    rows = sum(na * h * w for h, w in dims)
+    z = torch.zeros((B, rows, no), dtype=torch.float32, device=DEV)
+    lg = torch.zeros((B, rows, nc), dtype=torch.float32, device=DEV)
+    feats, raws, off = [], [], 0
+    for l, (h, w) in enumerate(dims):
+        p = rnd((B, na * no, h, w), 50 + l, 2.0)
+        feats.append(p)
+        pa = torch.zeros((B, h, w, na * no + 2), dtype=torch.float32, device=DEV)
+        pa[..., :na * no] = p.permute(0, 2, 3, 1).to(DEV)
+        raw = torch.zeros((B, na, h, w, no), dtype=torch.float32, device=DEV)
+        run(ops.detect_decode(pa[..., :na * no], z, lg, raw, na, no, off, oracle.STRIDES[l], anchors[l]))
+        raws.append(raw)
+        off += na * h * w
+    # oracle: identity "conv" weights so detect() sees the same maps
+    sd = {}
+    for l in range(3):
+        sd[f"d.m.{l}.weight"] = torch.eye(na * no).reshape(na * no, na * no, 1, 1)
+        sd[f"d.m.{l}.bias"] = torch.zeros(na * no)
+    rz, rl, rr = oracle.detect(feats, sd, "d", nc, anchors)
+    assert torch.allclose(z.cpu(), rz, rtol=1e-6, atol=1e-5)
+    assert torch.equal(lg.cpu(), rl)
+    for a, b in zip(raws, rr):
+        assert torch.equal(a.cpu(), b)
+
+
+def _rand_pred(B, rows, nc, seed, ties=False):
+    g = np.random.default_rng(seed)
+    xy = g.uniform(0, 640, (B, rows, 2))
+    wh = g.uniform(4, 220, (B, rows, 2))
+    obj = g.uniform(0, 1, (B, rows, 1))
+    cls = g.uniform(0, 1, (B, rows, nc))
+    p = np.concatenate((xy, wh, obj, cls), 2).astype(np.float32)
+    if ties:
+        p[:, 50:400, 4:] = p[:, 50:51, 4:]           # many identical scores: order must fall back to the index
+    return p
+
+
+NMS_CASES = [
+    dict(B=2, rows=3000, nc=1, conf=0.25, iou=0.45),
+    dict(B=3, rows=25200, nc=1, conf=0.001, iou=0.5),
+    dict(B=2, rows=5000, nc=9, conf=0.2, iou=0.5, multi_label=True),
+    dict(B=1, rows=6300, nc=9, conf=0.05, iou=0.6, multi_label=True),        # > max_nms candidates
+    dict(B=2, rows=2000, nc=4, conf=0.3, iou=0.5, agnostic=True, classes=[0, 2]),
+    dict(B=2, rows=1500, nc=1, conf=0.1, iou=0.5, ties=True),
+    dict(B=2, rows=800, nc=3, conf=0.999, iou=0.5),                           # nothing survives
+    dict(B=1, rows=37, nc=2, conf=0.05, iou=0.3, multi_label=True),
+]
+
+
+@pytest.mark.parametrize("case", NMS_CASES)
+def test_nms_bit_exact(case):
+    from icafusion_amd.utils.general import nms_device, non_max_suppression
+    c = dict(case)
+    B, rows, nc = c.pop("B"), c.pop("rows"), c.pop("nc")
+    conf, iou, ties = c.pop("conf"), c.pop("iou"), c.pop("ties", False)
+    pred = _rand_pred(B, rows, nc, seed=rows + nc, ties=ties)
+    ref, ref_idx = oracle.non_max_suppression(pred, conf, iou, return_indices=True, **c)
+    pt = torch.from_numpy(pred).to(DEV)
+    got = non_max_suppression(pt, conf, iou, **c)
+    det, count, keep = nms_device(pt, conf, iou, **c)
+    for b in range(B):
+        np.testing.assert_array_equal(got[b].cpu().numpy(), ref[b])
+        n = int(count[b])
+        assert n == len(ref_idx[b])
+        np.testing.assert_array_equal(keep[b, :n].cpu().numpy().astype(np.int64), ref_idx[b])
+
+
+@pytest.mark.parametrize("name,src", [("nms_s_conf25", "model_s_kaist_320_b2"), ("nms_s_conf30", "model_s_kaist_320_b2"),
+                                      ("nms_s_conf001_iou5", "model_s_kaist_320_b2"),
+                                      ("nms_l_multilabel", "model_l_vedai_320_b1"),
+                                      ("nms_l_agnostic_classes", "model_l_vedai_320_b1")])
+def test_nms_golden_fixtures(name, src):
+    """Against the committed outputs of the reference's own non_max_suppression wrapper."""
+    from helpers import load_golden
+    from icafusion_amd.utils.general import non_max_suppression
+    g, z = load_golden(name), load_golden(src)["z"]
+    kw = dict(eval(str(g["kw"])))
+    got = non_max_suppression(torch.from_numpy(z).to(DEV), **kw)
+    for i, o in enumerate(got):
+        np.testing.assert_array_equal(o.cpu().numpy(), g[f"det{i}"])
+
+
+def test_graph_capture_replays_conv():
+    dt = torch.bfloat16
+    x = rnd((1, 64, 16, 16), 61)
+    w = rnd((64, 64, 3, 3), 62, 0.05)
+    plan = Plan(DEV, dt)
+    xa = to_act(x, dt)
+    wp, kp = ops.pack_conv_weight(w.to(DEV), dt)
+    y = plan.act(1, 16, 16, 64)
+    plan.add(ops.conv2d(xa, wp, kp, None, y, 3, 3, 1, 1, 1, 1, 64, 64, ops.ACT_SILU))
+    plan.run(); torch.cuda.synchronize()
+    eager = y.clone()
+    y.zero_()
+    plan.capture()
+    y.zero_()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        plan.run(s.cuda_stream)
+    s.synchronize()
+    assert torch.equal(y, eager)

@@ -1,0 +1,111 @@
+"""CPU-only checks of the host side: config surface, module tree / state_dict layout, C-ABI export table, error paths."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import yaml
+
+from helpers import REPO, load_cfg
+from icafusion_amd import _lib, configs
+from icafusion_amd.models.common import Conv, TransformerFusionBlock
+from icafusion_amd.models.yolo import Model, parse_model
+
+
+def test_library_exports_every_header_symbol():
+    """libicaf.so loads and exports exactly the functions include/icaf.h declares (no compute calls: no GPU here)."""
+    if not os.path.exists(_lib.LIB_PATH):
+        from icafusion_amd.build import build
+        build(verbose=False)
+    header = open(os.path.join(REPO, "include", "icaf.h")).read()
+    declared = set(re.findall(r"\b(icaf_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    handle = _lib.lib()
+    for name in declared:
+        assert hasattr(handle, name)
+    assert handle.icaf_version() >= 100
+    assert ctypes.sizeof(_lib.ConvArgs) == 184      # static_assert'ed on the C side (igemm.hip)
+
+
+def test_yaml_generator_is_in_sync():
+    for size, tag, nc in configs.VARIANTS:
+        name = f"yolov5{size}_Transfusion_{tag}.yaml"
+        assert load_cfg(name) == configs.transfusion_cfg(size, nc), name
+    data = yaml.safe_load(open(os.path.join(REPO, "data", "multispectral", "kaist.yaml")))
+    assert set(data) == {"path", "train_rgb", "val_rgb", "train_ir", "val_ir", "nc", "names"}
+
+
+@pytest.mark.parametrize("name,params", [("yolov5s_Transfusion_kaist.yaml", 23261018)])
+def test_model_construction_api(name, params):
+    m = Model(os.path.join(REPO, "models", "transformer", name))
+    assert sum(p.numel() for p in m.parameters()) == params
+    assert len(m.model) == 38 and m.model[10].f == -4 and m.model[20].f == [4, 14]
+    assert [type(l).__name__ for l in m.model][20:23] == ["TransformerFusionBlock"] * 3
+    assert m.save == [4, 6, 6, 9, 14, 16, 19, 20, 21, 23, 27, 30, 33, 36]          # incl. the reference's duplicate 6
+    assert m.stride.tolist() == [8.0, 16.0, 32.0] and m.names == ["0"]
+    det = m.model[-1]
+    assert (det.nl, det.na, det.no) == (3, 3, 6)
+    assert torch.allclose(det.anchors[0] * 8, det.anchor_grid[0].view(3, 2))
+    assert all(b.eps == 1e-3 for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d))
+    keys = set(m.state_dict())
+    for k in ("model.0.conv.weight", "model.20.pos_emb_vis", "model.20.vis_coefficient.w1",
+              "model.20.crosstransformer.0.crossatt.que_proj_vis.weight", "model.20.crosstransformer.0.ln_input.weight",
+              "model.20.crosstransformer.0.mlp.2.bias", "model.20.crosstransformer.0.coefficient8.bias",
+              "model.20.conv1x1_out.bn.running_var", "model.37.m.2.bias", "model.37.anchor_grid"):
+        assert k in keys, k
+    assert len(keys) == 728
+    # overrides
+    m2 = Model(load_cfg(name), nc=3)
+    assert m2.model[-1].no == 8 and m2.yaml["nc"] == 3
+    # drop-in module paths (pickled reference checkpoints resolve these)
+    import models.common as mc
+    import models.yolo_test as myt
+    import models.yolo as my
+    assert myt.Model is Model and my.Model is Model and mc.Conv is Conv and mc.TransformerFusionBlock is TransformerFusionBlock
+
+
+def test_loops_argument_and_unsupported_modules():
+    cfg = load_cfg("yolov5s_Transfusion_kaist_loops3.yaml")
+    m = Model(cfg)
+    assert all(m.model[i].crosstransformer[0].loops == 3 for i in (20, 21, 22))
+    bad = load_cfg("yolov5s_Transfusion_kaist.yaml")
+    bad["backbone"][1] = [-1, 1, "GhostConv", [128, 3, 2]]
+    with pytest.raises(NotImplementedError):
+        Model(bad)
+
+
+def test_no_cpu_fallback_and_fuse():
+    m = Model(load_cfg("yolov5s_Transfusion_kaist.yaml")).eval()
+    x = torch.zeros(1, 3, 64, 64)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(x, x)
+    with pytest.raises(NotImplementedError):
+        m.train()(x, x)
+    m.fuse()
+    assert not any(hasattr(c, "bn") for c in m.modules() if type(c) is Conv)
+    assert "model.0.conv.bias" in m.state_dict()
+    from icafusion_amd.utils.general import non_max_suppression
+    with pytest.raises(RuntimeError):
+        non_max_suppression(torch.zeros(1, 10, 6), 0.25, 0.45)
+
+
+def test_layer_shapes_and_concat_placement():
+    m = Model(load_cfg("yolov5s_Transfusion_kaist.yaml"))
+    shapes = m._layer_shapes(1, 640, 640)
+    assert shapes[0] == (32, 320, 320) and shapes[9] == (512, 20, 20) and shapes[20] == (128, 80, 80)
+    assert shapes[25] == (512, 40, 40) and shapes[29] == (256, 80, 80) and shapes[36] == (512, 20, 20)
+
+
+def test_host_metrics_match_reference_fixture():
+    import numpy as np
+    from helpers import load_golden
+    from icafusion_amd.utils.metrics import ap_per_class
+    from icafusion_amd.utils.general import box_iou, scale_coords
+    g = load_golden("metrics_ap")
+    r = ap_per_class(g["tp"], g["conf"], g["pcls"], g["tcls"])
+    np.testing.assert_allclose(r[5], g["ap"], rtol=1e-9)
+    np.testing.assert_allclose(r[3], g["p"], rtol=1e-9)
+    np.testing.assert_allclose(r[4], g["r"], rtol=1e-9)
+    np.testing.assert_allclose(box_iou(torch.from_numpy(g["box1"]), torch.from_numpy(g["box2"])).numpy(), g["iou"], rtol=1e-6)
+    np.testing.assert_allclose(scale_coords((512, 640), torch.from_numpy(g["coords"]).clone(), (480, 720)).numpy(), g["scaled"], rtol=1e-6)
