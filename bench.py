@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py — RGB/IR image-pairs/sec of the ICAFusion hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One step = one pass of the hot path over one batch of synthetic pairs already resident in HBM:
+two-stream backbone -> 3x DMFF -> PANet head -> Detect (one hipGraph replay) -> device NMS -> [N>1: RCCL all-gather
+of the detection blocks].  Default workload = BASELINE.json configs[1]: yolov5s + DMFF, bf16, batch 32, 640x640.
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel, HIP-event timed) and
+`cpu_baseline` (the CPU oracle = a port of the reference's algorithm, timed on this host's cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import yaml   # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+# algorithmic FLOPs per pair (2*MAC of conv + linear + bmm), SURVEY.md §8d / BASELINE.md
+GFLOP_PER_PAIR = {("s", 640, 640): 30.08, ("s", 512, 640): 24.61, ("l", 640, 640): 192.2, ("l", 1280, 1280): 738.9}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU (weak scaling)")
+    ap.add_argument("--height", type=int, default=640)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--model", default="s", choices=["n", "s", "m", "l"])
+    ap.add_argument("--dataset", default="kaist")
+    ap.add_argument("--dtype", default="bf16", choices=list(DT))
+    ap.add_argument("--loops", type=int, default=1)
+    ap.add_argument("--conf", type=float, default=0.1, help="detect_twostream.py default")
+    ap.add_argument("--iou", type=float, default=0.5)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, args, loops):
+    """Oracle forward + oracle NMS on host cores, bounded sample (checker code used as the measured CPU port).
+    The thread count is calibrated first: with every hardware thread of a large host, torch's CPU convs oversubscribe
+    badly on these small layers, so the best of a few counts is used and reported as `cores`."""
+    from icafusion_amd.synth import synth_images
+    from oracle import icaf_oracle as oracle
+    om = oracle.OracleModel(cfg, sd, loops=loops)
+    r1, i1 = synth_images(1, args.height, args.width, seed=0)
+    ncpu = os.cpu_count() or 1
+    best_thr, best_t = 1, float("inf")
+    for thr in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+        torch.set_num_threads(thr)
+        om.forward(r1, i1)
+        t0 = time.perf_counter()
+        om.forward(r1, i1)
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best_thr, best_t = thr, dt
+        if dt > 5.0:
+            break
+    torch.set_num_threads(best_thr)
+    bs = 4
+    rgb, ir = synth_images(bs, args.height, args.width, seed=0)
+    t_fwd = t_nms = 0.0
+    n = 0
+    t_start = time.perf_counter()
+    while n < 16 and (n == 0 or (time.perf_counter() - t_start) < args.cpu_seconds):
+        t0 = time.perf_counter()
+        z = om.forward(rgb, ir)[0]
+        t1 = time.perf_counter()
+        oracle.non_max_suppression(z.numpy(), args.conf, args.iou)
+        t2 = time.perf_counter()
+        t_fwd += t1 - t0
+        t_nms += t2 - t1
+        n += 1
+    pairs = n * bs
+    return {"value": round(pairs / (t_fwd + t_nms), 3), "unit": "pairs/s", "cores": best_thr, "host_cpus": ncpu,
+            "kind": "port", "forward_pairs_per_s": round(pairs / t_fwd, 3), "nms_ms_per_pair": round(1e3 * t_nms / pairs, 3),
+            "sample": f"{n} batches of {bs} pairs, {args.height}x{args.width}, fp32 torch-CPU oracle forward + C/numpy NMS "
+                      f"(oracle/icaf_oracle.py), same synthetic weights/inputs recipe, {best_thr} threads (best of 8/16/32/64)"}
+
+
+def main():
+    args = parse()
+    from icafusion_amd import dist as D
+    from icafusion_amd import ops
+    from icafusion_amd.models.yolo import Model
+    from icafusion_amd.synth import synth_images, synth_state_dict
+    from icafusion_amd.utils.general import nms_device
+    import torch.distributed as tdist
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    tag = {"kaist": "kaist", "FLIR": "FLIR", "VEDAI": "VEDAI", "LLVIP": "LLVIP"}[args.dataset]
+    yaml_name = f"yolov5{args.model}_Transfusion_{tag}.yaml"
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "models", "transformer", yaml_name)))
+    model = Model(cfg).eval()
+    sd = synth_state_dict(model, seed=0)
+    model.load_state_dict(sd)
+    for i in (20, 21, 22):
+        model.model[i].crosstransformer[0].loops = args.loops
+    model = model.to(dev)
+    model.compute_dtype = DT[args.dtype]
+    model.static_outputs = True
+    B, H, W = args.batch, args.height, args.width
+    plan = model.plan_for(B, H, W, dev)
+    # inputs resident in HBM before the timed region: each rank synthesises its own shard of the global batch
+    lo, hi = D.shard_range(B * world, rank, world)
+    rgb, ir = synth_images(B, H, W, seed=100 + rank)
+    plan.inputs[0].copy_(rgb.to(dev))
+    plan.inputs[1].copy_(ir.to(dev))
+    nc = cfg["nc"]
+    z = plan.outputs[0]
+    stream = torch.cuda.Stream(device=dev)
+    sp = stream.cuda_stream
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        plan.capture()
+
+    gathered = torch.empty((world * B, 300 * 6 + 1), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        plan.run(sp)
+        det, count, _ = nms_device(z, args.conf, args.iou, stream_ptr=sp)
+        if world > 1:
+            D.gather_detections(det, count, out=gathered)       # issued on `stream` (the current torch stream)
+        return det, count
+
+    def barrier():
+        if world > 1:
+            tdist.barrier()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(args.steps):
+            det, count = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- forward-only rate and per-kernel HIP-event timing (instrumented pass, outside the timed region) -------
+    ev0, ev1 = ops.Event(), ops.Event()
+    ev0.record(sp)
+    for _ in range(args.steps):
+        plan.run(sp)
+    ev1.record(sp)
+    fwd_ms = ev0.elapsed_ms(ev1) / args.steps
+    saved_graph, plan.graph = plan.graph, None
+    per_kernel = {}
+    reps = 3
+    for _ in range(reps):
+        for l, (name, ms, flops, nbytes) in zip(plan.launches, plan.timed_run(sp)):
+            kname = ops.conv_kernel_name(l) if l.fn is ops.lib().icaf_conv2d else name
+            d = per_kernel.setdefault(kname, [0.0, 0.0, 0.0, 0])
+            d[0] += ms; d[1] += flops; d[2] += nbytes; d[3] += 1
+    plan.graph = saved_graph
+    total_ms = sum(v[0] for v in per_kernel.values()) / reps
+    dom = max(per_kernel.items(), key=lambda kv: kv[1][0])
+    dname, (dms, dflops, dbytes, dn) = dom
+    is_mfma = dflops > 0
+    if is_mfma:
+        achieved = dflops / (dms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype],
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4)}
+    else:
+        achieved = dbytes / (dms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dname, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(achieved / PEAK_HBM_GBS, 4)}
+    roof.update({"traffic": None, "avg_launch_us": round(1e3 * dms / dn, 2), "launches_per_step": dn // reps,
+                 "share_of_forward_kernel_time": round(dms / reps / total_ms, 3)})
+    att = per_kernel.get("cross_attention")
+    kernels = {k: {"ms_per_step": round(v[0] / reps, 4), "launches": v[3] // reps,
+                   "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[1] else None,
+                   "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1)} for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
+
+    if rank == 0:
+        pairs = B * world * args.steps
+        value = pairs / elapsed
+        gf = GFLOP_PER_PAIR.get((args.model, H, W))
+        out = {
+            "metric": "RGB/IR image-pairs/sec (two-stream forward + NMS)", "value": round(value, 2), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{yaml_name[:-5]} + DMFF(loops={args.loops}) {args.dtype}, batch {B}/GPU, "
+                                   f"{H}x{W} synthetic RGB/IR pairs, seeded random weights, NMS conf {args.conf} iou {args.iou}",
+                       "global_batch": B * world, "parallelism": f"dp{world} (pairs sharded, one all-gather of detections)",
+                       "graph": not args.no_graph},
+            "forward_only_pairs_per_s": round(B / (fwd_ms * 1e-3), 2),
+            "forward_ms_per_batch": round(fwd_ms, 3),
+            "model_tflops": round(gf * B / (fwd_ms * 1e-3) / 1e3, 2) if gf else None,
+            "roofline": roof,
+            "attention_kernel": None if att is None else {
+                "tflops": round(att[1] / (att[0] * 1e-3) / 1e12, 2), "ms_per_step": round(att[0] / reps, 4),
+                "mfma_frac_of_dense_peak": round(att[1] / (att[0] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4)},
+            "kernels": kernels,
+            "plan_buffer_MB": round(plan.nbytes / 2 ** 20, 1),
+            "detections_first_image": int(count[0]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, args, args.loops)
+        print(json.dumps(out))
+    if world > 1:
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

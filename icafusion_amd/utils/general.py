@@ -66,7 +66,7 @@ def box_iou(box1, box2):
 
 
 def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-               max_det=300, max_nms=30000, max_wh=4096.0):
+               max_det=300, max_nms=30000, max_wh=4096.0, stream_ptr=None):
     """Device-resident NMS: returns (det (B,max_det,6), count (B,), keep_idx (B,max_det)) without any host sync."""
     if not prediction.is_cuda:
         raise RuntimeError("non_max_suppression runs on the MI355X only (no CPU fallback; see oracle/ for the "
@@ -78,7 +78,7 @@ def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     key = (B, rows, nc, ml, max_det, pred.device)
     if key not in _RUNNERS:
         _RUNNERS[key] = ops.NmsRunner(B, rows, nc, pred.device, ml, max_det)
-    return _RUNNERS[key].launch(pred, conf_thres, iou_thres, agnostic, classes, max_nms, max_wh)
+    return _RUNNERS[key].launch(pred, conf_thres, iou_thres, agnostic, classes, max_nms, max_wh, stream_ptr)
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Per-launch HIP-event timing of one forward plan (GPU box): which layers dominate and how far each is from the
+MFMA / HBM roofs.  Usage: python tools/layer_profile.py [--model s --batch 32 --size 640 --dtype bf16]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch   # noqa: E402
+import yaml    # noqa: E402
+
+from icafusion_amd import ops                      # noqa: E402
+from icafusion_amd.models.yolo import Model        # noqa: E402
+from icafusion_amd.synth import synth_images, synth_state_dict   # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="s"); ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--size", type=int, default=640); ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
+cfg = yaml.safe_load(open(os.path.join(ROOT, "models", "transformer", f"yolov5{a.model}_Transfusion_kaist.yaml")))
+m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 0)); m = m.to("cuda:0"); m.compute_dtype = dt
+plan = m.plan_for(a.batch, a.size, a.size, "cuda:0")
+rgb, ir = synth_images(a.batch, a.size, a.size, 0)
+plan.inputs[0].copy_(rgb.cuda()); plan.inputs[1].copy_(ir.cuda())
+plan.run(); torch.cuda.synchronize()
+acc = None
+for _ in range(a.reps):
+    r = plan.timed_run()
+    acc = [x[1] for x in r] if acc is None else [p + x[1] for p, x in zip(acc, r)]
+rows = []
+for l, ms in zip(plan.launches, acc):
+    ms /= a.reps
+    desc = l.name
+    if l.fn is ops.lib().icaf_conv2d:
+        c = l.keep[0]
+        desc = f"{ops.conv_kernel_name(l):26s} {l.name:12s} M={c.B * c.Ho * c.Wo:8d} N={c.Cout:5d} K={c.kh * c.kw * c.Cin:5d} g={c.groups} {c.Ho}x{c.Wo}"
+    rows.append((ms, l.flops / (ms * 1e-3) / 1e12 if l.flops else 0.0, l.bytes / (ms * 1e-3) / 1e9, desc))
+tot = sum(r[0] for r in rows)
+print(f"total kernel time {tot:.3f} ms for batch {a.batch}: {a.batch / tot * 1e3:.0f} pairs/s")
+for i, (ms, tf, gb, d) in enumerate(rows):
+    print(f"{i:3d} {ms * 1e3:8.1f} us {tf:7.1f} TF {gb:7.0f} GB/s  {d}")
