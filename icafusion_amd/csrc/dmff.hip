@@ -147,14 +147,14 @@ template <> __device__ __forceinline__ u32x4 pack_p<ICAF_BF16>(const f32x16& s, 
     u32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-        v[e] = (unsigned)f32_to_bf16(s[8 * st + 2 * e]) | ((unsigned)f32_to_bf16(s[8 * st + 2 * e + 1]) << 16);
+        v[e] = pack2_bf16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
     return v;
 }
 template <> __device__ __forceinline__ u32x4 pack_p<ICAF_F16>(const f32x16& s, int st) {
     u32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-        v[e] = (unsigned)f32_to_f16(s[8 * st + 2 * e]) | ((unsigned)f32_to_f16(s[8 * st + 2 * e + 1]) << 16);
+        v[e] = pack2_f16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
     return v;
 }
 
@@ -284,13 +284,13 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const typename Elem<DT>
                             *(f32x4*)(orow + d0) = f32x4{v0, v1, v2, v3};
                         } else if constexpr (DT == ICAF_BF16) {
                             u32x2 pk;
-                            pk[0] = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
-                            pk[1] = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
+                            pk[0] = pack2_bf16(v0, v1);
+                            pk[1] = pack2_bf16(v2, v3);
                             *(u32x2*)(orow + d0) = pk;
                         } else {
                             u32x2 pk;
-                            pk[0] = (unsigned)f32_to_f16(v0) | ((unsigned)f32_to_f16(v1) << 16);
-                            pk[1] = (unsigned)f32_to_f16(v2) | ((unsigned)f32_to_f16(v3) << 16);
+                            pk[0] = pack2_f16(v0, v1);
+                            pk[1] = pack2_f16(v2, v3);
                             *(u32x2*)(orow + d0) = pk;
                         }
                     }

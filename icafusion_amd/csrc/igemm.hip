@@ -43,7 +43,7 @@ template <int ACT> __device__ __forceinline__ float apply_act(float v) {
     else return v;
 }
 
-template <int DT, int ODT, int BM, int BN, int WM, int WN>
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
     using E = Elem<DT>;
     using EO = Elem<ODT>;
@@ -195,10 +195,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float t = acc[a][b][4 * q + j] + bv[j];
-                    if (p.act == ICAF_ACT_SILU) t = silu_f(t);
-                    else if (p.act == ICAF_ACT_GELU) t = gelu_f(t);
-                    v[j] = t * alpha_acc;
+                    v[j] = apply_act<ACT>(acc[a][b][4 * q + j] + bv[j]) * alpha_acc;
                 }
                 unsigned char* dst = lds + ml * SO + nl * EO::BYTES;
                 if constexpr (EO::BYTES == 4) {
@@ -206,11 +203,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
                 } else {
                     u32x2 pk;
                     if constexpr (ODT == ICAF_BF16) {
-                        pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                        pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                        pk[0] = pack2_bf16(v[0], v[1]);
+                        pk[1] = pack2_bf16(v[2], v[3]);
                     } else {
-                        pk[0] = (unsigned)f32_to_f16(v[0]) | ((unsigned)f32_to_f16(v[1]) << 16);
-                        pk[1] = (unsigned)f32_to_f16(v[2]) | ((unsigned)f32_to_f16(v[3]) << 16);
+                        pk[0] = pack2_f16(v[0], v[1]);
+                        pk[1] = pack2_f16(v[2], v[3]);
                     }
                     *(u32x2*)dst = pk;
                 }
@@ -228,9 +225,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
         const int m = m0 + row, n = n0 + cv * VO;
         if (m >= p.M || n >= p.Cout) continue;
         const u32x4 sv = *(const u32x4*)(lds + row * SO + cv * 16);
+        const int nvalid = (p.Cout - n) < VO ? (p.Cout - n) : VO;
+        if (!rg && p.vec_y && nvalid == VO) {        // common case: no residual — the staged vector is final
+            *(u32x4*)(yg + (long long)m * p.ldy + n) = sv;
+            continue;
+        }
         float v[VO];
         unpack16<ODT>(sv, v);
-        const int nvalid = (p.Cout - n) < VO ? (p.Cout - n) : VO;
         if (rg) {
             const typename E::type* rp = rg + (long long)m * p.ldr + n;
             if (p.vec_r && nvalid == VO) {
@@ -282,8 +283,10 @@ static int launch_cfg(const ConvP& p, int groups, hipStream_t s) {
     ConvP q = p;
     q.mtiles = (p.M + BM - 1) / BM;
     q.ntiles = (p.Cout + BN - 1) / BN;
-    dim3 grid((unsigned)(q.mtiles * q.ntiles), 1, (unsigned)groups);
-    hipLaunchKernelGGL((igemm_kernel<DT, ODT, BM, BN, WM, WN>), grid, dim3(NTHREADS), 0, s, q);
+    dim3 grid((unsigned)(q.mtiles * q.ntiles), 1, (unsigned)groups), block(NTHREADS);
+    if (p.act == ICAF_ACT_SILU) igemm_kernel<DT, ODT, BM, BN, WM, WN, ICAF_ACT_SILU><<<grid, block, 0, s>>>(q);
+    else if (p.act == ICAF_ACT_GELU) igemm_kernel<DT, ODT, BM, BN, WM, WN, ICAF_ACT_GELU><<<grid, block, 0, s>>>(q);
+    else igemm_kernel<DT, ODT, BM, BN, WM, WN, ICAF_ACT_NONE><<<grid, block, 0, s>>>(q);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
@@ -315,6 +318,7 @@ static int validate(const icaf_conv_args* a) {
         return fail(ICAF_ERR_ARG, "icaf_conv2d: output size does not match input/kernel/stride/padding");
     const int ka = a->dtype == ICAF_F32 ? 32 : 64;
     if (a->Kp % ka || a->Kp < a->kh * a->kw * a->Cin) return fail(ICAF_ERR_ARG, "icaf_conv2d: Kp=%d must be a multiple of %d covering K=%d", a->Kp, ka, a->kh * a->kw * a->Cin);
+    if (a->act < 0 || a->act > 2) return fail(ICAF_ERR_ARG, "icaf_conv2d: bad activation code %d", a->act);
     if (a->ldy < a->Cout) return fail(ICAF_ERR_ARG, "icaf_conv2d: ldy < Cout");
     if (a->res && a->ldr < a->Cout) return fail(ICAF_ERR_ARG, "icaf_conv2d: ldr < Cout");
     if ((long long)a->B * a->Ho * a->Wo > 0x7fffffffLL) return fail(ICAF_ERR_ARG, "icaf_conv2d: too many output pixels");

@@ -83,6 +83,64 @@ __global__ __launch_bounds__(256) void sppf_kernel(const typename Elem<DT>::type
     }
 }
 
+
+// LDS version (used whenever a whole H x W plane of VPB channel-vectors fits): the chained pools are done exactly as
+// the reference chains them — three rounds of a separable (horizontal, then vertical) k-max over the plane held in
+// LDS — so each output costs 2k LDS reads instead of (3k-2)^2 global reads.
+template <int DT>
+__global__ __launch_bounds__(256) void sppf_lds_kernel(const typename Elem<DT>::type* __restrict__ x, int ldx,
+                                                       typename Elem<DT>::type* __restrict__ y1, typename Elem<DT>::type* __restrict__ y2,
+                                                       typename Elem<DT>::type* __restrict__ y3, int ldy, int H, int W, int C, int k,
+                                                       int vpb) {
+    using E = Elem<DT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* cur = (u32x4*)smem;
+    u32x4* tmp = cur + (size_t)H * W * vpb;
+    const int nvb = (C / E::VEC) / vpb;                 // vector groups per image
+    const int b = blockIdx.x / nvb, vg = blockIdx.x - b * nvb;
+    const int n = H * W * vpb, r = k / 2;
+    const long long pix0 = (long long)b * H * W;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int v = i % vpb, p = i / vpb;
+        cur[i] = *(const u32x4*)(x + (pix0 + p) * ldx + (vg * vpb + v) * E::VEC);
+    }
+    __syncthreads();
+    typename E::type* outs[3] = {y1, y2, y3};
+#pragma unroll
+    for (int stage = 0; stage < 3; ++stage) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int v = i % vpb, p = i / vpb, xx = p % W, yy = p / W;
+            float m[E::VEC];
+            unpack16<DT>(cur[i], m);
+            for (int d = -r; d <= r; ++d) {
+                if (d == 0 || (unsigned)(xx + d) >= (unsigned)W) continue;
+                float f[E::VEC];
+                unpack16<DT>(cur[(yy * W + xx + d) * vpb + v], f);
+#pragma unroll
+                for (int j = 0; j < E::VEC; ++j) m[j] = fmaxf(m[j], f[j]);
+            }
+            tmp[i] = pack16<DT>(m);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int v = i % vpb, p = i / vpb, xx = p % W, yy = p / W;
+            float m[E::VEC];
+            unpack16<DT>(tmp[i], m);
+            for (int d = -r; d <= r; ++d) {
+                if (d == 0 || (unsigned)(yy + d) >= (unsigned)H) continue;
+                float f[E::VEC];
+                unpack16<DT>(tmp[((yy + d) * W + xx) * vpb + v], f);
+#pragma unroll
+                for (int j = 0; j < E::VEC; ++j) m[j] = fmaxf(m[j], f[j]);
+            }
+            const u32x4 o = pack16<DT>(m);
+            cur[i] = o;
+            *(u32x4*)(outs[stage] + (pix0 + p) * ldy + (vg * vpb + v) * E::VEC) = o;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- nearest-neighbour integer upsample (writes a channel slice of the consumer's concat buffer) ---------------
 __global__ __launch_bounds__(256) void upsample_kernel(const u32x4* __restrict__ x, int ldxv, u32x4* __restrict__ y, int ldyv,
                                                        int B, int H, int W, int nv, int scale) {
@@ -144,6 +202,19 @@ extern "C" int icaf_sppf_pool(const void* x, int ldx, void* y1, void* y2, void* 
     if (dtype < 0 || dtype > 2) return fail(ICAF_ERR_ARG, "icaf_sppf_pool: bad dtype");
     const int vec = vec_of(dtype);
     if (C % vec || ldx % vec || ldy % vec || !(k & 1)) return fail(ICAF_ERR_ARG, "icaf_sppf_pool: C/ld must be multiples of %d and k odd", vec);
+    const int nv = C / vec;
+    int vpb = 0;
+    for (int c : {8, 4, 2, 1})
+        if (nv % c == 0 && (size_t)H * W * c * 32 <= 60 * 1024) { vpb = c; break; }
+    if (vpb) {
+        const size_t lds = (size_t)H * W * vpb * 32;
+        dim3 grid((unsigned)(B * (nv / vpb))), block(256);
+        if (dtype == ICAF_F32) sppf_lds_kernel<ICAF_F32><<<grid, block, lds, S(s)>>>((const float*)x, ldx, (float*)y1, (float*)y2, (float*)y3, ldy, H, W, C, k, vpb);
+        else if (dtype == ICAF_BF16) sppf_lds_kernel<ICAF_BF16><<<grid, block, lds, S(s)>>>((const unsigned short*)x, ldx, (unsigned short*)y1, (unsigned short*)y2, (unsigned short*)y3, ldy, H, W, C, k, vpb);
+        else sppf_lds_kernel<ICAF_F16><<<grid, block, lds, S(s)>>>((const unsigned short*)x, ldx, (unsigned short*)y1, (unsigned short*)y2, (unsigned short*)y3, ldy, H, W, C, k, vpb);
+        ICAF_LAUNCH_CHECK();
+        return ICAF_OK;
+    }
     const long long total = (long long)B * H * W * (C / vec);
     dim3 grid(grid_for(total)), block(256);
     if (dtype == ICAF_F32) hipLaunchKernelGGL(sppf_kernel<ICAF_F32>, grid, block, 0, S(s), (const float*)x, ldx, (float*)y1, (float*)y2, (float*)y3, ldy, B, H, W, C, k);

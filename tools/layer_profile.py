@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="s"); ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--size", type=int, default=640); ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--sweep", action="store_true", help="time every igemm launch with each tile config")
 a = ap.parse_args()
 dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
 cfg = yaml.safe_load(open(os.path.join(ROOT, "models", "transformer", f"yolov5{a.model}_Transfusion_kaist.yaml")))
@@ -42,3 +43,36 @@ tot = sum(r[0] for r in rows)
 print(f"total kernel time {tot:.3f} ms for batch {a.batch}: {a.batch / tot * 1e3:.0f} pairs/s")
 for i, (ms, tf, gb, d) in enumerate(rows):
     print(f"{i:3d} {ms * 1e3:8.1f} us {tf:7.1f} TF {gb:7.0f} GB/s  {d}")
+
+if a.sweep:
+    print("\n# tile sweep (us): id1=128x128 id2=128x64 id3=256x32 id4=64x64; '*' = auto choice")
+    names = {1: "128x128", 2: "128x64", 3: "256x32", 4: "64x64"}
+    sp = ops.current_stream_ptr()
+    seen = {}
+    for i, l in enumerate(plan.launches):
+        if l.fn is not ops.lib().icaf_conv2d:
+            continue
+        c = l.keep[0]
+        key = (c.B * c.Ho * c.Wo, c.Cout, c.kh * c.kw * c.Cin, c.groups, c.sh, c.out_dtype, c.act, c.res is not None)
+        if key in seen:
+            continue
+        seen[key] = i
+        auto = ops.conv_kernel_name(l).rsplit("_", 1)[1]
+        res = []
+        for t in (1, 2, 3, 4):
+            if t == 1 and c.out_dtype == 0:
+                continue
+            if t == 3 and c.Cout > 64:
+                continue
+            c.tile = t
+            l(sp); torch.cuda.synchronize()
+            e0, e1 = ops.Event(), ops.Event()
+            e0.record(sp)
+            for _ in range(10):
+                l(sp)
+            e1.record(sp)
+            res.append((e0.elapsed_ms(e1) * 100, names[t]))
+        c.tile = 0
+        best = min(res)
+        print(f"{i:3d} M={key[0]:8d} N={key[1]:5d} K={key[2]:5d} g={key[3]} s={key[4]} " +
+              " ".join(f"{n}{'*' if n == auto else ''}={t:7.1f}" for t, n in res) + f"   best={best[1]}")
