@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--conf", type=float, default=0.1, help="detect_twostream.py default")
     ap.add_argument("--iou", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -118,6 +119,7 @@ def main():
     model = model.to(dev)
     model.compute_dtype = DT[args.dtype]
     model.static_outputs = True
+    model.autotune = not args.no_autotune
     B, H, W = args.batch, args.height, args.width
     plan = model.plan_for(B, H, W, dev)
     # inputs resident in HBM before the timed region: each rank synthesises its own shard of the global batch

@@ -6,11 +6,7 @@
 // im2col buffer), Wp = packed K-major weights.  Replaces reference models/common.py:48-60 (Conv), :184-194
 // (Bottleneck shortcut), nn.Linear layers of :607-618 / :704-709 and models/yolo_test.py:50 (Detect convs).
 //
-// Structure (per 256-thread workgroup = 4 wavefronts of 64):
-//   * BM x BN output tile, K walked in 64-byte slices (32 bf16 / 16 fp32 elements) through double-buffered LDS;
-//     global -> register -> LDS staging with 16-byte vectors (a slice of one pixel's channels is contiguous in
-//     NHWC, zero-filled outside the image), row stride padded to 80 B so the ds_read_b128 fragment reads of a
-//     16-lane group hit 16 distinct 16-byte slots;
+// Common structure (256-thread workgroup = 4 wavefronts of 64, BM x BN output tile, K walked in 64-byte slices):
 //   * v_mfma_f32_32x32x16_{bf16,f16} (or v_mfma_f32_32x32x2_f32 x4 in the fp32 parity build): the weight rows are
 //     the MFMA A operand and the pixel rows the B operand, so each lane's accumulator registers hold 4 consecutive
 //     output channels of ONE pixel — bias/activation are applied in registers, the tile is staged through LDS
@@ -18,6 +14,16 @@
 //     residual read the same way;
 //   * blockIdx -> tile mapping is XCD-aware: tiles that share an input tile (same pixels, different channel
 //     block) and neighbouring pixel tiles (3x3 halos) are placed on the same XCD so re-reads hit its private L2.
+//
+// Two operand-staging pipelines share that structure:
+//   igemm_dma_kernel  (default) LDS-DMA: every K slice (64 or 128 bytes per row) is fetched with
+//     `buffer_load_dwordx4 ... lds` straight into a 2/3-stage LDS ring (no VGPR round trip, no ds_write), slices stay
+//     in flight across the single s_barrier per slice (counted s_waitcnt vmcnt), halo / tail / out-of-range lanes
+//     are zero-filled by the buffer descriptor's range check, and the LDS image is XOR-swizzled through the per-lane
+//     SOURCE address (the DMA destination is lane-linear) so that the ds_read_b128 fragment reads are bank-conflict
+//     free without padding.
+//   igemm_kernel      register-staged double buffer with padded LDS rows; used when an operand exceeds the 2 GiB
+//     buffer-descriptor range and kept selectable for A/B measurements (configuration ids 11..14).
 #include "icaf_common.h"
 
 static_assert(sizeof(icaf_conv_args) == 184, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
@@ -30,11 +36,12 @@ struct ConvP {
     int B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, sh, sw, ph, pw, ldr, Kp, act;
     int M, K, nchunks, mtiles, ntiles;
     int vec_y, vec_r;
+    unsigned int x_bytes, w_bytes;      // buffer-descriptor ranges (DMA pipeline); 0 = not representable
     float alpha_acc[2], alpha_res[2];
 };
 
-constexpr int ROWB = 64;        // bytes of K per LDS row per chunk
-constexpr int ROWS = 80;        // padded LDS row stride in bytes
+constexpr int ROWB = 64;        // bytes of K per LDS row per slice
+constexpr int ROWS = 80;        // padded LDS row stride in bytes (register-staged pipeline)
 constexpr int NTHREADS = 256;
 
 template <int ACT> __device__ __forceinline__ float apply_act(float v) {
@@ -43,26 +50,278 @@ template <int ACT> __device__ __forceinline__ float apply_act(float v) {
     else return v;
 }
 
+__device__ __forceinline__ int xcd_tile(int ntile_total) {
+    // bijective remap: consecutive logical tiles stay on one XCD (blocks are dispatched round-robin over 8 XCDs)
+    const int bid = blockIdx.x, q = ntile_total >> 3, r = ntile_total & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ---- epilogue shared by both pipelines: bias + activation in registers, LDS staging, 16-byte write-back --------
 template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT>
-__global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsigned char* lds, const ConvP& p, int g, int m0, int n0) {
     using E = Elem<DT>;
     using EO = Elem<ODT>;
-    constexpr int VEC = E::VEC;              // elements per 16-byte vector
-    constexpr int BK = ROWB / E::BYTES;      // K elements per chunk
-    constexpr int NA = BM * 4 / NTHREADS;    // 16-byte vectors of the pixel tile per thread
-    constexpr int NB = BN * 4 / NTHREADS;    // ... of the weight tile per thread (may be 0 -> handled by predicate)
-    constexpr int NBv = (BN * 4 + NTHREADS - 1) / NTHREADS;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_M = BM / WM;
     constexpr int VO = 16 / EO::BYTES;       // output elements per 16-byte vector
     constexpr int SO = BN * EO::BYTES + 16;  // staging row stride (bytes)
-    constexpr int AB_BYTES = 2 * (BM + BN) * ROWS;
-    constexpr int OUT_BYTES = BM * SO;
-    constexpr int LDS_BYTES = AB_BYTES > OUT_BYTES ? AB_BYTES : OUT_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const float alpha_acc = p.alpha_acc[g], alpha_res = p.alpha_res[g];
+    const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;      // tile-local channel of this register quad
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+                const f32x4 t = *(const f32x4*)(bias + n0 + nl);
+                bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
+            }
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int ml = wm * WM + b * 32 + l31;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT>(acc[a][b][4 * q + j] + bv[j]) * alpha_acc;
+                unsigned char* dst = lds + ml * SO + nl * EO::BYTES;
+                if constexpr (EO::BYTES == 4) {
+                    *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    u32x2 pk;
+                    if constexpr (ODT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
+                    else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
+                    *(u32x2*)dst = pk;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    typename EO::type* __restrict__ yg = (typename EO::type*)p.y + g * p.y_gs;
+    const typename E::type* __restrict__ rg = p.res ? (const typename E::type*)p.res + g * p.res_gs : nullptr;
+    constexpr int VPR = BN / VO;                       // 16-byte vectors per staged row
+    constexpr int NVEC = BM * VPR;
+    for (int idx = tid; idx < NVEC; idx += NTHREADS) {
+        const int row = idx / VPR, cv = idx - row * VPR;
+        const int m = m0 + row, n = n0 + cv * VO;
+        if (m >= p.M || n >= p.Cout) continue;
+        const u32x4 sv = *(const u32x4*)(lds + row * SO + cv * 16);
+        const int nvalid = (p.Cout - n) < VO ? (p.Cout - n) : VO;
+        if (!rg && p.vec_y && nvalid == VO) {        // common case: no residual — the staged vector is final
+            *(u32x4*)(yg + (long long)m * p.ldy + n) = sv;
+            continue;
+        }
+        float v[VO];
+        unpack16<ODT>(sv, v);
+        if (rg) {
+            const typename E::type* rp = rg + (long long)m * p.ldr + n;
+            if (p.vec_r && nvalid == VO) {
+                if constexpr (VO == E::VEC) {
+                    float r[VO];
+                    unpack16<DT>(*(const u32x4*)rp, r);
+#pragma unroll
+                    for (int j = 0; j < VO; ++j) v[j] += alpha_res * r[j];
+                } else {            // fp32 output of a 16-bit residual
+#pragma unroll
+                    for (int j = 0; j < VO; ++j) v[j] += alpha_res * E::ld(rp + j);
+                }
+            } else {
+                for (int j = 0; j < nvalid; ++j) v[j] += alpha_res * E::ld(rp + j);
+            }
+        }
+        typename EO::type* yp = yg + (long long)m * p.ldy + n;
+        if (p.vec_y && nvalid == VO) {
+            *(u32x4*)yp = pack16<ODT>(v);
+        } else {
+            for (int j = 0; j < nvalid; ++j) EO::st(yp + j, v[j]);
+        }
+    }
+}
+
+template <int DT, int ODT, int BM, int BN>
+struct TileLds {
+    static constexpr int SO = BN * Elem<ODT>::BYTES + 16;
+    static constexpr int OUT_BYTES = BM * SO;
+    static constexpr int REG_BYTES = 2 * (BM + BN) * ROWS;
+};
+
+// ===============================================================================================================
+// LDS-DMA pipeline
+// ===============================================================================================================
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 18, "vmcnt immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+}
+
+using lds_ptr_t = __attribute__((address_space(3))) void*;
+
+// RB = bytes of K per LDS row per slice (64 or 128), NS = ring depth.  With RB = 128 every DMA lane group fetches a
+// whole 128-byte cache line of one pixel / weight row: the LDS-DMA feed rate from L2 measured on MI355X is 14-21 TB/s
+// for full lines against 8 TB/s for 64-byte half lines (tools/probes/dma_bw_probe.hip), and that feed rate — not the
+// MFMA pipe — is what bounds these small-tile GEMMs.
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS>
+__global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
+    using E = Elem<DT>;
+    using L = TileLds<DT, ODT, BM, BN>;
+    constexpr int VEC = E::VEC;
+    constexpr int BK = RB / E::BYTES;              // K elements per slice
+    constexpr int SPR = RB / 16;                   // 16-byte slots per row (4 / 8) = lanes per row of a DMA instruction
+    constexpr int RPI = 1024 / RB;                 // LDS rows written by one wave-wide DMA instruction (16 / 8)
+    constexpr int AI = BM / RPI, BI = BN / RPI;    // DMA instructions per slice for the pixel / weight tile
+    constexpr int NA = AI / 4;                     // ... per wave (pixel tile)
+    constexpr int NBF = BI / 4, NBR = BI % 4;      // weight tile: NBF per wave, waves < NBR one more
+    constexpr int NBMAX = NBF + (NBR ? 1 : 0);
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_M = BM / WM;
+    constexpr int STAGE = (BM + BN) * RB;
+    constexpr int NSTEP = RB / 32;                 // MFMA steps per slice
+    static_assert(AI % 4 == 0 && (BM / WM) * (BN / WN) == 4, "tile shape");
+    static_assert(NS * STAGE >= L::OUT_BYTES, "epilogue staging must fit in the ring");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.z;
+    const int tile = xcd_tile(p.mtiles * p.ntiles);
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const typename E::type*)p.x + g * p.x_gs), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const typename E::type*)p.w + g * p.w_gs), 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;          // beyond any legal range (operands are < 2 GiB): reads as zero
+
+    // Lane -> (row, slot) of one DMA instruction: SPR lanes per row; the LDS slot is lane-linear, the SOURCE slot is
+    // XOR-swizzled with key(row).  RB = 64: key = (row >> 2) & 3;  RB = 128: key = (row >> 1) & 7.  A wave's
+    // instructions are j = wave + 4i, so row = j*RPI + rsub has a key that depends on (wave & 1, rsub) only.
+    const int rsub = lane / SPR;
+    const int dkey = RB == 64 ? ((rsub >> 2) & 3) : (((wave & 1) << 2) | (rsub >> 1));
+    const int lslot = (lane % SPR) ^ dkey;                         // logical 16-byte slot fetched by this lane
+    unsigned a_off[NA];
+    int a_h0[NA], a_w0[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (wave + 4 * i) * RPI + rsub;
+        const int m = m0 + row;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, b = t / p.Ho;
+        a_h0[i] = ho * p.sh - p.ph;
+        a_w0[i] = wo * p.sw - p.pw;
+        a_off[i] = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.ldx * (unsigned)E::BYTES;
+    }
+    int kc = lslot * VEC, ky = 0, kx = 0;
+    while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.kw) { kx = 0; ++ky; } }
+    const unsigned w_off0 = ((unsigned)(n0 + wave * RPI + rsub) * (unsigned)p.Kp + (unsigned)(lslot * VEC)) * E::BYTES;
+    const int nb_mine = NBF + (wave < NBR ? 1 : 0);
+
+    auto issue = [&](int chunk, int stage) {
+        unsigned char* st = lds + stage * STAGE;
+        const bool kvalid = ky < p.kh;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int h = a_h0[i] + ky, w = a_w0[i] + kx;
+            const bool ok = a_ok[i] && kvalid && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+            const unsigned voff = ok ? a_off[i] + (unsigned)((h * p.W + w) * p.ldx + kc) * E::BYTES : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + (wave + 4 * i) * 1024), 16, voff, 0, 0, 0);
+        }
+        const bool cvalid = chunk < p.nchunks;
+#pragma unroll
+        for (int i = 0; i < NBMAX; ++i) {
+            if (i < nb_mine) {
+                const unsigned voff = cvalid ? w_off0 + (unsigned)chunk * RB + (unsigned)(4 * i * RPI) * (unsigned)p.Kp * E::BYTES : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + BM * RB + (wave + 4 * i) * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+        kc += BK;
+        while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.kw) { kx = 0; ++ky; } }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    // fragment reads: row*RB + ((2*step + hi) ^ key(row)) * 16; every fragment base row is a multiple of 32, so
+    // key(row) = key(l31)
+    const int fkey = RB == 64 ? ((l31 >> 2) & 3) : ((l31 >> 1) & 7);
+    int foff[NSTEP];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) foff[s] = l31 * RB + (((2 * s + hi) ^ fkey) << 4);
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s, s);
+
+    for (int c = 0; c < p.nchunks; ++c) {
+        // slice c has landed once at most the (NS-2) younger slices of this wave are still outstanding
+        if (nb_mine == NBF) wait_vmcnt<(NS - 2) * (NA + NBF)>();
+        else wait_vmcnt<(NS - 2) * (NA + NBF + 1)>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // (a) slice c visible to every wave, (b) stage (c-1)%NS is free
+        issue(c + NS - 1, (c + NS - 1) % NS);
+        const unsigned char* a_s = lds + (c % NS) * STAGE;
+        const unsigned char* b_s = a_s + BM * RB;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            u32x4 fp[TM], fw[TN];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) fp[b] = *(const u32x4*)(a_s + (wm * WM + b * 32) * RB + foff[s]);
+#pragma unroll
+            for (int a = 0; a < TN; ++a) fw[a] = *(const u32x4*)(b_s + (wn * WN + a * 32) * RB + foff[s]);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) mma_step<DT>(acc[a][b], fw[a], fp[b]);
+        }
+    }
+    wait_vmcnt<0>();                               // drain the zero-fill slices issued past the end
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    epilogue<DT, ODT, BM, BN, WM, WN, ACT>(acc, lds, p, g, m0, n0);
+}
+
+// ===============================================================================================================
+// register-staged pipeline (fallback / A-B reference)
+// ===============================================================================================================
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT>
+__global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
+    using E = Elem<DT>;
+    using L = TileLds<DT, ODT, BM, BN>;
+    constexpr int VEC = E::VEC;              // elements per 16-byte vector
+    constexpr int BK = ROWB / E::BYTES;      // K elements per chunk
+    constexpr int NA = BM * 4 / NTHREADS;    // 16-byte vectors of the pixel tile per thread
+    constexpr int NBv = (BN * 4 + NTHREADS - 1) / NTHREADS;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_M = BM / WM;
+    constexpr int LDS_BYTES = L::REG_BYTES > L::OUT_BYTES ? L::REG_BYTES : L::OUT_BYTES;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     static_assert(LDS_BYTES <= 65536, "static LDS limit");
-    static_assert(NB * NTHREADS == BN * 4 || NB == 0, "weight tile vectors");
-    (void)NB;
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -70,21 +329,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int g = blockIdx.z;
-
-    // ---- XCD-aware tile id (bijective remap: consecutive logical tiles stay on one XCD) ---------------------
-    const int ntile_total = p.mtiles * p.ntiles;
-    int tile;
-    {
-        const int bid = blockIdx.x, q = ntile_total >> 3, r = ntile_total & 7, xcd = bid & 7, idx = bid >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    const int tile = xcd_tile(p.mtiles * p.ntiles);
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
     const typename E::type* __restrict__ xg = (const typename E::type*)p.x + g * p.x_gs;
     const typename E::type* __restrict__ wg = (const typename E::type*)p.w + g * p.w_gs;
 
-    // ---- per-thread gather state for the pixel (A) tile ---------------------------------------------------------
     long long a_base[NA];
     int a_h0[NA], a_w0[NA];
     bool a_ok[NA];
@@ -100,7 +351,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
         a_w0[i] = wo * p.sw - p.pw;
         a_base[i] = (long long)b * p.H * p.W * p.ldx;
     }
-    // k-position of this thread's vector: channel c inside tap (ky, kx); advanced by BK per chunk
     int kc = kv * VEC, ky = 0, kx = 0;
     while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.kw) { kx = 0; ++ky; } }
 
@@ -175,86 +425,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
         if (more) store_tiles((c + 1) & 1);
         __syncthreads();
     }
-
-    // ---- epilogue: bias + activation in registers, stage through LDS, coalesced 16-byte write-back ------------
-    const float alpha_acc = p.alpha_acc[g], alpha_res = p.alpha_res[g];
-    const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
-#pragma unroll
-    for (int a = 0; a < TN; ++a) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;      // tile-local channel of this register quad
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
-                const f32x4 t = *(const f32x4*)(bias + n0 + nl);
-                bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
-            }
-#pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                const int ml = wm * WM + b * 32 + l31;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = apply_act<ACT>(acc[a][b][4 * q + j] + bv[j]) * alpha_acc;
-                }
-                unsigned char* dst = lds + ml * SO + nl * EO::BYTES;
-                if constexpr (EO::BYTES == 4) {
-                    *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-                    u32x2 pk;
-                    if constexpr (ODT == ICAF_BF16) {
-                        pk[0] = pack2_bf16(v[0], v[1]);
-                        pk[1] = pack2_bf16(v[2], v[3]);
-                    } else {
-                        pk[0] = pack2_f16(v[0], v[1]);
-                        pk[1] = pack2_f16(v[2], v[3]);
-                    }
-                    *(u32x2*)dst = pk;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    typename EO::type* __restrict__ yg = (typename EO::type*)p.y + g * p.y_gs;
-    const typename E::type* __restrict__ rg = p.res ? (const typename E::type*)p.res + g * p.res_gs : nullptr;
-    constexpr int VPR = BN / VO;                       // 16-byte vectors per staged row
-    constexpr int NVEC = BM * VPR;
-    for (int idx = tid; idx < NVEC; idx += NTHREADS) {
-        const int row = idx / VPR, cv = idx - row * VPR;
-        const int m = m0 + row, n = n0 + cv * VO;
-        if (m >= p.M || n >= p.Cout) continue;
-        const u32x4 sv = *(const u32x4*)(lds + row * SO + cv * 16);
-        const int nvalid = (p.Cout - n) < VO ? (p.Cout - n) : VO;
-        if (!rg && p.vec_y && nvalid == VO) {        // common case: no residual — the staged vector is final
-            *(u32x4*)(yg + (long long)m * p.ldy + n) = sv;
-            continue;
-        }
-        float v[VO];
-        unpack16<ODT>(sv, v);
-        if (rg) {
-            const typename E::type* rp = rg + (long long)m * p.ldr + n;
-            if (p.vec_r && nvalid == VO) {
-                if constexpr (VO == E::VEC) {
-                    float r[VO];
-                    unpack16<DT>(*(const u32x4*)rp, r);
-#pragma unroll
-                    for (int j = 0; j < VO; ++j) v[j] += alpha_res * r[j];
-                } else {            // fp32 output of a 16-bit residual: two half vectors
-#pragma unroll
-                    for (int j = 0; j < VO; ++j) v[j] += alpha_res * E::ld(rp + j);
-                }
-            } else {
-                for (int j = 0; j < nvalid; ++j) v[j] += alpha_res * E::ld(rp + j);
-            }
-        }
-        typename EO::type* yp = yg + (long long)m * p.ldy + n;
-        if (p.vec_y && nvalid == VO) {
-            *(u32x4*)yp = pack16<ODT>(v);
-        } else {
-            for (int j = 0; j < nvalid; ++j) EO::st(yp + j, v[j]);
-        }
-    }
+    epilogue<DT, ODT, BM, BN, WM, WN, ACT>(acc, lds, p, g, m0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -263,44 +434,92 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
 struct TileCfg { int id, bm, bn; const char* tag; };
 static const TileCfg kTiles[] = {{1, 128, 128, "128x128"}, {2, 128, 64, "128x64"}, {3, 256, 32, "256x32"}, {4, 64, 64, "64x64"}};
 
-static int pick_tile(const icaf_conv_args* a, long long M) {
-    if (a->tile) return a->tile;
+// Launch configuration id = tile (1..4) + 10 * pipeline:
+//   pipeline 0: LDS-DMA, 64-byte slices, 3-stage ring      pipeline 1: register-staged (fallback)
+//   pipeline 2: LDS-DMA, 128-byte slices, 2-stage ring     pipeline 3: LDS-DMA, 128-byte slices, 3-stage ring
+static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
+    const bool dma_ok = p.x_bytes != 0;
+    if (a->tile >= 1 && a->tile <= 34 && a->tile % 10 >= 1 && a->tile % 10 <= 4) {
+        const int pipe = a->tile / 10;
+        return (pipe != 1 && !dma_ok) ? a->tile % 10 + 10 : a->tile;
+    }
     const bool f32 = a->dtype == ICAF_F32 || a->out_dtype == ICAF_F32;
     const int N = a->Cout;
-    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * a->groups; };
+    const long long M = p.M;
+    auto blocks = [&](int t) { return ((M + kTiles[t - 1].bm - 1) / kTiles[t - 1].bm) * ((N + kTiles[t - 1].bn - 1) / kTiles[t - 1].bn) * a->groups; };
     int t;
     if (N > 64 && !f32) t = 1;
     else if (N > 32) t = 2;
     else t = 3;
-    // small problems: prefer more, smaller workgroups so every CU gets work
-    const int bm = kTiles[t - 1].bm, bn = kTiles[t - 1].bn;
-    if (blocks(bm, bn) < 256 && blocks(64, 64) > blocks(bm, bn)) t = 4;
-    return t;
+    // small problems: prefer more, smaller workgroups so every CU gets several
+    if (t == 1 && blocks(1) < 512 && blocks(2) > blocks(1)) t = 2;
+    if (blocks(t) < 512 && blocks(4) > blocks(t)) t = 4;
+    if (!dma_ok) return t + 10;
+    const int eb = a->dtype == ICAF_F32 ? 4 : 2;
+    // full 128-byte lines whenever a pixel's tap (or two adjacent taps) provides them
+    return (long long)p.K * eb >= 256 ? t + 20 : t;
 }
 
-template <int DT, int ODT, int BM, int BN, int WM, int WN>
-static int launch_cfg(const ConvP& p, int groups, hipStream_t s) {
-    ConvP q = p;
-    q.mtiles = (p.M + BM - 1) / BM;
-    q.ntiles = (p.Cout + BN - 1) / BN;
-    dim3 grid((unsigned)(q.mtiles * q.ntiles), 1, (unsigned)groups), block(NTHREADS);
-    if (p.act == ICAF_ACT_SILU) igemm_kernel<DT, ODT, BM, BN, WM, WN, ICAF_ACT_SILU><<<grid, block, 0, s>>>(q);
-    else if (p.act == ICAF_ACT_GELU) igemm_kernel<DT, ODT, BM, BN, WM, WN, ICAF_ACT_GELU><<<grid, block, 0, s>>>(q);
-    else igemm_kernel<DT, ODT, BM, BN, WM, WN, ICAF_ACT_NONE><<<grid, block, 0, s>>>(q);
+template <typename KernelT>
+static int set_lds_attr(KernelT kernel, int bytes) {
+    if (bytes > 64 * 1024) ICAF_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return ICAF_OK;
+}
+
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS>
+static int launch_dma(const ConvP& q, dim3 grid, hipStream_t s) {
+    constexpr int ring = NS * (BM + BN) * RB;
+    static_assert(ring <= 160 * 1024, "LDS capacity");
+    static bool attr_done = false;                 // one flag per instantiation
+    if (!attr_done) {
+        int st = set_lds_attr(igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS>, ring);
+        if (st) return st;
+        attr_done = true;
+    }
+    igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS><<<grid, dim3(NTHREADS), ring, s>>>(q);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
 
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT>
+static int launch_act(const ConvP& q, dim3 grid, int pipe, hipStream_t s) {
+    switch (pipe) {
+        case 0: return launch_dma<DT, ODT, BM, BN, WM, WN, ACT, 64, 3>(q, grid, s);
+        case 2: return launch_dma<DT, ODT, BM, BN, WM, WN, ACT, 128, 2>(q, grid, s);
+        case 3: return launch_dma<DT, ODT, BM, BN, WM, WN, ACT, 128, 3>(q, grid, s);
+        default:
+            igemm_kernel<DT, ODT, BM, BN, WM, WN, ACT><<<grid, dim3(NTHREADS), 0, s>>>(q);
+            ICAF_LAUNCH_CHECK();
+            return ICAF_OK;
+    }
+}
+
+template <int DT, int ODT, int BM, int BN, int WM, int WN>
+static int launch_cfg(const ConvP& p, int groups, int pipe, hipStream_t s) {
+    ConvP q = p;
+    q.mtiles = (p.M + BM - 1) / BM;
+    q.ntiles = (p.Cout + BN - 1) / BN;
+    if (pipe != 1) {       // the DMA pipelines walk K in RB-byte slices
+        const int eb = DT == ICAF_F32 ? 4 : 2, bk = (pipe == 0 ? 64 : 128) / eb;
+        q.nchunks = (p.K + bk - 1) / bk;
+    }
+    dim3 grid((unsigned)(q.mtiles * q.ntiles), 1, (unsigned)groups);
+    if (p.act == ICAF_ACT_SILU) return launch_act<DT, ODT, BM, BN, WM, WN, ICAF_ACT_SILU>(q, grid, pipe, s);
+    if (p.act == ICAF_ACT_GELU) return launch_act<DT, ODT, BM, BN, WM, WN, ICAF_ACT_GELU>(q, grid, pipe, s);
+    return launch_act<DT, ODT, BM, BN, WM, WN, ICAF_ACT_NONE>(q, grid, pipe, s);
+}
+
 template <int DT, int ODT>
-static int launch_tile(const ConvP& p, int groups, int tile, hipStream_t s) {
-    switch (tile) {
+static int launch_tile(const ConvP& p, int groups, int cfg, hipStream_t s) {
+    const int pipe = cfg / 10;
+    switch (cfg % 10) {
         case 1:
             if constexpr (ODT == ICAF_F32) return fail(ICAF_ERR_UNSUPPORTED, "tile 128x128 has no fp32-output build");
-            else return launch_cfg<DT, ODT, 128, 128, 64, 64>(p, groups, s);
-        case 2: return launch_cfg<DT, ODT, 128, 64, 64, 32>(p, groups, s);
-        case 3: return launch_cfg<DT, ODT, 256, 32, 64, 32>(p, groups, s);
-        case 4: return launch_cfg<DT, ODT, 64, 64, 32, 32>(p, groups, s);
-        default: return fail(ICAF_ERR_ARG, "unknown tile id %d", tile);
+            else return launch_cfg<DT, ODT, 128, 128, 64, 64>(p, groups, pipe, s);
+        case 2: return launch_cfg<DT, ODT, 128, 64, 64, 32>(p, groups, pipe, s);
+        case 3: return launch_cfg<DT, ODT, 256, 32, 64, 32>(p, groups, pipe, s);
+        case 4: return launch_cfg<DT, ODT, 64, 64, 32, 32>(p, groups, pipe, s);
+        default: return fail(ICAF_ERR_ARG, "unknown tile id %d", cfg);
     }
 }
 
@@ -334,11 +553,19 @@ static void fill(const icaf_conv_args* a, ConvP& p) {
     p.M = a->B * a->Ho * a->Wo;
     p.K = a->kh * a->kw * a->Cin;
     const int bk = a->dtype == ICAF_F32 ? 16 : 32;
-    p.nchunks = (p.K + bk - 1) / bk;
+    p.nchunks = (p.K + bk - 1) / bk;                  // 64-byte slices (launch_cfg recomputes it for 128-byte slices)
+    p.mtiles = p.ntiles = 0;
     const int vo = a->out_dtype == ICAF_F32 ? 4 : 8, vi = a->dtype == ICAF_F32 ? 4 : 8;
-    const int yb = a->out_dtype == ICAF_F32 ? 4 : 2, rb = a->dtype == ICAF_F32 ? 4 : 2;
+    const int yb = a->out_dtype == ICAF_F32 ? 4 : 2, eb = a->dtype == ICAF_F32 ? 4 : 2;
     p.vec_y = (a->ldy % vo == 0) && (((uintptr_t)a->y & 15) == 0) && ((a->y_gs * yb) % 16 == 0);
-    p.vec_r = a->res && (a->ldr % vi == 0) && (((uintptr_t)a->res & 15) == 0) && ((a->res_gs * rb) % 16 == 0);
+    p.vec_r = a->res && (a->ldr % vi == 0) && (((uintptr_t)a->res & 15) == 0) && ((a->res_gs * eb) % 16 == 0);
+    // buffer-descriptor ranges for the DMA pipeline: the x view spans ((pixels-1)*ldx + Cin) elements, the packed
+    // weights Np x Kp; both must stay below 2 GiB so that offset 0x80000000 is always out of range (reads as zero)
+    const long long xb = (((long long)a->B * a->H * a->W - 1) * a->ldx + a->Cin) * eb;
+    const long long np = ((long long)a->Cout + 127) / 128 * 128;
+    const long long wb = np * a->Kp * eb;
+    if (xb < 0x7fffff00LL && wb < 0x7fffff00LL) { p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb; }
+    else { p.x_bytes = 0; p.w_bytes = 0; }
     for (int i = 0; i < 2; ++i) { p.alpha_acc[i] = a->alpha_acc[i]; p.alpha_res[i] = a->alpha_res[i]; }
 }
 
@@ -351,7 +578,7 @@ extern "C" int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s) {
     if (st) return st;
     ConvP p;
     fill(a, p);
-    const int tile = pick_tile(a, p.M);
+    const int tile = pick_tile(a, p);
     hipStream_t hs = S(s);
     if (a->dtype == ICAF_BF16)
         return a->out_dtype == ICAF_F32 ? launch_tile<ICAF_BF16, ICAF_F32>(p, a->groups, tile, hs)
@@ -367,8 +594,9 @@ extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int b
     if (st) return st;
     ConvP p;
     fill(a, p);
-    const int tile = pick_tile(a, p.M);
+    const int tile = pick_tile(a, p);
     static const char* dn[] = {"f32", "bf16", "f16"};
-    snprintf(buf, buf_len, "igemm_%s_%s_%s", dn[a->dtype], dn[a->out_dtype], kTiles[tile - 1].tag);
+    static const char* pn[] = {"_dma64x3", "_reg", "_dma128x2", "_dma128x3"};
+    snprintf(buf, buf_len, "igemm%s_%s_%s_%s", pn[tile / 10], dn[a->dtype], dn[a->out_dtype], kTiles[tile % 10 - 1].tag);
     return ICAF_OK;
 }

@@ -60,6 +60,14 @@ class Plan:
             for l in self.launches:
                 l(sp)
 
+    def autotune(self, stream_ptr=None):
+        """Pick the fastest igemm configuration for every conv / linear launch of this plan (device-timed)."""
+        sp = stream_ptr if stream_ptr is not None else ops.current_stream_ptr()
+        fn = ops.lib().icaf_conv2d
+        for l in self.launches:             # one untimed pass first: lazy module load, attribute setup
+            l(sp)
+        return [ops.autotune_conv(l, sp) for l in self.launches if l.fn is fn]
+
     def capture(self):
         """Capture the launch list into a hipGraph on a side stream (legacy default stream cannot capture)."""
         side = torch.cuda.Stream(device=self.device)

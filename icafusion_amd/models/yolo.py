@@ -155,6 +155,7 @@ class Model(HipModule):
                 mod.eps, mod.momentum = 1e-3, 0.03
         self.compute_dtype = None    # None: the parameters' dtype (.half() / .bfloat16() as in the reference);
         #                              set to torch.bfloat16 / float16 to keep fp32 masters and only pack in 16 bit
+        self.autotune = False        # device-time every igemm configuration once per plan and keep the fastest
         self.use_graph = False       # replay each plan as one hipGraph launch
         self.static_outputs = False  # return views of plan-owned buffers instead of clones
 
@@ -269,6 +270,8 @@ class Model(HipModule):
         plans = self.__dict__.setdefault("_plans", {})
         if key not in plans:
             plan = self.build_plan(B, H, W, x.device, dt)
+            if self.autotune:
+                plan.autotune()
             if self.use_graph:
                 plan.capture()
             plans[key] = plan
@@ -297,6 +300,8 @@ class Model(HipModule):
         plans = self.__dict__.setdefault("_plans", {})
         if key not in plans:
             plan = self.build_plan(B, H, W, device, dt)
+            if self.autotune:
+                plan.autotune()
             if self.use_graph:
                 plan.capture()
             plans[key] = plan

@@ -132,6 +132,50 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
                   nbytes=nbytes)
 
 
+_TUNE_CACHE = {}
+CONV_PIPELINES = (0, 1, 2)        # LDS-DMA 64 B x3, register-staged, LDS-DMA 128 B x2 (3 = 128 B x3: never won)
+
+
+def _conv_signature(a):
+    return (a.B * a.Ho * a.Wo, a.Cout, a.Cin, a.kh, a.kw, a.sh, a.sw, a.H, a.W, a.ldx, a.ldy, a.groups, a.dtype,
+            a.out_dtype, a.act, bool(a.res))
+
+
+def autotune_conv(launch, stream_ptr, reps=3):
+    """Time every (tile, pipeline) configuration of one recorded conv launch on the device and keep the fastest.
+    All configurations walk K in the same order, so the result is bit-identical whichever is picked."""
+    a = launch.keep[0]
+    sig = _conv_signature(a)
+    if sig in _TUNE_CACHE:
+        a.tile = _TUNE_CACHE[sig]
+        return a.tile
+    cands = []
+    for pipe in CONV_PIPELINES:
+        for t in (1, 2, 3, 4):
+            if t == 1 and (a.out_dtype == F32 or a.Cout <= 64):
+                continue
+            if t == 3 and a.Cout > 32:
+                continue
+            cands.append(t + 10 * pipe)
+    best, best_ms = 0, float("inf")
+    e0, e1 = Event(), Event()
+    for c in cands:
+        a.tile = c
+        st = launch.fn(*launch.args, stream_ptr)
+        if st != 0:
+            continue
+        e0.record(stream_ptr)
+        for _ in range(reps):
+            launch.fn(*launch.args, stream_ptr)
+        e1.record(stream_ptr)
+        ms = e0.elapsed_ms(e1)
+        if ms < best_ms:
+            best, best_ms = c, ms
+    a.tile = best
+    _TUNE_CACHE[sig] = best
+    return best
+
+
 def conv_kernel_name(launch):
     buf = C.create_string_buffer(256)
     check(lib().icaf_conv2d_kernel_name(launch.args[0], buf, 256), "icaf_conv2d_kernel_name")

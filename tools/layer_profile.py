@@ -19,10 +19,12 @@ ap.add_argument("--model", default="s"); ap.add_argument("--batch", type=int, de
 ap.add_argument("--size", type=int, default=640); ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--sweep", action="store_true", help="time every igemm launch with each tile config")
+ap.add_argument("--autotune", action="store_true")
 a = ap.parse_args()
 dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
 cfg = yaml.safe_load(open(os.path.join(ROOT, "models", "transformer", f"yolov5{a.model}_Transfusion_kaist.yaml")))
 m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 0)); m = m.to("cuda:0"); m.compute_dtype = dt
+m.autotune = a.autotune
 plan = m.plan_for(a.batch, a.size, a.size, "cuda:0")
 rgb, ir = synth_images(a.batch, a.size, a.size, 0)
 plan.inputs[0].copy_(rgb.cuda()); plan.inputs[1].copy_(ir.cuda())
@@ -57,21 +59,22 @@ if a.sweep:
         if key in seen:
             continue
         seen[key] = i
-        auto = ops.conv_kernel_name(l).rsplit("_", 1)[1]
+        auto = "?"
         res = []
-        for t in (1, 2, 3, 4):
-            if t == 1 and c.out_dtype == 0:
+        for pipe in (0, 1, 2, 3):
+          for t in (1, 2, 3, 4):
+            if t == 1 and (c.out_dtype == 0 or c.Cout <= 64):
                 continue
-            if t == 3 and c.Cout > 64:
+            if t == 3 and c.Cout > 32:
                 continue
-            c.tile = t
+            c.tile = t + 10 * pipe
             l(sp); torch.cuda.synchronize()
             e0, e1 = ops.Event(), ops.Event()
             e0.record(sp)
             for _ in range(10):
                 l(sp)
             e1.record(sp)
-            res.append((e0.elapsed_ms(e1) * 100, names[t]))
+            res.append((e0.elapsed_ms(e1) * 100, f"p{pipe}:{names[t]}"))
         c.tile = 0
         best = min(res)
         print(f"{i:3d} M={key[0]:8d} N={key[1]:5d} K={key[2]:5d} g={key[3]} s={key[4]} " +
