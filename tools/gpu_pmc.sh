@@ -1,0 +1,14 @@
+#!/bin/bash
+# HBM traffic per kernel from the L2 memory-side counters, one counter per pass (FETCH_SIZE and WRITE_SIZE do not fit
+# together: MI355X_MICROARCH.md "rocprofv3 PMC slots").  Kernel-trace only — no other trace domain is combined with --pmc.
+# Summaries land in gpurun_out/pmc_summary.json (copied to profiles/ by hand).
+mkdir -p gpurun_out
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o pmc -- \
+      python $R/bench.py --no-cpu-baseline --no-graph --no-autotune --steps 3 --warmup 1 "$@" > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.err
+  tail -2 $R/gpurun_out/pmc_$c.err
+done
+cd $R && python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_summary.json
+head -c 3000 gpurun_out/pmc_summary.json
