@@ -14,12 +14,16 @@ class ImageIn:
     """Marks a raw NCHW fp32 network input (the only non-NHWC tensor on the path)."""
 
     def __init__(self, tensor):
-        assert tensor.dim() == 4
+        assert tensor.dim() in (4, 5)          # 5-D: the RGB and IR images stacked as (2, B, 3, H, W)
         self.t = tensor
 
     @property
     def shape(self):
-        return self.t.shape
+        return self.t.shape[-4:]
+
+    @property
+    def pair(self):
+        return self.t.dim() == 5
 
 
 class Plan:
@@ -32,8 +36,9 @@ class Plan:
         self.nbytes = 0
 
     # -- buffers ------------------------------------------------------------------------------------------
-    def act(self, B, H, W, C, dtype=None):
-        t = torch.zeros((B, H, W, C), dtype=dtype or self.dtype, device=self.device)
+    def act(self, B, H, W, C, dtype=None, pair=False):
+        """NHWC activation buffer; pair=True allocates both backbone streams adjacently as (2, B, H, W, C)."""
+        t = torch.zeros(((2, B, H, W, C) if pair else (B, H, W, C)), dtype=dtype or self.dtype, device=self.device)
         self.nbytes += t.numel() * t.element_size()
         return t
 

@@ -141,57 +141,75 @@ class Conv(HipModule):
             b = (b - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
         return w, b
 
-    def emit(self, plan, x, out=None, res=None):
+    def emit(self, plan, x, out=None, res=None, twin=None, also=(), twin_also=()):
+        """Append this layer's launch.
+
+        twin: the structurally identical Conv of the other backbone stream — x / out / res are then pair acts
+              (2, B, H, W, C) and both streams run as ONE groups=2 launch with per-stream weights.
+        also: further Convs with the same geometry and activation reading the same input (C3's cv1 and cv2): their
+              output channels are appended to this layer's, one GEMM with N = sum of the widths (twin_also: the
+              twin stream's counterparts)."""
         if self.conv.groups != 1 or self.conv.dilation != (1, 1):
             raise NotImplementedError("grouped / dilated convolutions are outside the hot path")
         kh, kw = self.conv.kernel_size
         sh, sw = self.conv.stride
         ph, pw = _pair(self.conv.padding)
-        c1, c2 = self.conv.in_channels, self.conv.out_channels
+        c1 = self.conv.in_channels
+        c2 = self.conv.out_channels + sum(e.conv.out_channels for e in also)
+        for e in also:
+            assert (e.conv.kernel_size, e.conv.stride, _pair(e.conv.padding), e.conv.in_channels, e._act_code()) == \
+                   ((kh, kw), (sh, sw), (ph, pw), c1, self._act_code()), "fused convs must share geometry"
         vec = ops.VEC[plan.dtype]
+        paired = twin is not None
+        assert len(twin_also) == (len(also) if paired else 0)
+
+        def streams():
+            """[(Conv, ...)] per stream: the convs whose folded weights are concatenated along Cout."""
+            rows = [(self,) + tuple(also)]
+            if paired:
+                rows.append((twin,) + tuple(twin_also))
+            return rows
+        key_tail = (plan.dtype, plan.device, id(twin), tuple(id(e) for e in also))
+
+        def pack(transform, cin_pad):
+            packs = []
+            for convs in streams():
+                ws, bs = zip(*(c.folded() for c in convs))
+                w, b = torch.cat(ws), torch.cat(bs)
+                wp, kp = ops.pack_conv_weight(transform(w), plan.dtype, cin_pad)
+                packs.append((wp, kp, ops.pack_bias(b, c2)))
+            if not paired:
+                return packs[0]
+            return (torch.stack([p[0] for p in packs]).contiguous(), packs[0][1],
+                    torch.stack([p[2] for p in packs]).contiguous())
+
         if isinstance(x, ImageIn):
+            assert x.pair == paired
             B, _, H, W = x.shape
             s2d = (kh, kw, sh, sw, ph, pw) == (6, 6, 2, 2, 2, 2) and H % 2 == 0 and W % 2 == 0
             if s2d:                       # 6x6/s2/p2 over the image == 3x3/s1/p1 over space-to-depth(image)
                 cpad = -(-4 * c1 // vec) * vec
-                pre = plan.act(B, H // 2, W // 2, cpad)
+                pre = plan.act(B, H // 2, W // 2, cpad, pair=paired)
                 plan.add(ops.preprocess(x.t, pre, 1, name="preprocess_s2d"))
-                key = ("s2d", plan.dtype, plan.device)
-
-                def make():
-                    w, b = self.folded()
-                    wp, kp = ops.pack_conv_weight(ops.s2d_conv_weight(w), plan.dtype, cpad)
-                    return wp, kp, ops.pack_bias(b, c2)
-                wp, kp, bp = self._cached(key, make)
+                wp, kp, bp = self._cached(("s2d",) + key_tail, lambda: pack(ops.s2d_conv_weight, cpad))
                 x, c1, (kh, kw, sh, sw, ph, pw) = pre, cpad, (3, 3, 1, 1, 1, 1)
             else:
                 cpad = -(-c1 // vec) * vec
-                pre = plan.act(B, H, W, cpad)
+                pre = plan.act(B, H, W, cpad, pair=paired)
                 plan.add(ops.preprocess(x.t, pre, 0, name="preprocess_pad"))
-                key = ("pad", plan.dtype, plan.device)
-
-                def make():
-                    w, b = self.folded()
-                    wp, kp = ops.pack_conv_weight(w, plan.dtype, cpad)
-                    return wp, kp, ops.pack_bias(b, c2)
-                wp, kp, bp = self._cached(key, make)
+                wp, kp, bp = self._cached(("pad",) + key_tail, lambda: pack(lambda w: w, cpad))
                 x, c1 = pre, cpad
         else:
-            if x.shape[3] != c1:
-                raise ValueError(f"Conv expects {c1} input channels, got {x.shape[3]}")
+            assert (x.dim() == 5) == paired
+            if x.shape[-1] != c1:
+                raise ValueError(f"Conv expects {c1} input channels, got {x.shape[-1]}")
             if c1 % vec:
                 raise NotImplementedError(f"channel count {c1} must be a multiple of {vec} for dtype {plan.dtype}")
-            key = ("std", plan.dtype, plan.device)
-
-            def make():
-                w, b = self.folded()
-                wp, kp = ops.pack_conv_weight(w, plan.dtype)
-                return wp, kp, ops.pack_bias(b, c2)
-            wp, kp, bp = self._cached(key, make)
-        B, H, W, _ = x.shape
+            wp, kp, bp = self._cached(("std",) + key_tail, lambda: pack(lambda w: w, None))
+        B, H, W = x.shape[-4:-1]
         Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
         if out is None:
-            out = plan.act(B, Ho, Wo, c2)
+            out = plan.act(B, Ho, Wo, c2, pair=paired)
         plan.add(ops.conv2d(x, wp, kp, bp, out, kh, kw, sh, sw, ph, pw, c1, c2, self._act_code(), res=res,
                             name=f"conv{kh}x{kw}s{sh}"))
         return out
@@ -199,7 +217,8 @@ class Conv(HipModule):
 
 class Bottleneck(HipModule):
     """1x1 -> 3x3 with optional identity shortcut (reference models/common.py:184-194); the shortcut add is the
-    residual term of the second conv's epilogue."""
+    residual term of the second conv's epilogue (which may write in place over its own residual: every output
+    element is read and written by the same thread, and the GEMM's input is the 1x1's separate output)."""
 
     def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
         super().__init__()
@@ -208,14 +227,16 @@ class Bottleneck(HipModule):
         self.cv2 = Conv(c_, c2, 3, 1, g=g)
         self.add = shortcut and c1 == c2
 
-    def emit(self, plan, x, out=None):
-        t = self.cv1.emit(plan, x)
-        return self.cv2.emit(plan, t, out=out, res=x if self.add else None)
+    def emit(self, plan, x, out=None, twin=None):
+        t = self.cv1.emit(plan, x, twin=twin.cv1 if twin is not None else None)
+        return self.cv2.emit(plan, t, out=out, res=x if self.add else None,
+                             twin=twin.cv2 if twin is not None else None)
 
 
 class C3(HipModule):
-    """CSP bottleneck with three convs (reference models/common.py:216-227).  The torch.cat is never
-    materialised: both branches write channel slices of one buffer that cv3 reads."""
+    """CSP bottleneck with three convs (reference models/common.py:216-227).  cv1 and cv2 read the same input, so they
+    run as ONE GEMM writing both halves of the buffer cv3 reads (the torch.cat is never materialised); the
+    bottleneck chain then updates the first half in place."""
 
     def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
         super().__init__()
@@ -225,16 +246,17 @@ class C3(HipModule):
         self.cv3 = Conv(2 * c_, c2, 1)
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
 
-    def emit(self, plan, x, out=None):
-        B, H, W, _ = x.shape
+    def emit(self, plan, x, out=None, twin=None):
+        B, H, W = x.shape[-4:-1]
         c_ = self.cv1.conv.out_channels
-        cat = plan.act(B, H, W, 2 * c_)
-        n = len(self.m)
-        a = self.cv1.emit(plan, x, out=cat[..., :c_] if n == 0 else None)
+        paired = twin is not None
+        cat = plan.act(B, H, W, 2 * c_, pair=paired)
+        self.cv1.emit(plan, x, out=cat, twin=twin.cv1 if paired else None, also=(self.cv2,),
+                      twin_also=(twin.cv2,) if paired else ())
+        a = cat[..., :c_]
         for j, blk in enumerate(self.m):
-            a = blk.emit(plan, a, out=cat[..., :c_] if j == n - 1 else None)
-        self.cv2.emit(plan, x, out=cat[..., c_:])
-        return self.cv3.emit(plan, cat, out=out)
+            blk.emit(plan, a, out=a, twin=twin.m[j] if paired else None)
+        return self.cv3.emit(plan, cat, out=out, twin=twin.cv3 if paired else None)
 
 
 class SPPF(HipModule):
@@ -248,14 +270,15 @@ class SPPF(HipModule):
         self.cv2 = Conv(c_ * 4, c2, 1, 1)
         self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
 
-    def emit(self, plan, x, out=None):
-        B, H, W, _ = x.shape
+    def emit(self, plan, x, out=None, twin=None):
+        B, H, W = x.shape[-4:-1]
         c_ = self.cv1.conv.out_channels
         k = self.m.kernel_size if isinstance(self.m.kernel_size, int) else self.m.kernel_size[0]
-        cat = plan.act(B, H, W, 4 * c_)
-        self.cv1.emit(plan, x, out=cat[..., :c_])
+        paired = twin is not None
+        cat = plan.act(B, H, W, 4 * c_, pair=paired)
+        self.cv1.emit(plan, x, out=cat[..., :c_], twin=twin.cv1 if paired else None)
         plan.add(ops.sppf_pool(cat[..., :c_], cat[..., c_:2 * c_], cat[..., 2 * c_:3 * c_], cat[..., 3 * c_:], k))
-        return self.cv2.emit(plan, cat, out=out)
+        return self.cv2.emit(plan, cat, out=out, twin=twin.cv2 if paired else None)
 
 
 class Concat(HipModule):

@@ -109,8 +109,9 @@ def parse_model(d, ch):
     return nn.Sequential(*layers), sorted(save)
 
 
-def emit_any(m, plan, src, out=None):
-    """Emit one yaml row: our HipModules, torch's nn.Upsample, or an nn.Sequential repeat of either."""
+def emit_any(m, plan, src, out=None, twin=None):
+    """Emit one yaml row: our HipModules, torch's nn.Upsample, or an nn.Sequential repeat of either.  `twin` is the
+    same row of the other backbone stream when both run as one paired launch sequence."""
     if isinstance(m, nn.Upsample):
         return emit_upsample(m, plan, src, out=out)
     if isinstance(m, Detect):
@@ -118,11 +119,31 @@ def emit_any(m, plan, src, out=None):
     if isinstance(m, nn.Sequential):
         mods = list(m)
         for j, sub in enumerate(mods):
-            src = emit_any(sub, plan, src, out if j == len(mods) - 1 else None)
+            src = emit_any(sub, plan, src, out if j == len(mods) - 1 else None, twin[j] if twin is not None else None)
         return src
     if not hasattr(m, "emit"):
         raise NotImplementedError(f"layer type {type(m).__name__} is outside the hot path")
+    if twin is not None:
+        return m.emit(plan, src, out=out, twin=twin)
     return m.emit(plan, src, out=out)
+
+
+PAIRABLE = (Conv, C3, SPPF)
+
+
+def _same_structure(a, b):
+    if type(a) is not type(b):
+        return False
+    if isinstance(a, nn.Sequential):
+        return len(a) == len(b) and all(_same_structure(x, y) for x, y in zip(a, b))
+    if not isinstance(a, PAIRABLE):
+        return False
+    sa, sb = a.state_dict(), b.state_dict()
+    if list(sa) != list(sb) or any(sa[k].shape != sb[k].shape for k in sa):
+        return False
+    geo = lambda m: [(c.kernel_size, c.stride, c.padding, c.groups) for c in m.modules() if isinstance(c, nn.Conv2d)]  # noqa: E731
+    acts = lambda m: [type(c.act) for c in m.modules() if isinstance(c, Conv)]                                       # noqa: E731
+    return geo(a) == geo(b) and acts(a) == acts(b)
 
 
 class Model(HipModule):
@@ -157,6 +178,7 @@ class Model(HipModule):
         #                              set to torch.bfloat16 / float16 to keep fp32 masters and only pack in 16 bit
         self.autotune = False        # device-time every igemm configuration once per plan and keep the fastest
         self.use_graph = False       # replay each plan as one hipGraph launch
+        self.pair_streams = True     # run structurally identical RGB / IR backbone rows as one groups=2 launch
         self.static_outputs = False  # return views of plan-owned buffers instead of clones
 
     # -- reference API ----------------------------------------------------------------------------------------
@@ -214,10 +236,29 @@ class Model(HipModule):
             shapes.append(cur)
         return shapes
 
+    def stream_twins(self):
+        """{IR-stream row -> RGB-stream row} for the leading run of rows that are pure chains (from = -1) with
+        identical structure in both backbones.  Those rows run as ONE launch sequence over pair acts
+        (groups = 2: per-stream weights, gridDim.z = stream): half the launches, twice the workgroups each."""
+        if not self.pair_streams:
+            return {}
+        ir0 = next((m.i for m in self.model if m.f == -4), None)
+        twins = {}
+        if ir0 is None or self.model[0].f != -1:
+            return twins
+        for k in range(ir0):
+            if ir0 + k >= len(self.model):
+                break
+            a, b = self.model[k], self.model[ir0 + k]
+            if a.f != -1 or b.f != (-4 if k == 0 else -1) or not _same_structure(a, b):
+                break
+            twins[ir0 + k] = k
+        return twins
+
     def build_plan(self, B, H, W, device, dtype):
         plan = Plan(device, dtype)
-        rgb = torch.zeros((B, 3, H, W), dtype=torch.float32, device=device)
-        ir = torch.zeros((B, 3, H, W), dtype=torch.float32, device=device)
+        imgs = torch.zeros((2, B, 3, H, W), dtype=torch.float32, device=device)   # RGB and IR staging, adjacent
+        rgb, ir = imgs[0], imgs[1]
         plan.inputs = [rgb, ir]
         shapes = self._layer_shapes(B, H, W)
         # Concat placement: producer layer index -> (concat buffer, channel offset)
@@ -234,9 +275,27 @@ class Model(HipModule):
                 for s in srcs:
                     placement[s] = (buf, off, shapes[s][0])
                     off += shapes[s][0]
+        twins = self.stream_twins()                 # a prefix run by construction; cut it at the first row that a
+        ir0 = min(twins) if twins else None         # Concat placement pins to another buffer
+        run = 0
+        while ir0 is not None and (ir0 + run) in twins and run not in placement and (ir0 + run) not in placement:
+            run += 1
+        twins = {ir0 + k: k for k in range(run)}
+        rgb_rows = set(twins.values())
+        pair_out = {}
         y, x = [], None
         for m in self.model:
             f = m.f
+            if m.i in rgb_rows:                     # both streams in one paired launch sequence
+                src = ImageIn(imgs) if m.i == 0 else pair_out[m.i - 1]
+                pair_out[m.i] = emit_any(m, plan, src, None, twin=self.model[ir0 + m.i])
+                x = pair_out[m.i][0]
+                y.append(x)
+                continue
+            if m.i in twins:                        # already emitted with its RGB twin
+                x = pair_out[twins[m.i]][1]
+                y.append(x)
+                continue
             if f == -4:
                 src = ImageIn(ir)
             elif f == -1:

@@ -34,11 +34,25 @@ def current_stream_ptr():
 
 
 def _act_geom(t):
+    """(B, H, W, C, ld) of an act; a 5-D (2, B, H, W, C) *pair* (the two streams of the backbone at a constant
+    element stride, t.stride(0)) reports the geometry of one member."""
+    if t.dim() == 5:
+        assert t.shape[0] == 2, f"pair acts hold exactly two streams, got {t.shape}"
+        t = t[0]
     assert t.dim() == 4 and t.stride(3) == 1, f"act must be NHWC-contiguous in C, got {t.shape} {t.stride()}"
     B, H, W, Cc = t.shape
     ld = t.stride(2)
     assert t.stride(1) == W * ld and (B == 1 or t.stride(0) == H * W * ld), f"bad act strides {t.stride()}"
     return B, H, W, Cc, ld
+
+
+def flat_pair(t):
+    """View a pair act (2, B, H, W, C) as one act of batch 2B (weight-less kernels treat the streams as more batch)."""
+    if t.dim() == 4:
+        return t
+    G, B, H, W, Cc = t.shape
+    assert t.stride(0) == B * t.stride(1), "pair members must be adjacent in memory"
+    return t.as_strided((G * B, H, W, Cc), t.stride()[1:])
 
 
 class Launch:
@@ -103,6 +117,11 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
     By, Ho, Wo, cy, ldy = _act_geom(y)
     assert cx >= cin and cy >= cout and By == B
     assert Ho == (H + 2 * ph - kh) // sh + 1 and Wo == (W + 2 * pw - kw) // sw + 1, "conv geometry mismatch"
+    if x.dim() == 5:                  # pair act: both backbone streams in one launch, per-stream weights
+        assert group_strides is None and y.dim() == 5 and w_packed.dim() == 3 and (res is None or res.dim() == 5)
+        groups = 2
+        group_strides = dict(x=x.stride(0), w=w_packed.stride(0), bias=bias.stride(0) if bias is not None else 0,
+                             y=y.stride(0), res=res.stride(0) if res is not None else 0)
     a = ConvArgs()
     a.x, a.w, a.y = x.data_ptr(), w_packed.data_ptr(), y.data_ptr()
     a.bias = bias.data_ptr() if bias is not None else None
@@ -185,6 +204,8 @@ def conv_kernel_name(launch):
 def preprocess(img, out, mode, name="preprocess"):
     """img: (B, C, H, W) fp32 NCHW contiguous; out: act (B, H', W', Cpad)."""
     assert img.dtype == torch.float32 and img.is_contiguous()
+    if img.dim() == 5:                # both streams' images stacked (2, B, C, H, W): one launch over 2B images
+        img, out = img.view(-1, *img.shape[2:]), flat_pair(out)
     B, Cc, H, W = img.shape
     Bo, Ho, Wo, cpad, ldo = _act_geom(out)
     assert ldo == cpad and Bo == B
@@ -195,6 +216,7 @@ def preprocess(img, out, mode, name="preprocess"):
 
 
 def sppf_pool(x, y1, y2, y3, k, name="sppf_pool"):
+    x, y1, y2, y3 = flat_pair(x), flat_pair(y1), flat_pair(y2), flat_pair(y3)
     B, H, W, Cc, ldx = _act_geom(x)
     ldy = _act_geom(y1)[4]
     assert _act_geom(y2)[4] == ldy and _act_geom(y3)[4] == ldy
