@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-overlap", action="store_true", help="run NMS on the forward stream (no cross-batch overlap)")
+    ap.add_argument("--tune-cache", default=None, help="json file: load igemm tile choices if present, save after tuning")
     return ap.parse_args()
 
 
@@ -97,7 +99,7 @@ def main():
     from icafusion_amd import ops
     from icafusion_amd.models.yolo import Model
     from icafusion_amd.synth import synth_images, synth_state_dict
-    from icafusion_amd.utils.general import nms_device
+    from icafusion_amd.pipeline import DetectionPipeline
     import torch.distributed as tdist
 
     rank, world, local = D.init_from_env()
@@ -121,43 +123,35 @@ def main():
     model.static_outputs = True
     model.autotune = not args.no_autotune
     B, H, W = args.batch, args.height, args.width
-    plan = model.plan_for(B, H, W, dev)
+    if args.tune_cache and os.path.exists(args.tune_cache):
+        ops.load_tune_cache(args.tune_cache)
+    model.use_graph = not args.no_graph
+    pipe = DetectionPipeline(model, B, H, W, dev, conf_thres=args.conf, iou_thres=args.iou, world=world,
+                             overlap=not args.no_overlap)
+    plan = pipe.plan
+    if args.tune_cache and rank == 0:
+        ops.save_tune_cache(args.tune_cache)
     # inputs resident in HBM before the timed region: each rank synthesises its own shard of the global batch
-    lo, hi = D.shard_range(B * world, rank, world)
     rgb, ir = synth_images(B, H, W, seed=100 + rank)
     plan.inputs[0].copy_(rgb.to(dev))
     plan.inputs[1].copy_(ir.to(dev))
     nc = cfg["nc"]
-    z = plan.outputs[0]
-    stream = torch.cuda.Stream(device=dev)
-    sp = stream.cuda_stream
+    sp = pipe.fwd_stream.cuda_stream
     torch.cuda.synchronize()
-    if not args.no_graph:
-        plan.capture()
-
-    gathered = torch.empty((world * B, 300 * 6 + 1), dtype=torch.float32, device=dev) if world > 1 else None
-
-    def step():
-        plan.run(sp)
-        det, count, _ = nms_device(z, args.conf, args.iou, stream_ptr=sp)
-        if world > 1:
-            D.gather_detections(det, count, out=gathered)       # issued on `stream` (the current torch stream)
-        return det, count
+    step = pipe.step
 
     def barrier():
         if world > 1:
             tdist.barrier()
 
-    with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            step()
+    for _ in range(args.warmup):
+        step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        for _ in range(args.steps):
-            det, count = step()
+    for _ in range(args.steps):
+        det, count = step()[:2]
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -194,7 +188,8 @@ def main():
         achieved = dbytes / (dms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dname, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 4)}
-    roof.update({"traffic": None, "avg_launch_us": round(1e3 * dms / dn, 2), "launches_per_step": dn // reps,
+    roof.update({"traffic": None, "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_traffic.json)",
+                 "algorithmic_bytes_per_launch": round(dbytes / dn), "avg_launch_us": round(1e3 * dms / dn, 2), "launches_per_step": dn // reps,
                  "share_of_forward_kernel_time": round(dms / reps / total_ms, 3)})
     att = per_kernel.get("cross_attention")
     kernels = {k: {"ms_per_step": round(v[0] / reps, 4), "launches": v[3] // reps,
@@ -212,7 +207,7 @@ def main():
             "config": {"workload": f"{yaml_name[:-5]} + DMFF(loops={args.loops}) {args.dtype}, batch {B}/GPU, "
                                    f"{H}x{W} synthetic RGB/IR pairs, seeded random weights, NMS conf {args.conf} iou {args.iou}",
                        "global_batch": B * world, "parallelism": f"dp{world} (pairs sharded, one all-gather of detections)",
-                       "graph": not args.no_graph},
+                       "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap},
             "forward_only_pairs_per_s": round(B / (fwd_ms * 1e-3), 2),
             "forward_ms_per_batch": round(fwd_ms, 3),
             "model_tflops": round(gf * B / (fwd_ms * 1e-3) / 1e3, 2) if gf else None,
@@ -224,6 +219,15 @@ def main():
             "plan_buffer_MB": round(plan.nbytes / 2 ** 20, 1),
             "detections_first_image": int(count[0]),
         }
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):          # PMC counters cannot be read from inside this process: the committed summary of
+            pm = json.load(open(tf))    # tools/gpu_pmc.sh (same command line) supplies the dominant kernel's HBM bytes
+            k = pm.get("kernels", {}).get(dname)
+            if pm.get("workload") == out["config"]["workload"] and k \
+                    and "fetch_bytes_corrected" in k and "write_bytes_uncorrected" in k:
+                roof["traffic"] = round(k["fetch_bytes_corrected"] + k["write_bytes_uncorrected"])
+                roof["traffic_detail"] = {"fetch_bytes": round(k["fetch_bytes_corrected"]),
+                                          "write_bytes": round(k["write_bytes_uncorrected"])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, args, args.loops)
         print(json.dumps(out))

@@ -195,6 +195,19 @@ def autotune_conv(launch, stream_ptr, reps=3):
     return best
 
 
+def save_tune_cache(path):
+    import json
+    with open(path, "w") as f:
+        json.dump([[list(k), v] for k, v in _TUNE_CACHE.items()], f)
+
+
+def load_tune_cache(path):
+    import json
+    with open(path) as f:
+        for k, v in json.load(f):
+            _TUNE_CACHE[tuple(k)] = v
+
+
 def conv_kernel_name(launch):
     buf = C.create_string_buffer(256)
     check(lib().icaf_conv2d_kernel_name(launch.args[0], buf, 256), "icaf_conv2d_kernel_name")

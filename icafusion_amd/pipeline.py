@@ -1,0 +1,80 @@
+"""Two-stage detection pipeline: forward on one HIP stream, NMS (+ the detections all-gather) on a second one.
+
+The reference runs `model(img, img2)` and `non_max_suppression` back to back for every batch with a device sync in
+between (detect_twostream.py:83-88, test.py:126-141).  NMS is a latency-bound job that occupies one workgroup per
+image (32 of 256 CUs at batch 32), so here batch i's NMS runs concurrently with batch i+1's forward:
+
+    forward stream : graph(i) -> snapshot z(i) -> graph(i+1) -> snapshot z(i+1) -> ...
+    nms stream     :              wait snapshot(i) -> candidates / sort / greedy (i) [-> all_gather(i)] -> ...
+
+`z` is snapshotted into one of two staging buffers because the plan's output buffer is overwritten by the next
+replay; events order snapshot -> NMS -> reuse.  Results of step i are valid after `wait(i)` / `synchronize()`.
+PyTorch streams / events are used as plumbing only; every kernel on both streams is ours (plus RCCL).
+"""
+import torch
+
+from . import dist as D
+from .utils.general import nms_device
+
+
+class DetectionPipeline:
+    def __init__(self, model, batch, height, width, device, conf_thres=0.25, iou_thres=0.45, classes=None,
+                 agnostic=False, multi_label=False, max_det=300, world=1, overlap=True):
+        self.model, self.device, self.world = model, torch.device(device), world
+        self.nms_args = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic,
+                             multi_label=multi_label, max_det=max_det)
+        model.static_outputs = True
+        self.plan = model.plan_for(batch, height, width, self.device)
+        self.z = self.plan.outputs[0]
+        self.fwd_stream = torch.cuda.Stream(device=self.device)
+        self.nms_stream = torch.cuda.Stream(device=self.device) if overlap else self.fwd_stream
+        self.overlap = overlap
+        self.zbuf = [torch.empty_like(self.z) for _ in range(2)] if overlap else [self.z]
+        self.snap_done = [torch.cuda.Event() for _ in range(2)]
+        self.nms_done = [torch.cuda.Event() for _ in range(2)]
+        self.gathered = (torch.empty((world * batch, max_det * 6 + 1), dtype=torch.float32, device=self.device)
+                         if world > 1 else None)
+        self.n = 0
+        self.last = None
+
+    @property
+    def inputs(self):
+        """Static RGB / IR staging tensors (NCHW fp32); fill them, then call step()."""
+        return self.plan.inputs
+
+    def step(self):
+        """Enqueue one batch: forward replay, then NMS (+ gather) on the second stream.  Returns (det, count[, all])
+        device tensors that are valid once the nms stream has drained (see synchronize())."""
+        i = (self.n & 1) if self.overlap else 0
+        fs, ns = self.fwd_stream, self.nms_stream
+        self.plan.run(fs.cuda_stream)
+        if self.overlap:
+            if self.n >= 2:
+                fs.wait_event(self.nms_done[i])             # NMS of step n-2 has finished reading zbuf[i]
+            with torch.cuda.stream(fs):
+                self.zbuf[i].copy_(self.z, non_blocking=True)
+            self.snap_done[i].record(fs)
+            ns.wait_event(self.snap_done[i])
+        det, count, keep = nms_device(self.zbuf[i], stream_ptr=ns.cuda_stream, **self.nms_args)
+        out = (det, count)
+        if self.world > 1:
+            with torch.cuda.stream(ns):
+                out = D.gather_detections(det, count, out=self.gathered)
+        if self.overlap:
+            self.nms_done[i].record(ns)
+        self.n += 1
+        self.last = out
+        return out
+
+    def synchronize(self):
+        self.fwd_stream.synchronize()
+        self.nms_stream.synchronize()
+
+    def __call__(self, rgb, ir):
+        """Convenience: copy one batch in, run it, wait, return list of (n, 6) detections per image."""
+        self.plan.inputs[0].copy_(rgb)
+        self.plan.inputs[1].copy_(ir)
+        torch.cuda.current_stream(self.device).synchronize()
+        det, count = self.step()[:2]
+        self.synchronize()
+        return [det[k, :n].clone() for k, n in enumerate(count.tolist())]

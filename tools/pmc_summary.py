@@ -12,8 +12,21 @@ import re
 import sys
 
 
+_DN = ["f32", "bf16", "f16"]
+
+
 def short(name):
+    """rocprof kernel name -> the name bench.py reports (igemm instantiations that differ only in the activation
+    template argument are merged, as ops.conv_kernel_name does)."""
     name = re.sub(r"^void ", "", name)
+    m = re.match(r"icaf::igemm_dma_kernel<(\d+), (\d+), (\d+), (\d+), \d+, \d+, \d+, (\d+), (\d+)>", name)
+    if m:
+        dt, odt, bm, bn, rb, ns = map(int, m.groups())
+        return f"igemm_dma{rb}x{ns}_{_DN[dt]}_{_DN[odt]}_{bm}x{bn}"
+    m = re.match(r"icaf::igemm_kernel<(\d+), (\d+), (\d+), (\d+),", name)
+    if m:
+        dt, odt, bm, bn = map(int, m.groups())
+        return f"igemm_reg_{_DN[dt]}_{_DN[odt]}_{bm}x{bn}"
     m = re.match(r"icaf::(\w+)(<[^>]*>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else name[:80]
 
@@ -34,7 +47,9 @@ def collect(d):
 
 def main():
     res = {}
-    for d in sys.argv[1:]:
+    dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
+    workload = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--workload=")), None)
+    for d in dirs:
         for k, cs in collect(d).items():
             for c, (s, n) in cs.items():
                 res.setdefault(k, {})[c] = {"mean_per_dispatch": s / max(n, 1), "dispatches": n}
@@ -43,7 +58,11 @@ def main():
             cs["fetch_bytes_corrected"] = cs["FETCH_SIZE"]["mean_per_dispatch"] * 1024 * 2
         if "WRITE_SIZE" in cs:
             cs["write_bytes_uncorrected"] = cs["WRITE_SIZE"]["mean_per_dispatch"] * 1024
-    print(json.dumps(res, indent=1, sort_keys=True))
+    res = {k: v for k, v in res.items() if not k.startswith("at::")}
+    print(json.dumps({"workload": workload, "unit": "bytes per dispatch",
+                      "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
+                                "FETCH_SIZE x1024 x2 (gfx950 128-byte requests tallied at 64 B), WRITE_SIZE x1024",
+                      "kernels": res}, indent=1, sort_keys=True))
 
 
 if __name__ == "__main__":
