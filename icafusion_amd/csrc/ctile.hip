@@ -1,0 +1,247 @@
+// 3x3 direct convolution from an LDS halo tile for gfx950 (MI355X) — the high-resolution 3x3 layers of the backbones.
+//
+// The implicit-GEMM kernel (igemm.hip) re-fetches every input pixel once per filter tap: for a 3x3 layer the L2 -> LDS
+// feed carries 9x the tensor, and with few output channels (N <= 64) that feed — not HBM, not the MFMA pipe — is what
+// bounds the layer (stem: 1.05 GB of im2col traffic per stream at ~6 TB/s).  Here a workgroup owns a TH x TW patch of
+// output pixels of one image:
+//   1. the (TH-1)*S+3 x (TW-1)*S+3 input halo patch is fetched ONCE with `buffer_load_dwordx4 ... lds` (out-of-image
+//      pixels are zero-filled by the descriptor range check), laid out pixel-major with the 16-byte channel slots of a
+//      pixel XOR-swizzled by the pixel index so that the 16 lanes of a ds_read_b128 group (consecutive pixels of one
+//      row) hit 16 distinct bank groups; for stride 2 even and odd columns are stored as separate planes so that a
+//      tap still reads consecutive entries;
+//   2. the K loop walks (ky, kx, cin) in the SAME order and MFMA step size as igemm — results are bit-identical to
+//      igemm's — with the weight slices streamed through a 3-stage LDS-DMA ring (as in igemm) and the pixel operand
+//      of each MFMA step read straight from the halo patch at (lane base + tap offset);
+//   3. the epilogue is igemm's (bias + SiLU in registers, LDS-staged 16-byte stores, residual).
+// Requirements (checked by the host; anything else stays on igemm): 3x3, pad 1, stride 1 or 2, Cin a power of two with
+// 32..256 bytes per pixel, Cout <= BN, SiLU, out dtype == dtype.
+#include "conv_common.h"
+
+namespace icaf {
+
+template <int S, int TW> struct HaloGeom {
+    static constexpr int HWD = (TW - 1) * S + 3;                      // halo width in pixels
+    static constexpr int HALF = S == 2 ? (HWD + 1) / 2 : 0;           // entries of the even-column plane (stride 2)
+    // row pitch in entries.  TW = 16: an MFMA sub-tile spans two patch rows, whose entry indices must differ by a
+    // multiple of 16 to keep the b128 lane groups conflict-free.
+    static constexpr int PITCH = TW == 16 ? ((S == 2 ? 2 * HALF : HWD) + 15) / 16 * 16 : (S == 2 ? 2 * HALF : HWD);
+};
+
+template <int DT, int TH, int TW, int BN, int ACT, int S>
+__global__ __launch_bounds__(NTHREADS) void ctile_kernel(const ConvP p, const int lsp, const int lcin, const int tiles_x,
+                                                         const int tiles_per_img, const int halo_bytes) {
+    using E = Elem<DT>;
+    using G = HaloGeom<S, TW>;
+    constexpr int VEC = E::VEC;
+    constexpr int RB = 128, NS = 3;
+    constexpr int BK = RB / E::BYTES;              // K elements per weight slice
+    constexpr int KSTEP = 2 * VEC;                 // K elements per MFMA step
+    constexpr int NSTEP = BK / KSTEP;              // 4
+    constexpr int BM = TH * TW, WM = BM / 4, TM = WM / 32, TN = BN / 32;
+    constexpr int HH = (TH - 1) * S + 3;
+    constexpr int PITCH = G::PITCH, HALF = G::HALF, HWD = G::HWD;
+    constexpr int NBW = BN / 32;                   // weight DMA instructions per wave per slice (8 rows each)
+    constexpr int WSTAGE = BN * RB;
+    static_assert(TM >= 1 && (TW == 32 || TW == 16) && BM % 128 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char* halo = lds;
+    unsigned char* ring = lds + halo_bytes;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.z;
+    const int tile = xcd_tile(p.mtiles);
+    const int b = tile / tiles_per_img, tr = tile - b * tiles_per_img;
+    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;          // output-pixel origin of the patch
+    const int SP = 1 << lsp;                       // 16-byte slots per pixel
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const typename E::type*)p.x + g * p.x_gs), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const typename E::type*)p.w + g * p.w_gs), 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    // ---- 1. halo patch -> LDS (each DMA instruction fills 64 consecutive 16-byte slots) --------------------------
+    {
+        const int nslots = (HH * PITCH) << lsp;
+        const int ninstr = (nslots + 63) >> 6;
+        const unsigned img_off = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.ldx * (unsigned)E::BYTES;
+        const int gy0 = y0 * S - 1, gx0 = x0 * S - 1;
+        for (int j = wave; j < ninstr; j += 4) {
+            const int L = (j << 6) + lane;
+            const int idx = L >> lsp;
+            const int cs = (L & (SP - 1)) ^ ((idx >> (4 - lsp)) & (SP - 1));
+            const int hy = idx / PITCH, rem = idx - hy * PITCH;
+            int hx;
+            if constexpr (S == 2) { const int pl = rem >= HALF; hx = 2 * (rem - pl * HALF) + pl; }
+            else hx = rem;
+            const int gy = gy0 + hy, gx = gx0 + hx;
+            const bool ok = hy < HH && hx < HWD && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const unsigned voff = ok ? img_off + (unsigned)((gy * p.W + gx) * p.ldx) * E::BYTES + (unsigned)(cs << 4) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(halo + (j << 10)), 16, voff, 0, 0, 0);
+        }
+    }
+
+    // ---- 2. weight ring (identical addressing to igemm's RB = 128 pipeline) ---------------------------------------
+    const int rsub = lane >> 3;
+    const int dkey = ((wave & 1) << 2) | (rsub >> 1);
+    const int lslot = (lane & 7) ^ dkey;
+    const unsigned w_off0 = ((unsigned)(wave * 8 + rsub) * (unsigned)p.Kp + (unsigned)(lslot * VEC)) * E::BYTES;
+    auto issue_w = [&](int chunk, int stage) {
+        unsigned char* st = ring + stage * WSTAGE;
+        const bool cvalid = chunk < p.nchunks;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const unsigned voff = cvalid ? w_off0 + (unsigned)chunk * RB + (unsigned)(32 * i) * (unsigned)p.Kp * E::BYTES : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + (wave + 4 * i) * 1024), 16, voff, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int bb = 0; bb < TM; ++bb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][bb][r] = 0.0f;
+
+    // lane base entry of each 32-pixel sub-tile (tap offsets are added per MFMA step)
+    int lbase[TM];
+#pragma unroll
+    for (int bb = 0; bb < TM; ++bb) {
+        const int st = wave * TM + bb;                                 // sub-tile index within the patch
+        const int py = TW == 32 ? st : st * 2 + (l31 >> 4), px = TW == 32 ? l31 : (l31 & 15);
+        lbase[bb] = py * S * PITCH + px;
+    }
+    const int fkey = (l31 >> 1) & 7;
+    int foff[NSTEP];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) foff[s] = l31 * RB + (((2 * s + hi) ^ fkey) << 4);
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_w(s, s);
+
+    const int gsh = 4 - lsp, smask = SP - 1;
+    const int cin_slots_mask = smask;                                  // Cin * BYTES / 16 - 1
+    for (int c = 0; c < p.nchunks; ++c) {
+        wait_vmcnt<(NS - 2) * NBW>();              // slice c (and, for c = 0, the halo patch issued before it) landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_w(c + NS - 1, (c + NS - 1) % NS);
+        const unsigned char* b_s = ring + (c % NS) * WSTAGE;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int k0 = c * BK + s * KSTEP;                         // wave-uniform
+            const int tap = k0 >> lcin;
+            if (tap < 9) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const int toff = ky * PITCH + (S == 2 ? (kx & 1) * HALF + (kx >> 1) : kx);
+                const int csl = (((k0 & ((1 << lcin) - 1)) * E::BYTES) >> 4) + hi;      // logical 16-byte slot in the pixel
+                u32x4 fp[TM], fw[TN];
+#pragma unroll
+                for (int bb = 0; bb < TM; ++bb) {
+                    const int idx = lbase[bb] + toff;
+                    const int slot = (idx << lsp) + ((csl ^ (idx >> gsh)) & cin_slots_mask);
+                    fp[bb] = *(const u32x4*)(halo + (slot << 4));
+                }
+#pragma unroll
+                for (int a = 0; a < TN; ++a) fw[a] = *(const u32x4*)(b_s + (a * 32) * RB + foff[s]);
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < TM; ++bb) mma_step<DT>(acc[a][bb], fw[a], fp[bb]);
+            }
+        }
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    epilogue<DT, DT, BM, BN, WM, BN, ACT>(acc, lds, p, g, [&](int row) {
+        const int st = row >> 5, r = row & 31;
+        const int py = TW == 32 ? st : st * 2 + (r >> 4), px = TW == 32 ? r : (r & 15);
+        const int gy = y0 + py, gx = x0 + px;
+        return (gy < p.Ho && gx < p.Wo) ? (b * p.Ho + gy) * p.Wo + gx : -1;
+    }, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+struct CtileShape { int id, th, tw, bn, s; const char* tag; };
+static const CtileShape kShapes[] = {
+    {1, 8, 32, 32, 1, "8x32n32"}, {2, 8, 32, 64, 1, "8x32n64"}, {3, 8, 16, 64, 1, "8x16n64"}, {4, 4, 32, 64, 2, "4x32n64s2"},
+    {5, 8, 16, 128, 1, "8x16n128"},
+};
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+const char* ctile_tag(int shape) { return (shape >= 1 && shape <= 5) ? kShapes[shape - 1].tag : "?"; }
+
+// 0 if shape `id` can run these args, else an error code with the reason in last_error()
+int ctile_check(const icaf_conv_args* a, const ConvP& p, int shape) {
+    if (shape < 1 || shape > 5) return fail(ICAF_ERR_ARG, "ctile: unknown shape %d", shape);
+    const CtileShape& sh = kShapes[shape - 1];
+    const int eb = a->dtype == ICAF_F32 ? 4 : 2;
+    if (a->kh != 3 || a->kw != 3 || a->ph != 1 || a->pw != 1 || a->sh != sh.s || a->sw != sh.s)
+        return fail(ICAF_ERR_UNSUPPORTED, "ctile %s: needs a 3x3 / pad 1 / stride %d convolution", sh.tag, sh.s);
+    const int ppx = a->Cin * eb;
+    if ((a->Cin & (a->Cin - 1)) || ppx < 32 || ppx > 256) return fail(ICAF_ERR_UNSUPPORTED, "ctile: Cin=%d is not a power of two with 32..256 bytes per pixel", a->Cin);
+    if (a->Cout > sh.bn) return fail(ICAF_ERR_UNSUPPORTED, "ctile %s: Cout=%d > %d", sh.tag, a->Cout, sh.bn);
+    if (a->act != ICAF_ACT_SILU || a->out_dtype != a->dtype) return fail(ICAF_ERR_UNSUPPORTED, "ctile: SiLU and out dtype == dtype only");
+    if (p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "ctile: operand exceeds the 2 GiB buffer-descriptor range");
+    if (a->Kp % (128 / eb)) return fail(ICAF_ERR_UNSUPPORTED, "ctile: Kp must be a multiple of 128 bytes");
+    return ICAF_OK;
+}
+
+template <int DT, int TH, int TW, int BN, int S>
+static int launch_ctile_cfg(const ConvP& p, int groups, hipStream_t s) {
+    using G = HaloGeom<S, TW>;
+    constexpr int EB = Elem<DT>::BYTES;
+    constexpr int HH = (TH - 1) * S + 3;
+    constexpr int BM = TH * TW;
+    ConvP q = p;
+    const int lcin = ilog2(p.Cin), lsp = ilog2(p.Cin * EB / 16);
+    const int nslots = (HH * G::PITCH) << lsp;
+    const int halo_bytes = ((nslots + 63) / 64) * 1024;
+    const int ring = 3 * BN * 128;
+    const int stage_out = BM * (BN * EB + 16);
+    int lds = halo_bytes + ring;
+    if (lds < stage_out) lds = stage_out;
+    if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "ctile: %d bytes of LDS needed", lds);
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    q.mtiles = p.B * tiles_x * tiles_y;
+    q.ntiles = 1;
+    q.nchunks = (p.K + 128 / EB - 1) / (128 / EB);
+    auto kern = ctile_kernel<DT, TH, TW, BN, ICAF_ACT_SILU, S>;
+    static int attr_bytes = 0;                        // per instantiation: largest dynamic LDS size enabled so far
+    if (lds > 64 * 1024 && lds > attr_bytes) {
+        ICAF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_bytes = lds;
+    }
+    kern<<<dim3((unsigned)q.mtiles, 1, (unsigned)groups), dim3(NTHREADS), lds, s>>>(q, lsp, lcin, tiles_x, tiles_x * tiles_y, halo_bytes);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+template <int DT>
+static int launch_ctile_dt(const ConvP& p, int groups, int shape, hipStream_t s) {
+    switch (shape) {
+        case 1: return launch_ctile_cfg<DT, 8, 32, 32, 1>(p, groups, s);
+        case 2: return launch_ctile_cfg<DT, 8, 32, 64, 1>(p, groups, s);
+        case 3: return launch_ctile_cfg<DT, 8, 16, 64, 1>(p, groups, s);
+        case 4: return launch_ctile_cfg<DT, 4, 32, 64, 2>(p, groups, s);
+        case 5: return launch_ctile_cfg<DT, 8, 16, 128, 1>(p, groups, s);
+        default: return fail(ICAF_ERR_ARG, "ctile: unknown shape %d", shape);
+    }
+}
+
+int launch_ctile(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s) {
+    int st = ctile_check(a, p, shape);
+    if (st) return st;
+    if (a->dtype == ICAF_BF16) return launch_ctile_dt<ICAF_BF16>(p, a->groups, shape, s);
+    if (a->dtype == ICAF_F16) return launch_ctile_dt<ICAF_F16>(p, a->groups, shape, s);
+    return launch_ctile_dt<ICAF_F32>(p, a->groups, shape, s);
+}
+
+}  // namespace icaf

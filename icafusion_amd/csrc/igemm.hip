@@ -24,156 +24,11 @@
 //     free without padding.
 //   igemm_kernel      register-staged double buffer with padded LDS rows; used when an operand exceeds the 2 GiB
 //     buffer-descriptor range and kept selectable for A/B measurements (configuration ids 11..14).
-#include "icaf_common.h"
+#include "conv_common.h"
 
 static_assert(sizeof(icaf_conv_args) == 184, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
 
 namespace icaf {
-
-struct ConvP {
-    const void* x; const void* w; const float* bias; void* y; const void* res;
-    long long x_gs, w_gs, bias_gs, y_gs, res_gs;
-    int B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, sh, sw, ph, pw, ldr, Kp, act;
-    int M, K, nchunks, mtiles, ntiles;
-    int vec_y, vec_r;
-    unsigned int x_bytes, w_bytes;      // buffer-descriptor ranges (DMA pipeline); 0 = not representable
-    float alpha_acc[2], alpha_res[2];
-};
-
-constexpr int ROWB = 64;        // bytes of K per LDS row per slice
-constexpr int ROWS = 80;        // padded LDS row stride in bytes (register-staged pipeline)
-constexpr int NTHREADS = 256;
-
-template <int ACT> __device__ __forceinline__ float apply_act(float v) {
-    if constexpr (ACT == ICAF_ACT_SILU) return silu_f(v);
-    else if constexpr (ACT == ICAF_ACT_GELU) return gelu_f(v);
-    else return v;
-}
-
-__device__ __forceinline__ int xcd_tile(int ntile_total) {
-    // bijective remap: consecutive logical tiles stay on one XCD (blocks are dispatched round-robin over 8 XCDs)
-    const int bid = blockIdx.x, q = ntile_total >> 3, r = ntile_total & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-// ---- epilogue shared by both pipelines: bias + activation in registers, LDS staging, 16-byte write-back --------
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsigned char* lds, const ConvP& p, int g, int m0, int n0) {
-    using E = Elem<DT>;
-    using EO = Elem<ODT>;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int WAVES_M = BM / WM;
-    constexpr int VO = 16 / EO::BYTES;       // output elements per 16-byte vector
-    constexpr int SO = BN * EO::BYTES + 16;  // staging row stride (bytes)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
-    const float alpha_acc = p.alpha_acc[g], alpha_res = p.alpha_res[g];
-    const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
-#pragma unroll
-    for (int a = 0; a < TN; ++a) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;      // tile-local channel of this register quad
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
-                const f32x4 t = *(const f32x4*)(bias + n0 + nl);
-                bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
-            }
-#pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                const int ml = wm * WM + b * 32 + l31;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT>(acc[a][b][4 * q + j] + bv[j]) * alpha_acc;
-                unsigned char* dst = lds + ml * SO + nl * EO::BYTES;
-                if constexpr (EO::BYTES == 4) {
-                    *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-                    u32x2 pk;
-                    if constexpr (ODT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
-                    else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
-                    *(u32x2*)dst = pk;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    typename EO::type* __restrict__ yg = (typename EO::type*)p.y + g * p.y_gs;
-    const typename E::type* __restrict__ rg = p.res ? (const typename E::type*)p.res + g * p.res_gs : nullptr;
-    constexpr int VPR = BN / VO;                       // 16-byte vectors per staged row
-    constexpr int NVEC = BM * VPR;
-    for (int idx = tid; idx < NVEC; idx += NTHREADS) {
-        const int row = idx / VPR, cv = idx - row * VPR;
-        const int m = m0 + row, n = n0 + cv * VO;
-        if (m >= p.M || n >= p.Cout) continue;
-        const u32x4 sv = *(const u32x4*)(lds + row * SO + cv * 16);
-        const int nvalid = (p.Cout - n) < VO ? (p.Cout - n) : VO;
-        if (!rg && p.vec_y && nvalid == VO) {        // common case: no residual — the staged vector is final
-            *(u32x4*)(yg + (long long)m * p.ldy + n) = sv;
-            continue;
-        }
-        float v[VO];
-        unpack16<ODT>(sv, v);
-        if (rg) {
-            const typename E::type* rp = rg + (long long)m * p.ldr + n;
-            if (p.vec_r && nvalid == VO) {
-                if constexpr (VO == E::VEC) {
-                    float r[VO];
-                    unpack16<DT>(*(const u32x4*)rp, r);
-#pragma unroll
-                    for (int j = 0; j < VO; ++j) v[j] += alpha_res * r[j];
-                } else {            // fp32 output of a 16-bit residual
-#pragma unroll
-                    for (int j = 0; j < VO; ++j) v[j] += alpha_res * E::ld(rp + j);
-                }
-            } else {
-                for (int j = 0; j < nvalid; ++j) v[j] += alpha_res * E::ld(rp + j);
-            }
-        }
-        typename EO::type* yp = yg + (long long)m * p.ldy + n;
-        if (p.vec_y && nvalid == VO) {
-            *(u32x4*)yp = pack16<ODT>(v);
-        } else {
-            for (int j = 0; j < nvalid; ++j) EO::st(yp + j, v[j]);
-        }
-    }
-}
-
-template <int DT, int ODT, int BM, int BN>
-struct TileLds {
-    static constexpr int SO = BN * Elem<ODT>::BYTES + 16;
-    static constexpr int OUT_BYTES = BM * SO;
-    static constexpr int REG_BYTES = 2 * (BM + BN) * ROWS;
-};
-
-// ===============================================================================================================
-// LDS-DMA pipeline
-// ===============================================================================================================
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N <= 18, "vmcnt immediate");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if constexpr (N == 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-}
-
-using lds_ptr_t = __attribute__((address_space(3))) void*;
 
 // RB = bytes of K per LDS row per slice (64 or 128), NS = ring depth.  With RB = 128 every DMA lane group fetches a
 // whole 128-byte cache line of one pixel / weight row: the LDS-DMA feed rate from L2 measured on MI355X is 14-21 TB/s
@@ -303,7 +158,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
     wait_vmcnt<0>();                               // drain the zero-fill slices issued past the end
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    epilogue<DT, ODT, BM, BN, WM, WN, ACT>(acc, lds, p, g, m0, n0);
+    epilogue<DT, ODT, BM, BN, WM, WN, ACT>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
 }
 
 // ===============================================================================================================
@@ -425,7 +280,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
         if (more) store_tiles((c + 1) & 1);
         __syncthreads();
     }
-    epilogue<DT, ODT, BM, BN, WM, WN, ACT>(acc, lds, p, g, m0, n0);
+    epilogue<DT, ODT, BM, BN, WM, WN, ACT>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -437,8 +292,16 @@ static const TileCfg kTiles[] = {{1, 128, 128, "128x128"}, {2, 128, 64, "128x64"
 // Launch configuration id = tile (1..4) + 10 * pipeline:
 //   pipeline 0: LDS-DMA, 64-byte slices, 3-stage ring      pipeline 1: register-staged (fallback)
 //   pipeline 2: LDS-DMA, 128-byte slices, 2-stage ring     pipeline 3: LDS-DMA, 128-byte slices, 3-stage ring
+// ctile.hip
+int ctile_check(const icaf_conv_args* a, const ConvP& p, int shape);
+int launch_ctile(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
+const char* ctile_tag(int shape);
+
+//   40 + shape: 3x3 direct convolution from an LDS halo tile (ctile.hip); an explicit request that the layer cannot
+//   satisfy is an error (the autotuner skips it), it is never chosen silently.
 static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
     const bool dma_ok = p.x_bytes != 0;
+    if (a->tile > 40 && a->tile < 50) return a->tile;
     if (a->tile >= 1 && a->tile <= 34 && a->tile % 10 >= 1 && a->tile % 10 <= 4) {
         const int pipe = a->tile / 10;
         return (pipe != 1 && !dma_ok) ? a->tile % 10 + 10 : a->tile;
@@ -580,6 +443,7 @@ extern "C" int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s) {
     fill(a, p);
     const int tile = pick_tile(a, p);
     hipStream_t hs = S(s);
+    if (tile > 40) return launch_ctile(a, p, tile - 40, hs);
     if (a->dtype == ICAF_BF16)
         return a->out_dtype == ICAF_F32 ? launch_tile<ICAF_BF16, ICAF_F32>(p, a->groups, tile, hs)
                                         : launch_tile<ICAF_BF16, ICAF_BF16>(p, a->groups, tile, hs);
@@ -596,6 +460,12 @@ extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int b
     fill(a, p);
     const int tile = pick_tile(a, p);
     static const char* dn[] = {"f32", "bf16", "f16"};
+    if (tile > 40) {
+        st = ctile_check(a, p, tile - 40);
+        if (st) return st;
+        snprintf(buf, buf_len, "ctile_%s_%s", dn[a->dtype], ctile_tag(tile - 40));
+        return ICAF_OK;
+    }
     static const char* pn[] = {"_dma64x3", "_reg", "_dma128x2", "_dma128x3"};
     snprintf(buf, buf_len, "igemm%s_%s_%s_%s", pn[tile / 10], dn[a->dtype], dn[a->out_dtype], kTiles[tile % 10 - 1].tag);
     return ICAF_OK;

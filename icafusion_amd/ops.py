@@ -152,6 +152,7 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
 
 
 _TUNE_CACHE = {}
+CTILE_SHAPES = {1: (32, 1), 2: (64, 1), 3: (64, 1), 4: (64, 2), 5: (128, 1)}     # shape id -> (BN, stride), ctile.hip
 CONV_PIPELINES = (0, 1, 2)        # LDS-DMA 64 B x3, register-staged, LDS-DMA 128 B x2 (3 = 128 B x3: never won)
 
 
@@ -176,6 +177,10 @@ def autotune_conv(launch, stream_ptr, reps=3):
             if t == 3 and a.Cout > 32:
                 continue
             cands.append(t + 10 * pipe)
+    if (a.kh, a.kw, a.ph, a.pw) == (3, 3, 1, 1) and a.act == ACT_SILU and a.out_dtype == a.dtype:
+        for shape, (bn, stride) in CTILE_SHAPES.items():       # 3x3 direct convolution from an LDS halo patch
+            if a.sh == stride and a.sw == stride and a.Cout <= bn and (bn < 64 or a.Cout > bn // 2):
+                cands.append(40 + shape)
     best, best_ms = 0, float("inf")
     e0, e1 = Event(), Event()
     for c in cands:

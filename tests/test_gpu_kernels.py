@@ -113,6 +113,61 @@ def test_conv2d(case, dt):
     assert float(ybuf[..., cout:].abs().max()) == 0.0, "conv wrote outside its channel slice"
 
 
+CTILE_CASES = [
+    # B, H, W, cin, cout, stride, use_res, ctile shape (tile id 40 + shape)
+    (2, 40, 70, 16, 32, 1, False, 1),     # stem-like: 16 channels = 32 bytes per pixel, one tap per MFMA step
+    (1, 37, 45, 32, 32, 1, True, 1),      # ragged patch grid, residual (Bottleneck cv2)
+    (2, 24, 64, 32, 64, 1, False, 2),
+    (1, 19, 33, 64, 64, 1, True, 2),
+    (2, 40, 40, 64, 64, 1, True, 3),      # 8x16 patches: sub-tile spans two rows
+    (1, 21, 50, 32, 48, 1, False, 3),     # Cout < BN
+    (2, 48, 80, 32, 64, 2, False, 4),     # stride 2: even / odd column planes
+    (1, 37, 41, 16, 64, 2, False, 4),     # odd input size, stride 2
+    (1, 24, 24, 128, 128, 1, True, 5),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", CTILE_CASES)
+def test_conv3x3_halo_tile_kernel(case, dt):
+    """ctile.hip (3x3 direct convolution from an LDS halo patch) vs torch, and BIT-EXACT vs the implicit-GEMM kernel:
+    both walk K in the same order with the same MFMA step, so any difference is an addressing bug."""
+    B, H, W, cin, cout, s, use_res, shape = case
+    if cin * (4 if dt == torch.float32 else 2) > 256:
+        pytest.skip("pixel wider than 256 bytes: layer stays on igemm")
+    x = rnd((B, cin, H, W), 11)
+    w = rnd((cout, cin, 3, 3), 12, 1.0 / math.sqrt(cin * 9))
+    bias = rnd((cout,), 13, 0.2)
+    Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    res = rnd((B, cout, Ho, Wo), 14) if use_res else None
+    xa = to_act(x, dt, pad_to=cin + 16)
+    wp, kp = ops.pack_conv_weight(w.to(DEV), dt)
+    bp = ops.pack_bias(bias.to(DEV), cout)
+    ra = to_act(res, dt) if use_res else None
+    outs = []
+    for tile in (40 + shape, 2 if cout > 32 else 3):
+        ybuf = torch.zeros((B, Ho, Wo, cout + 8), dtype=dt, device=DEV)
+        y = ybuf[..., :cout]
+        run(ops.conv2d(xa, wp, kp, bp, y, 3, 3, s, s, 1, 1, cin, cout, ops.ACT_SILU, res=ra, alpha_acc=0.75,
+                       alpha_res=1.25, tile=tile))
+        assert float(ybuf[..., cout:].abs().max()) == 0.0
+        outs.append(y.clone())
+    ref = F.silu(F.conv2d(q(x, dt), q(w, dt), bias, s, 1)) * 0.75
+    if use_res:
+        ref = ref + 1.25 * q(res, dt)
+    close(from_act(outs[0]), ref, dt, f"ctile {case}")
+    assert torch.equal(outs[0], outs[1]), "halo-tile kernel and implicit GEMM must agree bit for bit"
+
+
+def test_conv3x3_halo_tile_rejects_other_layers():
+    x = torch.zeros((1, 8, 8, 32), dtype=torch.bfloat16, device=DEV)
+    w = rnd((32, 32, 1, 1), 1)
+    wp, kp = ops.pack_conv_weight(w.to(DEV), torch.bfloat16)
+    y = torch.zeros((1, 8, 8, 32), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ops._lib.IcafError):
+        run(ops.conv2d(x, wp, kp, None, y, 1, 1, 1, 1, 0, 0, 32, 32, ops.ACT_SILU, tile=41))
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_conv2d_fp32_output_and_groups(dt):
     rows, cin, cout = 300, 64, 192

@@ -75,7 +75,20 @@ if a.sweep:
                 l(sp)
             e1.record(sp)
             res.append((e0.elapsed_ms(e1) * 100, f"p{pipe}:{names[t]}"))
+        for shape in (1, 2, 3, 4, 5):                      # ctile.hip (3x3 halo-patch kernel); inapplicable -> status != 0
+            c.tile = 40 + shape
+            if l.fn(*l.args, sp) != 0:
+                continue
+            torch.cuda.synchronize()
+            e0, e1 = ops.Event(), ops.Event()
+            e0.record(sp)
+            for _ in range(10):
+                l(sp)
+            e1.record(sp)
+            res.append((e0.elapsed_ms(e1) * 100, f"ctile{shape}"))
         c.tile = 0
         best = min(res)
-        print(f"{i:3d} M={key[0]:8d} N={key[1]:5d} K={key[2]:5d} g={key[3]} s={key[4]} " +
-              " ".join(f"{n}{'*' if n == auto else ''}={t:7.1f}" for t, n in res) + f"   best={best[1]}")
+        res.sort()
+        print(f"{i:3d} M={key[0]:8d} N={key[1]:5d} K={key[2]:5d} g={key[3]} s={key[4]} best: " +
+              " ".join(f"{n}={t:.1f}" for t, n in res[:4]) + " | ctile: " +
+              " ".join(f"{n}={t:.1f}" for t, n in res if n.startswith("ctile")))
