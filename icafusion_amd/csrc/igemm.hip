@@ -34,7 +34,17 @@ namespace icaf {
 // whole 128-byte cache line of one pixel / weight row: the LDS-DMA feed rate from L2 measured on MI355X is 14-21 TB/s
 // for full lines against 8 TB/s for 64-byte half lines (tools/probes/dma_bw_probe.hip), and that feed rate — not the
 // MFMA pipe — is what bounds these small-tile GEMMs.
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS>
+// MODE selects the pixel-operand address generator (the K order, hence the result, is the same for all three):
+//   0  generic: every lane walks its own (ky, kx, cin) position — needed when a K slice straddles filter taps
+//      (Cin * bytes not a multiple of RB);
+//   1  1x1 / stride 1 / pad 0 with Cin * bytes a multiple of RB: the pixel operand is a plain row-major matrix, one
+//      VALU add per DMA instruction and slice;
+//   2  any filter with Cin * bytes a multiple of RB: a slice lies inside ONE tap, so the tap walk is wave-uniform
+//      (scalar unit) and a row costs two bounds checks and one add.
+// Loop shape: after the single barrier of a slice, ALL its fragments are read into registers (LDS latency overlaps the
+// address arithmetic), then the next slice's DMA instructions are issued in NSTEP portions between the MFMA steps, so
+// their VALU work hides under the matrix pipe instead of preceding it.
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE>
 __global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
     using E = Elem<DT>;
     using L = TileLds<DT, ODT, BM, BN>;
@@ -73,7 +83,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
     const int rsub = lane / SPR;
     const int dkey = RB == 64 ? ((rsub >> 2) & 3) : (((wave & 1) << 2) | (rsub >> 1));
     const int lslot = (lane % SPR) ^ dkey;                         // logical 16-byte slot fetched by this lane
-    unsigned a_off[NA];
+    unsigned a_off[NA];                            // MODE 0: image base; MODE 1: running row offset; MODE 2: tap-0 offset
     int a_h0[NA], a_w0[NA];
     bool a_ok[NA];
 #pragma unroll
@@ -82,36 +92,65 @@ __global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
         const int m = m0 + row;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
-        const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, b = t / p.Ho;
-        a_h0[i] = ho * p.sh - p.ph;
-        a_w0[i] = wo * p.sw - p.pw;
-        a_off[i] = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.ldx * (unsigned)E::BYTES;
+        if constexpr (MODE == 1) {
+            a_off[i] = a_ok[i] ? ((unsigned)mm * (unsigned)p.ldx + (unsigned)(lslot * VEC)) * E::BYTES : OOB;
+        } else {
+            const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, b = t / p.Ho;
+            a_h0[i] = ho * p.sh - p.ph;
+            a_w0[i] = wo * p.sw - p.pw;
+            a_off[i] = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.ldx * (unsigned)E::BYTES;
+            if constexpr (MODE == 2)               // offset of tap (0, 0), channel slot of this lane (may wrap below 0)
+                a_off[i] += (unsigned)((a_h0[i] * p.W + a_w0[i]) * p.ldx + lslot * VEC) * E::BYTES;
+        }
     }
-    int kc = lslot * VEC, ky = 0, kx = 0;
-    while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.kw) { kx = 0; ++ky; } }
-    const unsigned w_off0 = ((unsigned)(n0 + wave * RPI + rsub) * (unsigned)p.Kp + (unsigned)(lslot * VEC)) * E::BYTES;
+    // MODE 0: per-lane position; MODE 2: wave-uniform position of the slice (kc = channel offset inside the tap)
+    int kc = MODE == 0 ? lslot * VEC : 0, ky = 0, kx = 0;
+    if constexpr (MODE == 0) { while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.kw) { kx = 0; ++ky; } } }
+    unsigned w_row[NBMAX];
+#pragma unroll
+    for (int i = 0; i < NBMAX; ++i)
+        w_row[i] = ((unsigned)(n0 + (wave + 4 * i) * RPI + rsub) * (unsigned)p.Kp + (unsigned)(lslot * VEC)) * E::BYTES;
     const int nb_mine = NBF + (wave < NBR ? 1 : 0);
 
-    auto issue = [&](int chunk, int stage) {
+    // DMA instructions of one slice, portion `part` of NSTEP (instruction j of the wave belongs to portion j % NSTEP)
+    auto issue_part = [&](int chunk, int stage, int part) {
         unsigned char* st = lds + stage * STAGE;
-        const bool kvalid = ky < p.kh;
+        unsigned tap_delta = 0;
+        bool kvalid = true;
+        if constexpr (MODE == 0) kvalid = ky < p.kh;
+        if constexpr (MODE == 2) { kvalid = ky < p.kh; tap_delta = (unsigned)((ky * p.W + kx) * p.ldx + kc) * E::BYTES; }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int h = a_h0[i] + ky, w = a_w0[i] + kx;
-            const bool ok = a_ok[i] && kvalid && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-            const unsigned voff = ok ? a_off[i] + (unsigned)((h * p.W + w) * p.ldx + kc) * E::BYTES : OOB;
+            if (i % NSTEP != part) continue;
+            unsigned voff;
+            if constexpr (MODE == 1) {
+                voff = a_off[i] + (unsigned)chunk * RB;
+            } else {
+                const int h = a_h0[i] + ky, w = a_w0[i] + kx;
+                const bool ok = a_ok[i] && kvalid && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                if constexpr (MODE == 2) voff = ok ? a_off[i] + tap_delta : OOB;
+                else voff = ok ? a_off[i] + (unsigned)((h * p.W + w) * p.ldx + kc) * E::BYTES : OOB;
+            }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + (wave + 4 * i) * 1024), 16, voff, 0, 0, 0);
         }
         const bool cvalid = chunk < p.nchunks;
 #pragma unroll
         for (int i = 0; i < NBMAX; ++i) {
+            if ((NA + i) % NSTEP != part) continue;
             if (i < nb_mine) {
-                const unsigned voff = cvalid ? w_off0 + (unsigned)chunk * RB + (unsigned)(4 * i * RPI) * (unsigned)p.Kp * E::BYTES : OOB;
+                const unsigned voff = cvalid ? w_row[i] + (unsigned)chunk * RB : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + BM * RB + (wave + 4 * i) * 1024), 16, voff, 0, 0, 0);
             }
         }
-        kc += BK;
-        while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.kw) { kx = 0; ++ky; } }
+    };
+    auto advance = [&]() {                         // move the K position by one slice
+        if constexpr (MODE == 0) {
+            kc += BK;
+            while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.kw) { kx = 0; ++ky; } }
+        } else if constexpr (MODE == 2) {
+            kc += BK;
+            if (kc >= p.Cin) { kc = 0; if (++kx == p.kw) { kx = 0; ++ky; } }
+        }
     };
 
     f32x16 acc[TN][TM];
@@ -131,7 +170,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
     for (int s = 0; s < NSTEP; ++s) foff[s] = l31 * RB + (((2 * s + hi) ^ fkey) << 4);
 
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue(s, s);
+    for (int s = 0; s < NS - 1; ++s) {
+#pragma unroll
+        for (int part = 0; part < NSTEP; ++part) issue_part(s, s, part);
+        advance();
+    }
 
     for (int c = 0; c < p.nchunks; ++c) {
         // slice c has landed once at most the (NS-2) younger slices of this wave are still outstanding
@@ -139,21 +182,25 @@ __global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
         else wait_vmcnt<(NS - 2) * (NA + NBF + 1)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // (a) slice c visible to every wave, (b) stage (c-1)%NS is free
-        issue(c + NS - 1, (c + NS - 1) % NS);
         const unsigned char* a_s = lds + (c % NS) * STAGE;
         const unsigned char* b_s = a_s + BM * RB;
+        u32x4 fp[NSTEP][TM], fw[NSTEP][TN];
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
-            u32x4 fp[TM], fw[TN];
 #pragma unroll
-            for (int b = 0; b < TM; ++b) fp[b] = *(const u32x4*)(a_s + (wm * WM + b * 32) * RB + foff[s]);
+            for (int b = 0; b < TM; ++b) fp[s][b] = *(const u32x4*)(a_s + (wm * WM + b * 32) * RB + foff[s]);
 #pragma unroll
-            for (int a = 0; a < TN; ++a) fw[a] = *(const u32x4*)(b_s + (wn * WN + a * 32) * RB + foff[s]);
+            for (int a = 0; a < TN; ++a) fw[s][a] = *(const u32x4*)(b_s + (wn * WN + a * 32) * RB + foff[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
-                for (int b = 0; b < TM; ++b) mma_step<DT>(acc[a][b], fw[a], fp[b]);
+                for (int b = 0; b < TM; ++b) mma_step<DT>(acc[a][b], fw[s][a], fp[s][b]);
+            issue_part(c + NS - 1, (c + NS - 1) % NS, s);
         }
+        advance();
     }
     wait_vmcnt<0>();                               // drain the zero-fill slices issued past the end
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -329,19 +376,29 @@ static int set_lds_attr(KernelT kernel, int bytes) {
     return ICAF_OK;
 }
 
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS>
-static int launch_dma(const ConvP& q, dim3 grid, hipStream_t s) {
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE>
+static int launch_dma_mode(const ConvP& q, dim3 grid, hipStream_t s) {
     constexpr int ring = NS * (BM + BN) * RB;
     static_assert(ring <= 160 * 1024, "LDS capacity");
     static bool attr_done = false;                 // one flag per instantiation
     if (!attr_done) {
-        int st = set_lds_attr(igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS>, ring);
+        int st = set_lds_attr(igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE>, ring);
         if (st) return st;
         attr_done = true;
     }
-    igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS><<<grid, dim3(NTHREADS), ring, s>>>(q);
+    igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE><<<grid, dim3(NTHREADS), ring, s>>>(q);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
+}
+
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS>
+static int launch_dma(const ConvP& q, dim3 grid, hipStream_t s) {
+    const int eb = DT == ICAF_F32 ? 4 : 2;
+    const bool whole_taps = (q.Cin * eb) % RB == 0;          // a K slice never straddles two filter taps
+    if (whole_taps && q.kh == 1 && q.kw == 1 && q.sh == 1 && q.sw == 1 && q.ph == 0 && q.pw == 0)
+        return launch_dma_mode<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, 1>(q, grid, s);
+    if (whole_taps) return launch_dma_mode<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, 2>(q, grid, s);
+    return launch_dma_mode<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, 0>(q, grid, s);
 }
 
 template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT>
