@@ -7,7 +7,9 @@ namespace icaf {
 
 struct Anchors { float v[16]; };   // up to 8 anchors (w, h) in pixels
 
-// One thread per (b, anchor, y, x) cell; the `no` outputs of a cell are contiguous in the conv output.
+// One thread per OUTPUT ELEMENT (b, anchor, y, x, o), o fastest: z, logits and raw are written fully coalesced (their
+// rows are contiguous over (x, o)); the conv output is read in `no`-float runs at pixel stride ldp, each 128-byte line
+// being reused by the na anchors out of L2.
 //   z:      [B][rows_total][no]   rows ordered (anchor, y, x) per level, levels concatenated at row_offset
 //   logits: [B][rows_total][no-5] raw class scores
 //   raw:    [B][na][ny][nx][no]   pre-sigmoid map in the reference's permuted layout
@@ -15,31 +17,31 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restr
                                                             float* __restrict__ logits, float* __restrict__ raw, int B, int ny, int nx,
                                                             int na, int no, long long rows_total, long long row_offset, float stride,
                                                             Anchors anc) {
-    const long long cells = (long long)B * na * ny * nx;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < cells; idx += (long long)gridDim.x * blockDim.x) {
+    const long long total = (long long)B * na * ny * nx * no;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int o = (int)(e % no);
+        const long long idx = e / no;                      // cell index (b, a, y, x)
         const int x = (int)(idx % nx);
         long long t = idx / nx;
         const int y = (int)(t % ny);
         t /= ny;
         const int a = (int)(t % na), b = (int)(t / na);
-        const float* src = p + (((long long)b * ny + y) * nx + x) * ldp + a * no;
-        const long long row = row_offset + ((long long)a * ny + y) * nx + x;
-        float* zr = z + ((long long)b * rows_total + row) * no;
-        float* rr = raw ? raw + idx * no : nullptr;
-        float* lr = logits ? logits + ((long long)b * rows_total + row) * (no - 5) : nullptr;
-        const float aw = anc.v[2 * a], ah = anc.v[2 * a + 1];
-        for (int o = 0; o < no; ++o) {
-            const float v = src[o];
-            if (rr) rr[o] = v;
-            if (lr && o >= 5) lr[o - 5] = v;
-            const float sg = 1.0f / (1.0f + expf(-v));
-            float out = sg;
-            if (o == 0) out = ((sg * 2.0f - 0.5f) + (float)x) * stride;
-            else if (o == 1) out = ((sg * 2.0f - 0.5f) + (float)y) * stride;
-            else if (o == 2) { const float d = sg * 2.0f; out = (d * d) * aw; }
-            else if (o == 3) { const float d = sg * 2.0f; out = (d * d) * ah; }
-            zr[o] = out;
+        const float v = p[(((long long)b * ny + y) * nx + x) * ldp + a * no + o];
+        const long long row = (long long)b * rows_total + row_offset + ((long long)a * ny + y) * nx + x;
+        if (raw) raw[e] = v;
+        if (logits && o >= 5) logits[row * (no - 5) + (o - 5)] = v;
+        const float sg = 1.0f / (1.0f + expf(-v));
+        float out = sg;
+        if (o == 0) out = ((sg * 2.0f - 0.5f) + (float)x) * stride;
+        else if (o == 1) out = ((sg * 2.0f - 0.5f) + (float)y) * stride;
+        else if (o == 2 || o == 3) {
+            float an = anc.v[o - 2];                       // anchor (w, h) of `a`, selected without dynamic indexing
+#pragma unroll
+            for (int i = 1; i < 8; ++i) an = (a == i) ? (o == 2 ? anc.v[2 * i] : anc.v[2 * i + 1]) : an;
+            const float d = sg * 2.0f;
+            out = (d * d) * an;
         }
+        z[row * no + o] = out;
     }
 }
 
@@ -54,9 +56,9 @@ extern "C" int icaf_detect_decode(const float* p, int ldp, float* z, float* logi
     if (row_offset + (long long)na * ny * nx > rows_total) return fail(ICAF_ERR_ARG, "icaf_detect_decode: level does not fit in z");
     Anchors anc;
     for (int i = 0; i < 16; ++i) anc.v[i] = i < 2 * na ? anchors_px[i] : 0.0f;
-    const long long cells = (long long)B * na * ny * nx;
+    const long long cells = (long long)B * na * ny * nx * no;
     long long blocks = (cells + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(detect_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, S(s), p, ldp, z, logits, raw, B, ny, nx, na, no,
                        rows_total, row_offset, stride, anc);
     ICAF_LAUNCH_CHECK();

@@ -37,6 +37,43 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
     }
 }
 
+// ---- uint8 NCHW (the dataloader's 6-channel RGB+IR batch, reference test.py:116-123) -> NHWC / space-to-depth NHWC --
+// Fuses .to(device).float(), `/= 255.0` and the RGB / IR channel split: stream s of `nstreams` takes channels
+// [c0 + s*C, c0 + (s+1)*C) of every image and lands in out[s][b] (a pair act), so one launch stages both backbones from
+// a quarter of the bytes the fp32 path reads.  Division (not a reciprocal multiply) to round like the reference.
+template <int DT>
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ img, typename Elem<DT>::type* __restrict__ out,
+                                                            int B, int Ctot, int c0, int C, int nstreams, int H, int W, int Cpad, int mode) {
+    using E = Elem<DT>;
+    const int Ho = mode ? H / 2 : H, Wo = mode ? W / 2 : W;
+    const long long npix = (long long)nstreams * B * Ho * Wo;
+    const int nv = Cpad / E::VEC;
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long long)gridDim.x * blockDim.x) {
+        const int wo = (int)(pix % Wo);
+        long long t = pix / Wo;
+        const int ho = (int)(t % Ho);
+        t /= Ho;
+        const int b = (int)(t % B), st = (int)(t / B);
+        const unsigned char* src = img + ((long long)b * Ctot + c0 + st * C) * H * W;
+        for (int v = 0; v < nv; ++v) {
+            float f[E::VEC];
+#pragma unroll
+            for (int j = 0; j < E::VEC; ++j) {
+                const int ch = v * E::VEC + j;
+                float val = 0.0f;
+                if (mode == 0) {
+                    if (ch < C) val = (float)src[((long long)ch * H + ho) * W + wo] / 255.0f;
+                } else if (ch < 4 * C) {
+                    const int sub = ch / C, c = ch - sub * C, dy = sub >> 1, dx = sub & 1;
+                    val = (float)src[((long long)c * H + 2 * ho + dy) * W + 2 * wo + dx] / 255.0f;
+                }
+                f[j] = val;
+            }
+            *(u32x4*)(out + pix * Cpad + v * E::VEC) = pack16<DT>(f);
+        }
+    }
+}
+
 // ---- SPPF: y1 = maxpool_k(x), y2 = maxpool_k(y1), y3 = maxpool_k(y2), stride 1, -inf padding ----------------------
 // Chained k-pools equal direct pools with windows k, 2k-1, 3k-2 clipped at the border, so one pass over the
 // (3k-2)^2 neighbourhood produces all three outputs (the feature map is tiny and L2-resident).
@@ -192,6 +229,24 @@ extern "C" int icaf_preprocess_nchw(const float* img, void* out, int dtype, int 
     if (dtype == ICAF_F32) hipLaunchKernelGGL(preprocess_kernel<ICAF_F32>, grid, block, 0, S(s), img, (float*)out, B, C, H, W, Cpad, mode);
     else if (dtype == ICAF_BF16) hipLaunchKernelGGL(preprocess_kernel<ICAF_BF16>, grid, block, 0, S(s), img, (unsigned short*)out, B, C, H, W, Cpad, mode);
     else hipLaunchKernelGGL(preprocess_kernel<ICAF_F16>, grid, block, 0, S(s), img, (unsigned short*)out, B, C, H, W, Cpad, mode);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+extern "C" int icaf_preprocess_u8(const unsigned char* img, void* out, int dtype, int B, int Ctot, int c0, int C, int nstreams, int H,
+                                  int W, int Cpad, int mode, icaf_stream_t s) {
+    if (!img || !out) return fail(ICAF_ERR_ARG, "icaf_preprocess_u8: null pointer");
+    if (dtype < 0 || dtype > 2) return fail(ICAF_ERR_ARG, "icaf_preprocess_u8: bad dtype");
+    const int vec = vec_of(dtype);
+    if (Cpad % vec) return fail(ICAF_ERR_ARG, "icaf_preprocess_u8: Cpad %d must be a multiple of %d", Cpad, vec);
+    if (mode == 1 && ((H | W) & 1)) return fail(ICAF_ERR_ARG, "icaf_preprocess_u8: space-to-depth needs even H, W");
+    if (mode == 1 ? Cpad < 4 * C : Cpad < C) return fail(ICAF_ERR_ARG, "icaf_preprocess_u8: Cpad too small");
+    if (nstreams < 1 || c0 < 0 || c0 + nstreams * C > Ctot) return fail(ICAF_ERR_ARG, "icaf_preprocess_u8: channels [%d, %d) exceed %d", c0, c0 + nstreams * C, Ctot);
+    const long long total = (long long)nstreams * B * (mode ? H / 2 : H) * (mode ? W / 2 : W);
+    dim3 grid(grid_for(total)), block(256);
+    if (dtype == ICAF_F32) hipLaunchKernelGGL(preprocess_u8_kernel<ICAF_F32>, grid, block, 0, S(s), img, (float*)out, B, Ctot, c0, C, nstreams, H, W, Cpad, mode);
+    else if (dtype == ICAF_BF16) hipLaunchKernelGGL(preprocess_u8_kernel<ICAF_BF16>, grid, block, 0, S(s), img, (unsigned short*)out, B, Ctot, c0, C, nstreams, H, W, Cpad, mode);
+    else hipLaunchKernelGGL(preprocess_u8_kernel<ICAF_F16>, grid, block, 0, S(s), img, (unsigned short*)out, B, Ctot, c0, C, nstreams, H, W, Cpad, mode);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }

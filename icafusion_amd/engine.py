@@ -13,17 +13,18 @@ from . import ops
 class ImageIn:
     """Marks a raw NCHW fp32 network input (the only non-NHWC tensor on the path)."""
 
-    def __init__(self, tensor):
-        assert tensor.dim() in (4, 5)          # 5-D: the RGB and IR images stacked as (2, B, 3, H, W)
-        self.t = tensor
+    def __init__(self, tensor, c0=0, pair=None):
+        """fp32: (B, 3, H, W), or both streams stacked as (2, B, 3, H, W).  uint8: the dataloader's (B, Ctot, H, W)
+        batch, of which this input is channels [c0, c0+3) (pair=True: [c0, c0+3) and [c0+3, c0+6) for the two streams)."""
+        self.t, self.c0 = tensor, c0
+        self.u8 = tensor.dtype == torch.uint8
+        assert tensor.dim() == 4 if self.u8 else tensor.dim() in (4, 5)
+        self.pair = bool(pair) if self.u8 else tensor.dim() == 5
 
     @property
     def shape(self):
-        return self.t.shape[-4:]
-
-    @property
-    def pair(self):
-        return self.t.dim() == 5
+        B, _, H, W = self.t.shape[-4:]
+        return (B, 3, H, W)
 
 
 class Plan:

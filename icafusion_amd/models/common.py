@@ -190,13 +190,15 @@ class Conv(HipModule):
             if s2d:                       # 6x6/s2/p2 over the image == 3x3/s1/p1 over space-to-depth(image)
                 cpad = -(-4 * c1 // vec) * vec
                 pre = plan.act(B, H // 2, W // 2, cpad, pair=paired)
-                plan.add(ops.preprocess(x.t, pre, 1, name="preprocess_s2d"))
+                plan.add(ops.preprocess_u8(x.t, pre, 1, x.c0, name="preprocess_u8_s2d") if x.u8
+                         else ops.preprocess(x.t, pre, 1, name="preprocess_s2d"))
                 wp, kp, bp = self._cached(("s2d",) + key_tail, lambda: pack(ops.s2d_conv_weight, cpad))
                 x, c1, (kh, kw, sh, sw, ph, pw) = pre, cpad, (3, 3, 1, 1, 1, 1)
             else:
                 cpad = -(-c1 // vec) * vec
                 pre = plan.act(B, H, W, cpad, pair=paired)
-                plan.add(ops.preprocess(x.t, pre, 0, name="preprocess_pad"))
+                plan.add(ops.preprocess_u8(x.t, pre, 0, x.c0, name="preprocess_u8_pad") if x.u8
+                         else ops.preprocess(x.t, pre, 0, name="preprocess_pad"))
                 wp, kp, bp = self._cached(("pad",) + key_tail, lambda: pack(lambda w: w, cpad))
                 x, c1 = pre, cpad
         else:

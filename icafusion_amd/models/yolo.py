@@ -255,11 +255,19 @@ class Model(HipModule):
             twins[ir0 + k] = k
         return twins
 
-    def build_plan(self, B, H, W, device, dtype):
+    def build_plan(self, B, H, W, device, dtype, u8=False):
+        """u8=False: inputs are two fp32 NCHW images in [0, 1] (what the reference hands `model(img_rgb, img_ir)`);
+        u8=True: ONE uint8 (B, 6, H, W) tensor, the dataloader's RGB+IR batch — `/255`, the channel split and the cast
+        happen in the staging kernel (reference test.py:116-123)."""
         plan = Plan(device, dtype)
-        imgs = torch.zeros((2, B, 3, H, W), dtype=torch.float32, device=device)   # RGB and IR staging, adjacent
-        rgb, ir = imgs[0], imgs[1]
-        plan.inputs = [rgb, ir]
+        if u8:
+            img6 = torch.zeros((B, 6, H, W), dtype=torch.uint8, device=device)
+            plan.inputs = [img6]
+            in_pair, in_rgb, in_ir = ImageIn(img6, 0, pair=True), ImageIn(img6, 0), ImageIn(img6, 3)
+        else:
+            imgs = torch.zeros((2, B, 3, H, W), dtype=torch.float32, device=device)   # RGB and IR staging, adjacent
+            plan.inputs = [imgs[0], imgs[1]]
+            in_pair, in_rgb, in_ir = ImageIn(imgs), ImageIn(imgs[0]), ImageIn(imgs[1])
         shapes = self._layer_shapes(B, H, W)
         # Concat placement: producer layer index -> (concat buffer, channel offset)
         placement, cat_bufs = {}, {}
@@ -287,7 +295,7 @@ class Model(HipModule):
         for m in self.model:
             f = m.f
             if m.i in rgb_rows:                     # both streams in one paired launch sequence
-                src = ImageIn(imgs) if m.i == 0 else pair_out[m.i - 1]
+                src = in_pair if m.i == 0 else pair_out[m.i - 1]
                 pair_out[m.i] = emit_any(m, plan, src, None, twin=self.model[ir0 + m.i])
                 x = pair_out[m.i][0]
                 y.append(x)
@@ -297,9 +305,9 @@ class Model(HipModule):
                 y.append(x)
                 continue
             if f == -4:
-                src = ImageIn(ir)
+                src = in_ir
             elif f == -1:
-                src = ImageIn(rgb) if m.i == 0 else x
+                src = in_rgb if m.i == 0 else x
             elif isinstance(f, int):
                 src = y[f]
             else:
@@ -349,16 +357,37 @@ class Model(HipModule):
             return z, logits, raws
         return z.clone(), logits.clone(), [r.clone() for r in raws]
 
-    def plan_for(self, B, H, W, device="cuda", dtype=None):
-        """Pre-build (and return) the execution plan; its .inputs are the static RGB / IR staging buffers."""
+    def forward_u8(self, img6):
+        """Forward from the dataloader's uint8 (B, 6, H, W) RGB+IR batch (reference test.py:116-128 does
+        `.to(device).float() / 255`, splits `[:, :3]` / `[:, 3:]`, then `model(img_rgb, img_ir)`): same outputs as
+        forward(), one quarter of the input bytes, no fp32 image ever materialised."""
+        if self.training:
+            raise NotImplementedError("icafusion_amd implements the eval-mode inference path only (call .eval())")
+        if not img6.is_cuda or img6.dtype != torch.uint8 or img6.dim() != 4 or img6.shape[1] != 6:
+            raise ValueError("forward_u8 expects a cuda uint8 tensor of shape (B, 6, H, W)")
+        B, _, H, W = img6.shape
+        if H % 32 or W % 32:
+            raise ValueError(f"input size {H}x{W} must be a multiple of the max stride 32")
+        plan = self.plan_for(B, H, W, img6.device, u8=True)
+        if img6.data_ptr() != plan.inputs[0].data_ptr():
+            plan.inputs[0].copy_(img6)
+        plan.run()
+        z, logits, raws = plan.outputs
+        if self.static_outputs:
+            return z, logits, raws
+        return z.clone(), logits.clone(), [r.clone() for r in raws]
+
+    def plan_for(self, B, H, W, device="cuda", dtype=None, u8=False):
+        """Pre-build (and return) the execution plan; its .inputs are the static RGB / IR staging buffers (u8: the one
+        uint8 6-channel staging buffer)."""
         dt = dtype or self.compute_dtype or next(self.parameters()).dtype
         device = torch.device(device)
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        key = (B, H, W, dt, device)
+        key = (B, H, W, dt, device, "u8") if u8 else (B, H, W, dt, device)
         plans = self.__dict__.setdefault("_plans", {})
         if key not in plans:
-            plan = self.build_plan(B, H, W, device, dt)
+            plan = self.build_plan(B, H, W, device, dt, u8=u8)
             if self.autotune:
                 plan.autotune()
             if self.use_graph:

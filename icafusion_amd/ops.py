@@ -233,6 +233,21 @@ def preprocess(img, out, mode, name="preprocess"):
                                                cpad, mode), keep=(img, out), name=name, nbytes=nb)
 
 
+def preprocess_u8(img, out, mode, c0=0, name="preprocess_u8"):
+    """img: (B, Ctot, H, W) uint8 NCHW contiguous (the dataloader's RGB+IR batch); out: act (B, H', W', Cpad) fed from
+    channels [c0, c0+3), or a pair act (2, B, H', W', Cpad) fed from [c0, c0+3) and [c0+3, c0+6)."""
+    assert img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 4
+    nstreams = 2 if out.dim() == 5 else 1
+    B, Ctot, H, W = img.shape
+    o = flat_pair(out)
+    Bo, Ho, Wo, cpad, ldo = _act_geom(o)
+    assert ldo == cpad and Bo == nstreams * B and c0 + 3 * nstreams <= Ctot
+    assert (Ho, Wo) == ((H // 2, W // 2) if mode == 1 else (H, W))
+    nb = nstreams * B * 3 * H * W + o.numel() * o.element_size()
+    return Launch(lib().icaf_preprocess_u8, (img.data_ptr(), o.data_ptr(), dtype_code(o.dtype), B, Ctot, c0, 3, nstreams,
+                                             H, W, cpad, mode), keep=(img, out), name=name, nbytes=nb)
+
+
 def sppf_pool(x, y1, y2, y3, k, name="sppf_pool"):
     x, y1, y2, y3 = flat_pair(x), flat_pair(y1), flat_pair(y2), flat_pair(y3)
     B, H, W, Cc, ldx = _act_geom(x)

@@ -48,6 +48,11 @@ int icaf_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
  */
 int icaf_preprocess_nchw(const float* img, void* out, int dtype, int B, int C, int H, int W, int Cpad, int mode,
                          icaf_stream_t s);
+/* Same staging straight from the dataloader's uint8 batch (reference test.py:116-123: `img.to(device)`, `.float()`,
+ * `/= 255.0`, `img[:, :3]` / `img[:, 3:]`).  img: [B][Ctot][H][W] uint8; stream s (0 <= s < nstreams) takes channels
+ * [c0 + s*C, c0 + (s+1)*C) and is written to out[s][b] (nstreams*B images), value = (float)u8 / 255.0f. */
+int icaf_preprocess_u8(const unsigned char* img, void* out, int dtype, int B, int Ctot, int c0, int C, int nstreams,
+                       int H, int W, int Cpad, int mode, icaf_stream_t s);
 
 /* ---- implicit-GEMM convolution / linear ------------------------------------------------------------------
  * Replaces Conv.forward / fuseforward (models/common.py:48-60: SiLU(BN(Conv2d))) with BN folded into the

@@ -220,6 +220,27 @@ def test_first_layer_space_to_depth(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_preprocess_u8_matches_float_path(dt, mode):
+    """uint8 6-channel staging == reference recipe (`.float() / 255`, split, then the fp32 staging kernel), bit for bit."""
+    B, H, W = 2, 12, 20
+    g = np.random.default_rng(7)
+    img6 = torch.from_numpy(g.integers(0, 256, (B, 6, H, W), dtype=np.uint8)).to(DEV)
+    cpad = 16 if mode == 1 else 8
+    Ho, Wo = (H // 2, W // 2) if mode == 1 else (H, W)
+    pair = torch.zeros((2, B, Ho, Wo, cpad), dtype=dt, device=DEV)
+    run(ops.preprocess_u8(img6, pair, mode))
+    f = (img6.cpu().float() / 255.0).to(DEV)      # true division on the CPU, as the reference's CPU path (torch's GPU
+    for s_, sl in enumerate((slice(0, 3), slice(3, 6))):     # scalar division multiplies by the reciprocal instead)
+        ref = torch.zeros((B, Ho, Wo, cpad), dtype=dt, device=DEV)
+        run(ops.preprocess(f[:, sl].contiguous(), ref, mode))
+        assert torch.equal(pair[s_], ref)
+    single = torch.zeros((B, Ho, Wo, cpad), dtype=dt, device=DEV)
+    run(ops.preprocess_u8(img6, single, mode, c0=3))
+    assert torch.equal(single, pair[1])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_sppf_upsample_copy(dt):
     x = rnd((2, 64, 20, 12), 11)
     cat = torch.zeros((2, 20, 12, 256), dtype=dt, device=DEV)
@@ -237,7 +258,8 @@ def test_sppf_upsample_copy(dt):
 
 
 POOL_CASES = [(2, 128, 40, 40, 20, 20), (1, 64, 40, 40, 16, 16), (1, 64, 64, 80, 20, 20), (2, 32, 10, 10, 10, 10),
-              (1, 64, 68, 84, 20, 20)]
+              (1, 64, 68, 84, 20, 20),
+              (1, 32, 30, 33, 7, 9)]      # overlapping windows, token grid not a multiple of the 2x4 block per thread
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -95,6 +95,38 @@ def test_low_precision_forward_tolerance(dtype, box_tol, conf_tol):
     assert np.abs(z[..., 4:] - ref[..., 4:]).mean() <= conf_tol / 8
 
 
+def test_forward_u8_equals_float_forward():
+    """Model.forward_u8 (uint8 6-channel batch) == forward(img[:, :3] / 255, img[:, 3:] / 255)."""
+    cfg = load_cfg("yolov5s_Transfusion_kaist.yaml")
+    model = Model(cfg).eval()
+    model.load_state_dict(synth_state_dict(model, seed=3))
+    model = model.to("cuda:0")
+    g = np.random.default_rng(5)
+    img6 = torch.from_numpy(g.integers(0, 256, (2, 6, 320, 384), dtype=np.uint8)).cuda()
+    f = (img6.cpu().float() / 255.0).cuda()      # true division, as the reference's CPU path
+    for paired in (True, False):
+        model.pair_streams = paired
+        model.invalidate()
+        z0 = model(f[:, :3].contiguous(), f[:, 3:].contiguous())[0]
+        z1 = model.forward_u8(img6)[0]
+        assert torch.equal(z0, z1)
+
+
+def test_paired_streams_equal_separate_streams():
+    """Running both backbones as groups=2 launches (and C3's fused cv1+cv2 GEMM) must not change a single bit."""
+    cfg = load_cfg("yolov5s_Transfusion_kaist.yaml")
+    model = Model(cfg).eval()
+    model.load_state_dict(synth_state_dict(model, seed=4))
+    model = model.to("cuda:0")
+    rgb, ir = synth_images(2, 320, 320, seed=4)
+    outs = []
+    for paired in (True, False):
+        model.pair_streams = paired
+        model.invalidate()
+        outs.append(model(rgb.cuda(), ir.cuda())[0])
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_graph_replay_equals_eager():
     cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", seed=1, dtype=torch.bfloat16)
     rgb, ir = synth_images(2, 320, 320, seed=1)
