@@ -39,6 +39,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
     using EO = Elem<ODT>;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_M = BM / WM;
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;   // threads of the workgroup
     constexpr int VO = 16 / EO::BYTES;       // output elements per 16-byte vector
     constexpr int SO = BN * EO::BYTES + 16;  // staging row stride (bytes)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -51,7 +52,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
         for (int q = 0; q < 4; ++q) {
             const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;      // tile-local channel of this register quad
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
+            if (bias && n0 + nl < p.Cout) {        // (the packed bias is padded to a multiple of 128 >= Cout only)
                 const f32x4 t = *(const f32x4*)(bias + n0 + nl);
                 bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
             }
@@ -79,7 +80,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
     const typename E::type* __restrict__ rg = p.res ? (const typename E::type*)p.res + g * p.res_gs : nullptr;
     constexpr int VPR = BN / VO;                       // 16-byte vectors per staged row
     constexpr int NVEC = BM * VPR;
-    for (int idx = tid; idx < NVEC; idx += NTHREADS) {
+    for (int idx = tid; idx < NVEC; idx += NT) {
         const int row = idx / VPR, cv = idx - row * VPR;
         const int m = row_to_m(row), n = n0 + cv * VO;
         if (m < 0 || n >= p.Cout) continue;

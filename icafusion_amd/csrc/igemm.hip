@@ -45,7 +45,7 @@ namespace icaf {
 // address arithmetic), then the next slice's DMA instructions are issued in NSTEP portions between the MFMA steps, so
 // their VALU work hides under the matrix pipe instead of preceding it.
 template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE>
-__global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(const ConvP p) {
     using E = Elem<DT>;
     using L = TileLds<DT, ODT, BM, BN>;
     constexpr int VEC = E::VEC;
@@ -53,15 +53,16 @@ __global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
     constexpr int SPR = RB / 16;                   // 16-byte slots per row (4 / 8) = lanes per row of a DMA instruction
     constexpr int RPI = 1024 / RB;                 // LDS rows written by one wave-wide DMA instruction (16 / 8)
     constexpr int AI = BM / RPI, BI = BN / RPI;    // DMA instructions per slice for the pixel / weight tile
-    constexpr int NA = AI / 4;                     // ... per wave (pixel tile)
-    constexpr int NBF = BI / 4, NBR = BI % 4;      // weight tile: NBF per wave, waves < NBR one more
+    constexpr int NW = (BM / WM) * (BN / WN);      // wavefronts per workgroup (4, or 8 for the 256-row tiles)
+    constexpr int NA = AI / NW;                    // ... per wave (pixel tile)
+    constexpr int NBF = BI / NW, NBR = BI % NW;    // weight tile: NBF per wave, waves < NBR one more
     constexpr int NBMAX = NBF + (NBR ? 1 : 0);
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_M = BM / WM;
     constexpr int STAGE = (BM + BN) * RB;
     constexpr int NSTEP = RB / 32;                 // MFMA steps per slice
-    static_assert(AI % 4 == 0 && (BM / WM) * (BN / WN) == 4, "tile shape");
-    static_assert(NS * STAGE >= L::OUT_BYTES, "epilogue staging must fit in the ring");
+    static_assert(AI % NW == 0 && (NW == 4 || NW == 8), "tile shape");
+    // (the launch allocates max(ring, epilogue staging) bytes of LDS)
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
 
     // Lane -> (row, slot) of one DMA instruction: SPR lanes per row; the LDS slot is lane-linear, the SOURCE slot is
     // XOR-swizzled with key(row).  RB = 64: key = (row >> 2) & 3;  RB = 128: key = (row >> 1) & 7.  A wave's
-    // instructions are j = wave + 4i, so row = j*RPI + rsub has a key that depends on (wave & 1, rsub) only.
+    // instructions are j = wave + NW*i (NW even), so row = j*RPI + rsub has a key that depends on (wave & 1, rsub) only.
     const int rsub = lane / SPR;
     const int dkey = RB == 64 ? ((rsub >> 2) & 3) : (((wave & 1) << 2) | (rsub >> 1));
     const int lslot = (lane % SPR) ^ dkey;                         // logical 16-byte slot fetched by this lane
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
     bool a_ok[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int row = (wave + 4 * i) * RPI + rsub;
+        const int row = (wave + NW * i) * RPI + rsub;
         const int m = m0 + row;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
     unsigned w_row[NBMAX];
 #pragma unroll
     for (int i = 0; i < NBMAX; ++i)
-        w_row[i] = ((unsigned)(n0 + (wave + 4 * i) * RPI + rsub) * (unsigned)p.Kp + (unsigned)(lslot * VEC)) * E::BYTES;
+        w_row[i] = ((unsigned)(n0 + (wave + NW * i) * RPI + rsub) * (unsigned)p.Kp + (unsigned)(lslot * VEC)) * E::BYTES;
     const int nb_mine = NBF + (wave < NBR ? 1 : 0);
 
     // DMA instructions of one slice, portion `part` of NSTEP (instruction j of the wave belongs to portion j % NSTEP)
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
                 if constexpr (MODE == 2) voff = ok ? a_off[i] + tap_delta : OOB;
                 else voff = ok ? a_off[i] + (unsigned)((h * p.W + w) * p.ldx + kc) * E::BYTES : OOB;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + (wave + 4 * i) * 1024), 16, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
         }
         const bool cvalid = chunk < p.nchunks;
 #pragma unroll
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_dma_kernel(const ConvP p) {
             if ((NA + i) % NSTEP != part) continue;
             if (i < nb_mine) {
                 const unsigned voff = cvalid ? w_row[i] + (unsigned)chunk * RB : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + BM * RB + (wave + 4 * i) * 1024), 16, voff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + BM * RB + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
             }
         }
     };
@@ -334,11 +335,15 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 struct TileCfg { int id, bm, bn; const char* tag; };
-static const TileCfg kTiles[] = {{1, 128, 128, "128x128"}, {2, 128, 64, "128x64"}, {3, 256, 32, "256x32"}, {4, 64, 64, "64x64"}};
+static const TileCfg kTiles[] = {{1, 128, 128, "128x128"}, {2, 128, 64, "128x64"}, {3, 256, 32, "256x32"}, {4, 64, 64, "64x64"},
+                                 {5, 256, 128, "256x128"}, {6, 256, 256, "256x256"}};
 
 // Launch configuration id = tile (1..4) + 10 * pipeline:
 //   pipeline 0: LDS-DMA, 64-byte slices, 3-stage ring      pipeline 1: register-staged (fallback)
 //   pipeline 2: LDS-DMA, 128-byte slices, 2-stage ring     pipeline 3: LDS-DMA, 128-byte slices, 3-stage ring
+// Tiles 5 (256x128) and 6 (256x256) are 8-wavefront workgroups (one per CU, 96 / 128 KB ring) that exist only on
+// pipeline 2 for the 16-bit types: they halve the L2 -> LDS bytes per FLOP of the 128x128 tile, which is what bounds
+// the deep layers (the LDS-DMA feed tops out near 20 bytes / clock / CU).
 // ctile.hip
 int ctile_check(const icaf_conv_args* a, const ConvP& p, int shape);
 int launch_ctile(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
@@ -353,6 +358,7 @@ static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
         const int pipe = a->tile / 10;
         return (pipe != 1 && !dma_ok) ? a->tile % 10 + 10 : a->tile;
     }
+    if (a->tile == 25 || a->tile == 26) return a->tile;          // validated in launch_tile
     const bool f32 = a->dtype == ICAF_F32 || a->out_dtype == ICAF_F32;
     const int N = a->Cout;
     const long long M = p.M;
@@ -378,7 +384,8 @@ static int set_lds_attr(KernelT kernel, int bytes) {
 
 template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE>
 static int launch_dma_mode(const ConvP& q, dim3 grid, hipStream_t s) {
-    constexpr int ring = NS * (BM + BN) * RB;
+    constexpr int ring_only = NS * (BM + BN) * RB, stage_out = TileLds<DT, ODT, BM, BN>::OUT_BYTES;
+    constexpr int ring = ring_only > stage_out ? ring_only : stage_out;
     static_assert(ring <= 160 * 1024, "LDS capacity");
     static bool attr_done = false;                 // one flag per instantiation
     if (!attr_done) {
@@ -386,7 +393,7 @@ static int launch_dma_mode(const ConvP& q, dim3 grid, hipStream_t s) {
         if (st) return st;
         attr_done = true;
     }
-    igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE><<<grid, dim3(NTHREADS), ring, s>>>(q);
+    igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE><<<grid, dim3((BM / WM) * (BN / WN) * 64), ring, s>>>(q);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
@@ -429,6 +436,19 @@ static int launch_cfg(const ConvP& p, int groups, int pipe, hipStream_t s) {
     return launch_act<DT, ODT, BM, BN, WM, WN, ICAF_ACT_NONE>(q, grid, pipe, s);
 }
 
+// 8-wavefront tiles: pipeline 2 only
+template <int DT, int ODT, int BM, int BN, int WM, int WN>
+static int launch_big(const ConvP& p, int groups, hipStream_t s) {
+    ConvP q = p;
+    q.mtiles = (p.M + BM - 1) / BM;
+    q.ntiles = (p.Cout + BN - 1) / BN;
+    q.nchunks = (p.K + 63) / 64;                  // 128-byte slices of a 16-bit type
+    dim3 grid((unsigned)(q.mtiles * q.ntiles), 1, (unsigned)groups);
+    if (p.act == ICAF_ACT_SILU) return launch_dma<DT, ODT, BM, BN, WM, WN, ICAF_ACT_SILU, 128, 2>(q, grid, s);
+    if (p.act == ICAF_ACT_GELU) return launch_dma<DT, ODT, BM, BN, WM, WN, ICAF_ACT_GELU, 128, 2>(q, grid, s);
+    return launch_dma<DT, ODT, BM, BN, WM, WN, ICAF_ACT_NONE, 128, 2>(q, grid, s);
+}
+
 template <int DT, int ODT>
 static int launch_tile(const ConvP& p, int groups, int cfg, hipStream_t s) {
     const int pipe = cfg / 10;
@@ -439,6 +459,13 @@ static int launch_tile(const ConvP& p, int groups, int cfg, hipStream_t s) {
         case 2: return launch_cfg<DT, ODT, 128, 64, 64, 32>(p, groups, pipe, s);
         case 3: return launch_cfg<DT, ODT, 256, 32, 64, 32>(p, groups, pipe, s);
         case 4: return launch_cfg<DT, ODT, 64, 64, 32, 32>(p, groups, pipe, s);
+        case 5:
+        case 6:
+            if constexpr (DT == ICAF_F32 || ODT == ICAF_F32) return fail(ICAF_ERR_UNSUPPORTED, "tiles 256x128 / 256x256 exist for 16-bit types only");
+            else {
+                if (pipe != 2 || p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "tiles 256x128 / 256x256 run on the 128-byte LDS-DMA pipeline only (id 25 / 26)");
+                return cfg % 10 == 5 ? launch_big<DT, ODT, 256, 128, 64, 64>(p, groups, s) : launch_big<DT, ODT, 256, 256, 128, 64>(p, groups, s);
+            }
         default: return fail(ICAF_ERR_ARG, "unknown tile id %d", cfg);
     }
 }

@@ -177,6 +177,11 @@ def autotune_conv(launch, stream_ptr, reps=3):
             if t == 3 and a.Cout > 32:
                 continue
             cands.append(t + 10 * pipe)
+    if a.dtype != F32 and a.out_dtype == a.dtype:            # 8-wavefront tiles (128-byte LDS-DMA pipeline only)
+        if a.Cout >= 128:
+            cands.append(25)
+        if a.Cout >= 256:
+            cands.append(26)
     if (a.kh, a.kw, a.ph, a.pw) == (3, 3, 1, 1) and a.act == ACT_SILU and a.out_dtype == a.dtype:
         for shape, (bn, stride) in CTILE_SHAPES.items():       # 3x3 direct convolution from an LDS halo patch
             if a.sh == stride and a.sw == stride and a.Cout <= bn and (bn < 64 or a.Cout > bn // 2):

@@ -75,6 +75,17 @@ if a.sweep:
                 l(sp)
             e1.record(sp)
             res.append((e0.elapsed_ms(e1) * 100, f"p{pipe}:{names[t]}"))
+        for big in (25, 26):                               # 8-wavefront tiles
+            c.tile = big
+            if c.Cout < (128 if big == 25 else 256) or l.fn(*l.args, sp) != 0:
+                continue
+            torch.cuda.synchronize()
+            e0, e1 = ops.Event(), ops.Event()
+            e0.record(sp)
+            for _ in range(10):
+                l(sp)
+            e1.record(sp)
+            res.append((e0.elapsed_ms(e1) * 100, "p2:256x128" if big == 25 else "p2:256x256"))
         for shape in (1, 2, 3, 4, 5):                      # ctile.hip (3x3 halo-patch kernel); inapplicable -> status != 0
             c.tile = 40 + shape
             if l.fn(*l.args, sp) != 0:
