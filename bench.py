@@ -123,8 +123,11 @@ def main():
     model.static_outputs = True
     model.autotune = not args.no_autotune
     B, H, W = args.batch, args.height, args.width
-    if args.tune_cache and os.path.exists(args.tune_cache):
-        ops.load_tune_cache(args.tune_cache)
+    default_cache = os.path.join(ROOT, "profiles", "tune_cache.json")     # committed igemm tile choices: the same kernels
+    if args.tune_cache and os.path.exists(args.tune_cache):               # run (and were profiled) from round to round;
+        ops.load_tune_cache(args.tune_cache)                              # layers missing from it are tuned on the spot
+    elif not args.tune_cache and os.path.exists(default_cache):
+        ops.load_tune_cache(default_cache)
     model.use_graph = not args.no_graph
     pipe = DetectionPipeline(model, B, H, W, dev, conf_thres=args.conf, iou_thres=args.iou, world=world,
                              overlap=not args.no_overlap)

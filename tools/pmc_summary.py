@@ -19,7 +19,7 @@ def short(name):
     """rocprof kernel name -> the name bench.py reports (igemm instantiations that differ only in the activation
     template argument are merged, as ops.conv_kernel_name does)."""
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"icaf::igemm_dma_kernel<(\d+), (\d+), (\d+), (\d+), \d+, \d+, \d+, (\d+), (\d+)>", name)
+    m = re.match(r"icaf::igemm_dma_kernel<(\d+), (\d+), (\d+), (\d+), \d+, \d+, \d+, (\d+), (\d+)(?:, \d+)?>", name)
     if m:
         dt, odt, bm, bn, rb, ns = map(int, m.groups())
         return f"igemm_dma{rb}x{ns}_{_DN[dt]}_{_DN[odt]}_{bm}x{bn}"
@@ -27,8 +27,16 @@ def short(name):
     if m:
         dt, odt, bm, bn = map(int, m.groups())
         return f"igemm_reg_{_DN[dt]}_{_DN[odt]}_{bm}x{bn}"
+    m = re.match(r"icaf::ctile_kernel<(\d+), (\d+), (\d+), (\d+), \d+, (\d+)>", name)
+    if m:
+        dt, th, tw, bn, st = map(int, m.groups())
+        return f"ctile_{_DN[dt]}_{th}x{tw}n{bn}" + ("s2" if st == 2 else "")
     m = re.match(r"icaf::(\w+)(<[^>]*>)?", name)
-    return (m.group(1) + (m.group(2) or "")) if m else name[:80]
+    if m:
+        return {"preprocess_kernel": "preprocess_s2d", "pool_tokens_kernel": "dmff_pool_tokens", "upsample_merge_kernel": "dmff_upsample_merge",
+                "cross_attn_kernel": "cross_attention", "detect_decode_kernel": "detect_decode", "sppf_lds_kernel": "sppf_pool",
+                "upsample_kernel": "upsample_nearest"}.get(m.group(1), m.group(1))
+    return name[:80]
 
 
 def collect(d):
@@ -50,7 +58,7 @@ def main():
     dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
     workload = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--workload=")), None)
     for d in dirs:
-        for k, cs in collect(d).items():
+        for k, cs in collect(d).items():       # collect() already merges kernels that map to the same short name
             for c, (s, n) in cs.items():
                 res.setdefault(k, {})[c] = {"mean_per_dispatch": s / max(n, 1), "dispatches": n}
     for k, cs in res.items():
