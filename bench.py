@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-fuse-tail", action="store_true", help="materialise DMFF's merged tensor instead of the fused-tail GEMM")
     ap.add_argument("--no-overlap", action="store_true", help="run NMS on the forward stream (no cross-batch overlap)")
     ap.add_argument("--tune-cache", default=None, help="json file: load igemm tile choices if present, save after tuning")
     return ap.parse_args()
@@ -118,6 +119,7 @@ def main():
     model.load_state_dict(sd)
     for i in (20, 21, 22):
         model.model[i].crosstransformer[0].loops = args.loops
+        model.model[i].fuse_tail = not args.no_fuse_tail
     model = model.to(dev)
     model.compute_dtype = DT[args.dtype]
     model.static_outputs = True

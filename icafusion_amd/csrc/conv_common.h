@@ -13,6 +13,7 @@ struct ConvP {
     int vec_y, vec_r;
     unsigned int x_bytes, w_bytes;      // buffer-descriptor ranges (DMA pipeline); 0 = not representable
     float alpha_acc[2], alpha_res[2];
+    const float* pre; int pre_h, pre_w, ldpre;     // optional pre-activation bilinear term (icaf.h)
 };
 
 constexpr int ROWB = 64;        // bytes of K per LDS row per slice
@@ -33,7 +34,9 @@ __device__ __forceinline__ int xcd_tile(int ntile_total) {
 
 // ---- epilogue shared by both pipelines: bias + activation in registers, LDS staging, 16-byte write-back --------
 // row_to_m(tile_row) -> linear output pixel index (b, ho, wo), or -1 when the tile row lies outside the tensor.
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, typename RowMap>
+// PRE = true compiles the pre-activation bilinear term in (it costs ~40 registers, so only the few instantiations that
+// serve DMFF's fused tail carry it).
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, bool PRE, typename RowMap>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsigned char* lds, const ConvP& p, int g, RowMap row_to_m, int n0) {
     using E = Elem<DT>;
     using EO = Elem<ODT>;
@@ -46,6 +49,33 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const float alpha_acc = p.alpha_acc[g], alpha_res = p.alpha_res[g];
     const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
+    // pre-activation bilinear term: the four source taps and weights of this lane's TM pixels (align_corners=False:
+    // src = max(0, (dst + 0.5) * in/out - 0.5), neighbours clamped), exactly as upsample_merge_kernel computes them
+    const float* pt[PRE ? TM : 1][4];
+    float plx[PRE ? TM : 1], ply[PRE ? TM : 1];
+    if constexpr (PRE) {
+        const float sy = (float)p.pre_h / (float)p.Ho, sx = (float)p.pre_w / (float)p.Wo;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const int m = row_to_m(wm * WM + b * 32 + l31);
+            const int mm = m < 0 ? 0 : m;
+            const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, bi = t / p.Ho;
+            float fy = ((float)ho + 0.5f) * sy - 0.5f, fx = ((float)wo + 0.5f) * sx - 0.5f;
+            fy = fy < 0.0f ? 0.0f : fy;
+            fx = fx < 0.0f ? 0.0f : fx;
+            int y0 = (int)fy, x0 = (int)fx;
+            y0 = y0 < p.pre_h - 1 ? y0 : p.pre_h - 1;
+            x0 = x0 < p.pre_w - 1 ? x0 : p.pre_w - 1;
+            const int y1 = y0 < p.pre_h - 1 ? y0 + 1 : y0, x1 = x0 < p.pre_w - 1 ? x0 + 1 : x0;
+            ply[b] = fy - (float)y0;
+            plx[b] = fx - (float)x0;
+            const float* base = p.pre + (long long)bi * p.pre_h * p.pre_w * p.ldpre;
+            pt[b][0] = base + (long long)(y0 * p.pre_w + x0) * p.ldpre;
+            pt[b][1] = base + (long long)(y0 * p.pre_w + x1) * p.ldpre;
+            pt[b][2] = base + (long long)(y1 * p.pre_w + x0) * p.ldpre;
+            pt[b][3] = base + (long long)(y1 * p.pre_w + x1) * p.ldpre;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
 #pragma unroll
@@ -59,9 +89,20 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
                 const int ml = wm * WM + b * 32 + l31;
+                float pv[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (PRE) if (n0 + nl < p.Cout) {
+                    const f32x4 t00 = *(const f32x4*)(pt[b][0] + n0 + nl), t01 = *(const f32x4*)(pt[b][1] + n0 + nl);
+                    const f32x4 t10 = *(const f32x4*)(pt[b][2] + n0 + nl), t11 = *(const f32x4*)(pt[b][3] + n0 + nl);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float top = t00[j] * (1.0f - plx[b]) + t01[j] * plx[b];
+                        const float bot = t10[j] * (1.0f - plx[b]) + t11[j] * plx[b];
+                        pv[j] = top * (1.0f - ply[b]) + bot * ply[b];
+                    }
+                }
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT>(acc[a][b][4 * q + j] + bv[j]) * alpha_acc;
+                for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT>(acc[a][b][4 * q + j] + bv[j] + pv[j]) * alpha_acc;
                 unsigned char* dst = lds + ml * SO + nl * EO::BYTES;
                 if constexpr (EO::BYTES == 4) {
                     *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};

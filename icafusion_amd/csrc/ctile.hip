@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NTHREADS) void ctile_kernel(const ConvP p, const in
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    epilogue<DT, DT, BM, BN, WM, BN, ACT>(acc, lds, p, g, [&](int row) {
+    epilogue<DT, DT, BM, BN, WM, BN, ACT, false>(acc, lds, p, g, [&](int row) {
         const int st = row >> 5, r = row & 31;
         const int py = TW == 32 ? st : st * 2 + (r >> 4), px = TW == 32 ? r : (r & 15);
         const int gy = y0 + py, gx = x0 + px;
@@ -190,6 +190,7 @@ int ctile_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     if (a->Cout > sh.bn) return fail(ICAF_ERR_UNSUPPORTED, "ctile %s: Cout=%d > %d", sh.tag, a->Cout, sh.bn);
     if (a->act != ICAF_ACT_SILU || a->out_dtype != a->dtype) return fail(ICAF_ERR_UNSUPPORTED, "ctile: SiLU and out dtype == dtype only");
     if (p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "ctile: operand exceeds the 2 GiB buffer-descriptor range");
+    if (a->pre) return fail(ICAF_ERR_UNSUPPORTED, "ctile: no pre-activation term");
     if (a->Kp % (128 / eb)) return fail(ICAF_ERR_UNSUPPORTED, "ctile: Kp must be a multiple of 128 bytes");
     return ICAF_OK;
 }

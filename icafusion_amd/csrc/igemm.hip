@@ -26,7 +26,7 @@
 //     buffer-descriptor range and kept selectable for A/B measurements (configuration ids 11..14).
 #include "conv_common.h"
 
-static_assert(sizeof(icaf_conv_args) == 184, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
+static_assert(sizeof(icaf_conv_args) == 208, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
 
 namespace icaf {
 
@@ -44,7 +44,7 @@ namespace icaf {
 // Loop shape: after the single barrier of a slice, ALL its fragments are read into registers (LDS latency overlaps the
 // address arithmetic), then the next slice's DMA instructions are issued in NSTEP portions between the MFMA steps, so
 // their VALU work hides under the matrix pipe instead of preceding it.
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE>
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE, bool PRE>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(const ConvP p) {
     using E = Elem<DT>;
     using L = TileLds<DT, ODT, BM, BN>;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(c
     wait_vmcnt<0>();                               // drain the zero-fill slices issued past the end
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    epilogue<DT, ODT, BM, BN, WM, WN, ACT>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
+    epilogue<DT, ODT, BM, BN, WM, WN, ACT, PRE>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
 }
 
 // ===============================================================================================================
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
         if (more) store_tiles((c + 1) & 1);
         __syncthreads();
     }
-    epilogue<DT, ODT, BM, BN, WM, WN, ACT>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
+    epilogue<DT, ODT, BM, BN, WM, WN, ACT, false>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -372,6 +372,10 @@ static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
     if (blocks(t) < 512 && blocks(4) > blocks(t)) t = 4;
     if (!dma_ok) return t + 10;
     const int eb = a->dtype == ICAF_F32 ? 4 : 2;
+    if (a->pre) {                                   // only tiles 1 / 2 on pipelines 0 / 2 carry the pre term
+        if (t > 2) t = 2;
+        return ((long long)a->Cin * eb) % 128 == 0 ? t + 20 : t;
+    }
     // full 128-byte lines whenever a pixel's tap (or two adjacent taps) provides them
     return (long long)p.K * eb >= 256 ? t + 20 : t;
 }
@@ -382,18 +386,18 @@ static int set_lds_attr(KernelT kernel, int bytes) {
     return ICAF_OK;
 }
 
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE>
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE, bool PRE = false>
 static int launch_dma_mode(const ConvP& q, dim3 grid, hipStream_t s) {
     constexpr int ring_only = NS * (BM + BN) * RB, stage_out = TileLds<DT, ODT, BM, BN>::OUT_BYTES;
     constexpr int ring = ring_only > stage_out ? ring_only : stage_out;
     static_assert(ring <= 160 * 1024, "LDS capacity");
     static bool attr_done = false;                 // one flag per instantiation
     if (!attr_done) {
-        int st = set_lds_attr(igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE>, ring);
+        int st = set_lds_attr(igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE, PRE>, ring);
         if (st) return st;
         attr_done = true;
     }
-    igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE><<<grid, dim3((BM / WM) * (BN / WN) * 64), ring, s>>>(q);
+    igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE, PRE><<<grid, dim3((BM / WM) * (BN / WN) * 64), ring, s>>>(q);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
@@ -402,6 +406,14 @@ template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int 
 static int launch_dma(const ConvP& q, dim3 grid, hipStream_t s) {
     const int eb = DT == ICAF_F32 ? 4 : 2;
     const bool whole_taps = (q.Cin * eb) % RB == 0;          // a K slice never straddles two filter taps
+    if (q.pre) {      // pre-activation bilinear term (DMFF fused tail): 1x1 + SiLU on the 128-row tiles only
+        if constexpr (ACT == ICAF_ACT_SILU && ODT == DT && BM == 128 && (BM / WM) * (BN / WN) == 4 && NS * RB != 384) {
+            if (whole_taps && q.kh == 1 && q.kw == 1 && q.sh == 1 && q.sw == 1 && q.ph == 0 && q.pw == 0)
+                return launch_dma_mode<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, 1, true>(q, grid, s);
+        }
+        return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: `pre` is built for 1x1 / stride 1 SiLU layers with Cin*bytes %% %d == 0 on tiles 128x128 / 128x64 "
+                                          "(pipelines 0 and 2)", RB);
+    }
     if (whole_taps && q.kh == 1 && q.kw == 1 && q.sh == 1 && q.sw == 1 && q.ph == 0 && q.pw == 0)
         return launch_dma_mode<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, 1>(q, grid, s);
     if (whole_taps) return launch_dma_mode<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, 2>(q, grid, s);
@@ -415,6 +427,7 @@ static int launch_act(const ConvP& q, dim3 grid, int pipe, hipStream_t s) {
         case 2: return launch_dma<DT, ODT, BM, BN, WM, WN, ACT, 128, 2>(q, grid, s);
         case 3: return launch_dma<DT, ODT, BM, BN, WM, WN, ACT, 128, 3>(q, grid, s);
         default:
+            if (q.pre) return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: `pre` is not built for the register-staged pipeline");
             igemm_kernel<DT, ODT, BM, BN, WM, WN, ACT><<<grid, dim3(NTHREADS), 0, s>>>(q);
             ICAF_LAUNCH_CHECK();
             return ICAF_OK;
@@ -488,6 +501,8 @@ static int validate(const icaf_conv_args* a) {
     if (a->ldy < a->Cout) return fail(ICAF_ERR_ARG, "icaf_conv2d: ldy < Cout");
     if (a->res && a->ldr < a->Cout) return fail(ICAF_ERR_ARG, "icaf_conv2d: ldr < Cout");
     if ((long long)a->B * a->Ho * a->Wo > 0x7fffffffLL) return fail(ICAF_ERR_ARG, "icaf_conv2d: too many output pixels");
+    if (a->pre && (a->pre_h < 1 || a->pre_w < 1 || a->ldpre < a->Cout || (a->ldpre & 3) || ((uintptr_t)a->pre & 15) || a->groups != 1))
+        return fail(ICAF_ERR_ARG, "icaf_conv2d: pre needs pre_h, pre_w >= 1, ldpre >= Cout and a multiple of 4, 16-byte alignment, groups == 1");
     return ICAF_OK;
 }
 
@@ -514,6 +529,7 @@ static void fill(const icaf_conv_args* a, ConvP& p) {
     if (xb < 0x7fffff00LL && wb < 0x7fffff00LL) { p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb; }
     else { p.x_bytes = 0; p.w_bytes = 0; }
     for (int i = 0; i < 2; ++i) { p.alpha_acc[i] = a->alpha_acc[i]; p.alpha_res[i] = a->alpha_res[i]; }
+    p.pre = a->pre; p.pre_h = a->pre_h; p.pre_w = a->pre_w; p.ldpre = a->ldpre;
 }
 
 }  // namespace icaf

@@ -141,14 +141,15 @@ class Conv(HipModule):
             b = (b - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
         return w, b
 
-    def emit(self, plan, x, out=None, res=None, twin=None, also=(), twin_also=()):
+    def emit(self, plan, x, out=None, res=None, twin=None, also=(), twin_also=(), pre_term=None):
         """Append this layer's launch.
 
         twin: the structurally identical Conv of the other backbone stream — x / out / res are then pair acts
               (2, B, H, W, C) and both streams run as ONE groups=2 launch with per-stream weights.
         also: further Convs with the same geometry and activation reading the same input (C3's cv1 and cv2): their
               output channels are appended to this layer's, one GEMM with N = sum of the widths (twin_also: the
-              twin stream's counterparts)."""
+              twin stream's counterparts).
+        pre_term: fp32 coarse map (B, h, w, Cout) added, bilinearly resized, before bias + activation (icaf.h)."""
         if self.conv.groups != 1 or self.conv.dilation != (1, 1):
             raise NotImplementedError("grouped / dilated convolutions are outside the hot path")
         kh, kw = self.conv.kernel_size
@@ -213,7 +214,7 @@ class Conv(HipModule):
         if out is None:
             out = plan.act(B, Ho, Wo, c2, pair=paired)
         plan.add(ops.conv2d(x, wp, kp, bp, out, kh, kw, sh, sw, ph, pw, c1, c2, self._act_code(), res=res,
-                            name=f"conv{kh}x{kw}s{sh}"))
+                            name=f"conv{kh}x{kw}s{sh}", pre=pre_term))
         return out
 
 
@@ -441,18 +442,24 @@ class CrossTransformerBlock(HipModule):
         rows = x.shape[1]
         gs = dict(x=x.stride(0), w=wp.stride(0), bias=bp.stride(0), y=y.stride(0),
                   res=res.stride(0) if res is not None else 0)
-        plan.add(ops.conv2d(x[0].view(rows, 1, 1, cin), wp, kp, bp, y[0].view(rows, 1, 1, cout), 1, 1, 1, 1, 0, 0,
-                            cin, cout, act, res=res[0].view(rows, 1, 1, cout) if res is not None else None,
+
+        def rows_act(t, c):       # group 0 of a (2, rows, C) token tensor (row stride t.stride(1)) as a (rows, 1, 1, c) act
+            ld = t.stride(1)
+            return t[0].as_strided((rows, 1, 1, c), (ld, ld, ld, 1))
+        plan.add(ops.conv2d(rows_act(x, cin), wp, kp, bp, rows_act(y, cout), 1, 1, 1, 1, 0, 0,
+                            cin, cout, act, res=rows_act(res, cout) if res is not None else None,
                             alpha_acc=alpha_acc, alpha_res=alpha_res, groups=2, group_strides=gs, name=name))
 
-    def emit_tokens(self, plan, tok, B, N):
-        """tok: (2, B*N, C) [0]=RGB [1]=IR -> same shape after `loops` shared-weight iterations."""
+    def emit_tokens(self, plan, tok, B, N, final_out=None):
+        """tok: (2, B*N, C) [0]=RGB [1]=IR -> same shape after `loops` shared-weight iterations.  final_out: optional
+        (2, B*N, C) view (any row / group strides) that the last iteration writes instead of a fresh buffer."""
         p = self._packed(plan)
         C = tok.shape[2]
         rows = tok.shape[1]
         co, ln = p["co"], p["ln"]
         hid = self.mlp_vis[0].out_features
-        for _ in range(int(self.loops)):
+        nloops = int(self.loops)
+        for it in range(nloops):
             n1 = plan.tokens(2, rows, C)
             plan.add(ops.layernorm(tok, n1, ln["a1w"], ln["a1b"], ln["a2w"], ln["a2b"], p["eps"][0], name="ln_attn"))
             qkv = plan.tokens(2, rows, 3 * C)
@@ -466,7 +473,7 @@ class CrossTransformerBlock(HipModule):
             plan.add(ops.layernorm(xatt, n2, ln["mw"], ln["mb"], ln["mw"], ln["mb"], p["eps"][2], name="ln_mlp"))
             h = plan.tokens(2, rows, hid)
             self._gemm(plan, n2, p["fc1"], h, C, hid, ops.ACT_GELU, name="mlp_fc1")
-            nxt = plan.tokens(2, rows, C)
+            nxt = final_out if (final_out is not None and it == nloops - 1) else plan.tokens(2, rows, C)
             self._gemm(plan, h, p["fc2"], nxt, hid, C, ops.ACT_NONE, res=xatt, alpha_res=(co[4], co[6]),
                        alpha_acc=(co[5], co[7]), name="mlp_fc2")
             tok = nxt
@@ -495,6 +502,7 @@ class TransformerFusionBlock(HipModule):
             for _ in range(n_layer)])
         self.concat = Concat(dimension=1)
         self.conv1x1_out = Conv(c1=d_model * 2, c2=d_model, k=1, s=1, p=0, g=1, act=True)
+        self.fuse_tail = True        # run interpolate + residual + cat + conv1x1_out as one GEMM when the layout allows
 
     def emit(self, plan, xs, out=None):
         rgb, ir = xs
@@ -515,11 +523,38 @@ class TransformerFusionBlock(HipModule):
         pos_v, pos_i, w_v, w_i = self._cached(("dmff", plan.device), make)
         tok = plan.tokens(2, B * N, C)
         plan.add(ops.dmff_pool_tokens(rgb, ir, pos_v, pos_i, tok, th, tw, kh, kw, sh, sw, w_v, w_i))
-        for blk in self.crosstransformer:
-            tok = blk.emit_tokens(plan, tok, B, N)
-        merged = plan.act(B, H, W, 2 * C)
-        plan.add(ops.dmff_upsample_merge(tok, rgb, ir, merged, th, tw))
-        return self.conv1x1_out.emit(plan, merged, out=out)
+        feat2c = concat_view([rgb, ir]) if self.fuse_tail else None
+        if (2 * C * rgb.element_size()) % 128:        # the pre-term GEMM instantiations walk K in whole 128-byte slices
+            feat2c = None
+        blocks = list(self.crosstransformer)
+        if feat2c is None or not blocks or int(blocks[-1].loops) < 1:
+            # general path: materialise cat(rgb + up(tok_rgb), ir + up(tok_ir)), then the 1x1 fuse conv
+            for blk in blocks:
+                tok = blk.emit_tokens(plan, tok, B, N)
+            merged = plan.act(B, H, W, 2 * C)
+            plan.add(ops.dmff_upsample_merge(tok, rgb, ir, merged, th, tw))
+            return self.conv1x1_out.emit(plan, merged, out=out)
+        # Fused tail (both streams' features are adjacent channel slices of one buffer, as Model.build_plan places them):
+        # the 1x1 convolution commutes with the bilinear resize and with the residual add (all linear), so
+        #   conv(cat(rgb + up(t_rgb), ir + up(t_ir))) = conv(cat(rgb, ir)) + up(conv(cat(t_rgb, t_ir)))
+        # The token-resolution product P is a tiny GEMM (fp32 out); the full-resolution GEMM reads the untouched
+        # features and adds bilinear(P) before bias + SiLU in its epilogue.  The (B, H, W, 2C) merged tensor of
+        # models/common.py:827-840 is never written or read.
+        tokcat = plan.empty((B * N, 2 * C), plan.dtype)                      # [t_rgb | t_ir] per token
+        final = tokcat.as_strided((2, B * N, C), (C, 2 * C, 1))
+        for j, blk in enumerate(blocks):
+            tok = blk.emit_tokens(plan, tok, B, N, final_out=final if j == len(blocks) - 1 else None)
+        conv = self.conv1x1_out
+
+        def make():
+            w, _ = conv.folded()                                              # BN scale folded in; bias stays in the main GEMM
+            wp, kp = ops.pack_conv_weight(w, plan.dtype)
+            return wp, kp
+        wp, kp = self._cached(("tailw", plan.dtype, plan.device), make)
+        P = plan.empty((B, th, tw, C), torch.float32)
+        plan.add(ops.conv2d(tokcat.view(B * N, 1, 1, 2 * C), wp, kp, None, P.view(B * N, 1, 1, C), 1, 1, 1, 1, 0, 0,
+                            2 * C, C, ops.ACT_NONE, name="dmff_tail_tokens"))
+        return conv.emit(plan, feat2c, out=out, pre_term=P)
 
 
 # ----------------------------------------------------------------------------------------------------------

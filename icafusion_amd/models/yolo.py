@@ -283,6 +283,17 @@ class Model(HipModule):
                 for s in srcs:
                     placement[s] = (buf, off, shapes[s][0])
                     off += shapes[s][0]
+        # DMFF inputs: the RGB and IR feature maps a TransformerFusionBlock reads are placed as adjacent channel slices
+        # of one (B, H, W, 2C) buffer, so its 1x1 fuse conv can read cat(rgb, ir) in place (common.py, fused tail)
+        dmff_pair = {}
+        for m in self.model:
+            if isinstance(m, TransformerFusionBlock) and not isinstance(m.f, int) and len(m.f) == 2 and m.fuse_tail:
+                i, j = m.f
+                if i in placement or j in placement or i in dmff_pair or j in dmff_pair or shapes[i] != shapes[j]:
+                    continue
+                C, h, w = shapes[i]
+                buf = plan.act(B, h, w, 2 * C)
+                dmff_pair[i], dmff_pair[j] = (buf, 0, C, j), (buf, C, C, i)
         twins = self.stream_twins()                 # a prefix run by construction; cut it at the first row that a
         ir0 = min(twins) if twins else None         # Concat placement pins to another buffer
         run = 0
@@ -296,7 +307,12 @@ class Model(HipModule):
             f = m.f
             if m.i in rgb_rows:                     # both streams in one paired launch sequence
                 src = in_pair if m.i == 0 else pair_out[m.i - 1]
-                pair_out[m.i] = emit_any(m, plan, src, None, twin=self.model[ir0 + m.i])
+                pout = None
+                if m.i in dmff_pair and dmff_pair[m.i][3] == ir0 + m.i:       # pair act = the two halves of the DMFF buffer
+                    buf, _, c, _ = dmff_pair[m.i]
+                    Bb, h, w, _ = buf.shape
+                    pout = buf.as_strided((2, Bb, h, w, c), (c, h * w * 2 * c, w * 2 * c, 2 * c, 1))
+                pair_out[m.i] = emit_any(m, plan, src, pout, twin=self.model[ir0 + m.i])
                 x = pair_out[m.i][0]
                 y.append(x)
                 continue
@@ -315,6 +331,9 @@ class Model(HipModule):
             out = None
             if m.i in placement:
                 buf, off, c = placement[m.i]
+                out = buf[..., off:off + c]
+            elif m.i in dmff_pair:
+                buf, off, c, _ = dmff_pair[m.i]
                 out = buf[..., off:off + c]
             x = emit_any(m, plan, src, out)
             y.append(x)

@@ -110,7 +110,7 @@ def s2d_conv_weight(w4d):
 # launches
 # ------------------------------------------------------------------------------------------------------------
 def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res=None, alpha_acc=1.0,
-           alpha_res=1.0, groups=1, group_strides=None, tile=0, name="conv2d"):
+           alpha_res=1.0, groups=1, group_strides=None, tile=0, name="conv2d", pre=None):
     """Record an implicit-GEMM conv / linear.  x, y, res are acts; for groups=2 they are the group-0 views and
     group_strides = dict(x=, w=, bias=, y=, res=) gives element strides to group 1."""
     B, H, W, cx, ldx = _act_geom(x)
@@ -142,12 +142,16 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
     a.alpha_acc[0], a.alpha_acc[1] = float(aa[0]), float(aa[1])
     a.alpha_res[0], a.alpha_res[1] = float(ar[0]), float(ar[1])
     a.tile = tile
+    if pre is not None:               # fp32 coarse map (B, h, w, >= cout) added, bilinearly resized, before the activation
+        Bp, hp, wp_, cp, ldp = _act_geom(pre)
+        assert pre.dtype == torch.float32 and Bp == B and cp >= cout and groups == 1
+        a.pre, a.pre_h, a.pre_w, a.ldpre = pre.data_ptr(), hp, wp_, ldp
     m = B * Ho * Wo
     flops = 2.0 * m * cout * kh * kw * cin * groups
     es, eo = x.element_size(), y.element_size()
     nbytes = groups * (B * H * W * cin * es + cout * kh * kw * cin * es + m * cout * eo
                        + (m * cout * es if res is not None else 0))
-    return Launch(lib().icaf_conv2d, (C.byref(a),), keep=(a, x, w_packed, bias, y, res), name=name, flops=flops,
+    return Launch(lib().icaf_conv2d, (C.byref(a),), keep=(a, x, w_packed, bias, y, res, pre), name=name, flops=flops,
                   nbytes=nbytes)
 
 
@@ -158,7 +162,7 @@ CONV_PIPELINES = (0, 1, 2)        # LDS-DMA 64 B x3, register-staged, LDS-DMA 12
 
 def _conv_signature(a):
     return (a.B * a.Ho * a.Wo, a.Cout, a.Cin, a.kh, a.kw, a.sh, a.sw, a.H, a.W, a.ldx, a.ldy, a.groups, a.dtype,
-            a.out_dtype, a.act, bool(a.res))
+            a.out_dtype, a.act, bool(a.res), bool(a.pre))
 
 
 def autotune_conv(launch, stream_ptr, reps=3):
@@ -170,19 +174,21 @@ def autotune_conv(launch, stream_ptr, reps=3):
         a.tile = _TUNE_CACHE[sig]
         return a.tile
     cands = []
-    for pipe in CONV_PIPELINES:
+    if a.pre:                          # pre-activation term: built for tiles 128x128 / 128x64 on the LDS-DMA pipelines 0 / 2
+        cands = [t + 10 * pipe for pipe in (0, 2) for t in (1, 2) if not (t == 1 and (a.out_dtype == F32 or a.Cout <= 64))]
+    for pipe in (() if a.pre else CONV_PIPELINES):
         for t in (1, 2, 3, 4):
             if t == 1 and (a.out_dtype == F32 or a.Cout <= 64):
                 continue
             if t == 3 and a.Cout > 32:
                 continue
             cands.append(t + 10 * pipe)
-    if a.dtype != F32 and a.out_dtype == a.dtype:            # 8-wavefront tiles (128-byte LDS-DMA pipeline only)
+    if a.dtype != F32 and a.out_dtype == a.dtype and not a.pre:            # 8-wavefront tiles (128-byte LDS-DMA pipeline only)
         if a.Cout >= 128:
             cands.append(25)
         if a.Cout >= 256:
             cands.append(26)
-    if (a.kh, a.kw, a.ph, a.pw) == (3, 3, 1, 1) and a.act == ACT_SILU and a.out_dtype == a.dtype:
+    if (a.kh, a.kw, a.ph, a.pw) == (3, 3, 1, 1) and a.act == ACT_SILU and a.out_dtype == a.dtype and not a.pre:
         for shape, (bn, stride) in CTILE_SHAPES.items():       # 3x3 direct convolution from an LDS halo patch
             if a.sh == stride and a.sw == stride and a.Cout <= bn and (bn < 64 or a.Cout > bn // 2):
                 cands.append(40 + shape)

@@ -60,7 +60,7 @@ int icaf_preprocess_u8(const unsigned char* img, void* out, int dtype, int B, in
  * (models/common.py:607-618,704-709), the residual add of Bottleneck (models/common.py:194) and the
  * LearnableCoefficient mixes (models/common.py:746-750), and Detect's 1x1 output convs (models/yolo_test.py:50).
  *
- *   y[m][n] = alpha_res * res[m][n] + alpha_acc * act( sum_k A[m][k] * Wp[n][k] + bias[n] )
+ *   y[m][n] = alpha_res * res[m][n] + alpha_acc * act( sum_k A[m][k] * Wp[n][k] + bias[n] [+ bilinear(pre)[m][n]] )
  *
  * m = (b, ho, wo) output pixel, k = (kh, kw, cin) gathered on the fly from x (zero outside the image),
  * Wp = packed weights [Np][Kp] (K-major, Np = Cout rounded up to 128, Kp = K rounded up to 64 elements, zero
@@ -86,6 +86,13 @@ typedef struct icaf_conv_args {
     float alpha_acc[2];
     float alpha_res[2];
     int tile; /* 0 = auto; otherwise force a tile config id (tuning / tests) */
+    /* Optional pre-activation term, bilinearly resized (align_corners=False) from a coarse fp32 map:
+     *   y = alpha_res*res + alpha_acc * act( A.W + bias + bilinear(pre)[b][ho][wo][n] )
+     * pre: [B][pre_h][pre_w][ldpre] fp32 (NULL = none).  This is how DMFF's tail (models/common.py:827-841:
+     * F.interpolate(tokens) + feature, cat, conv1x1_out) runs as ONE GEMM over the untouched features: the 1x1
+     * convolution commutes with the (linear) resize, so conv(cat(f + up(t))) = conv(cat(f)) + up(conv(cat(t))). */
+    const float* pre;
+    int pre_h, pre_w, ldpre;
 } icaf_conv_args;
 
 int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s);

@@ -176,6 +176,26 @@ def test_conv3x3_halo_tile_rejects_other_layers():
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("tile", [0, 2, 22])
+def test_conv2d_pre_activation_bilinear_term(dt, tile):
+    """y = act(conv(x) + bias + F.interpolate(pre, bilinear, align_corners=False)): the epilogue term behind DMFF's
+    fused tail (reference models/common.py:827-841)."""
+    B, H, W, cin, cout, th, tw = 2, 22, 30, 64, 40, 5, 7
+    x = rnd((B, cin, H, W), 31)
+    w = rnd((cout, cin, 1, 1), 32, 1.0 / math.sqrt(cin))
+    bias = rnd((cout,), 33, 0.2)
+    pre = rnd((B, cout, th, tw), 34)
+    xa = to_act(x, dt)
+    wp, kp = ops.pack_conv_weight(w.to(DEV), dt)
+    bp = ops.pack_bias(bias.to(DEV), cout)
+    pa = pre.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = torch.zeros((B, H, W, cout), dtype=dt, device=DEV)
+    run(ops.conv2d(xa, wp, kp, bp, y, 1, 1, 1, 1, 0, 0, cin, cout, ops.ACT_SILU, pre=pa, tile=tile))
+    ref = F.silu(F.conv2d(q(x, dt), q(w, dt), bias) + F.interpolate(pre, size=(H, W), mode="bilinear", align_corners=False))
+    close(from_act(y), ref, dt, "conv + bilinear pre-activation term")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_conv2d_fp32_output_and_groups(dt):
     rows, cin, cout = 300, 64, 192
     x = rnd((2, rows, cin), 5)

@@ -127,6 +127,27 @@ def test_paired_streams_equal_separate_streams():
     assert torch.equal(outs[0], outs[1])
 
 
+def test_fused_dmff_tail_matches_materialised_tail():
+    """conv1x1_out(cat(f + up(t))) computed as conv(cat(f)) + up(conv(cat(t))) (one GEMM, no merged tensor) vs the
+    reference's order of operations (upsample_merge kernel + GEMM): equal up to fp32 rounding."""
+    cfg = load_cfg("yolov5s_Transfusion_kaist.yaml")
+    model = Model(cfg).eval()
+    model.load_state_dict(synth_state_dict(model, seed=6))
+    model = model.to("cuda:0")
+    rgb, ir = synth_images(2, 384, 320, seed=6)
+    outs = []
+    for fused in (True, False):
+        for i in (20, 21, 22):
+            model.model[i].fuse_tail = fused
+        model.invalidate()
+        plan = model.plan_for(2, 384, 320)
+        names = [l.name for l in plan.launches]
+        assert ("dmff_tail_tokens" in names) == fused and ("dmff_upsample_merge" in names) == (not fused)
+        outs.append(model(rgb.cuda(), ir.cuda())[0])
+    err = (outs[0] - outs[1]).abs().max().item() / outs[1].abs().max().item()
+    assert err < 1e-5, err
+
+
 def test_graph_replay_equals_eager():
     cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", seed=1, dtype=torch.bfloat16)
     rgb, ir = synth_images(2, 320, 320, seed=1)
