@@ -56,6 +56,7 @@ SIGNATURES = {
     "icaf_graph_destroy": (_i, [_p]),
     "icaf_event_create": (_i, [C.POINTER(_p)]),
     "icaf_event_record": (_i, [_p, _p]),
+    "icaf_stream_wait_event": (_i, [_p, _p]),
     "icaf_event_elapsed_ms": (_i, [_p, _p, C.POINTER(_f)]),
     "icaf_event_destroy": (_i, [_p]),
     "icaf_stream_sync": (_i, [_p]),

@@ -69,6 +69,10 @@ extern "C" int icaf_event_record(void* ev, icaf_stream_t s) {
     ICAF_HIP(hipEventRecord((hipEvent_t)ev, S(s)));
     return ICAF_OK;
 }
+extern "C" int icaf_stream_wait_event(icaf_stream_t s, void* ev) {
+    ICAF_HIP(hipStreamWaitEvent(S(s), (hipEvent_t)ev, 0));
+    return ICAF_OK;
+}
 extern "C" int icaf_event_elapsed_ms(void* start, void* stop, float* ms) {
     ICAF_HIP(hipEventSynchronize((hipEvent_t)stop));
     ICAF_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));

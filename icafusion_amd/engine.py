@@ -35,6 +35,11 @@ class Plan:
         self.outputs = None
         self.graph = None
         self.nbytes = 0
+        # side branches of the captured graph: id -> {"after": index of the launch the branch depends on,
+        # "join_before": index of the first main-chain launch that needs its results}.  Launches tagged with the id run
+        # on their own capture stream, i.e. as a parallel branch of the hipGraph: small latency-bound kernels (DMFF of
+        # the shallow levels) fill the CUs the backbone's tails leave idle.  Eager replay ignores branches.
+        self.branches = {}
 
     # -- buffers ------------------------------------------------------------------------------------------
     def act(self, B, H, W, C, dtype=None, pair=False):
@@ -75,16 +80,47 @@ class Plan:
         return [ops.autotune_conv(l, sp) for l in self.launches if l.fn is fn]
 
     def capture(self):
-        """Capture the launch list into a hipGraph on a side stream (legacy default stream cannot capture)."""
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        sp = side.cuda_stream
+        """Capture the launch list into a hipGraph on side streams (the legacy default stream cannot capture); launches
+        of a branch are captured on their own stream between a fork and a join event."""
+        dev = self.device
+        main = torch.cuda.Stream(device=dev)
+        main.wait_stream(torch.cuda.current_stream(dev))
+        sp = main.cuda_stream
         for l in self.launches:          # warm every kernel once outside capture (module load, first-touch)
             l(sp)
-        side.synchronize()
+        main.synchronize()
+        sides = {bid: torch.cuda.Stream(device=dev) for bid in self.branches}
+        forks = {bid: ops.Event() for bid in self.branches}
+        joins = {bid: ops.Event() for bid in self.branches}
+        self._capture_keep = (main, sides, forks, joins)
+
+        def body():
+            started, joined = set(), set()
+
+            def join(bid):
+                joins[bid].record(sides[bid].cuda_stream)
+                joins[bid].wait(sp)
+                joined.add(bid)
+            for idx, l in enumerate(self.launches):
+                for bid, b in self.branches.items():
+                    if b["join_before"] == idx and bid in started and bid not in joined:
+                        join(bid)
+                if l.branch:
+                    bid = l.branch
+                    if bid not in started:
+                        forks[bid].wait(sides[bid].cuda_stream)
+                        started.add(bid)
+                    l(sides[bid].cuda_stream)
+                else:
+                    l(sp)
+                for bid, b in self.branches.items():
+                    if b["after"] == idx:
+                        forks[bid].record(sp)
+            for bid in started - joined:
+                join(bid)
         g = ops.Graph()
-        g.capture(sp, lambda: [l(sp) for l in self.launches])
-        side.synchronize()
+        g.capture(sp, body)
+        main.synchronize()
         self.graph = g
         return self
 

@@ -179,6 +179,7 @@ class Model(HipModule):
         self.autotune = False        # device-time every igemm configuration once per plan and keep the fastest
         self.use_graph = False       # replay each plan as one hipGraph launch
         self.pair_streams = True     # run structurally identical RGB / IR backbone rows as one groups=2 launch
+        self.branch_dmff = True      # capture the shallow DMFF blocks as parallel branches of the hipGraph
         self.static_outputs = False  # return views of plan-owned buffers instead of clones
 
     # -- reference API ----------------------------------------------------------------------------------------
@@ -303,8 +304,11 @@ class Model(HipModule):
         rgb_rows = set(twins.values())
         pair_out = {}
         y, x = [], None
+        last_launch = {}                            # yaml row -> index of its last launch
+        dmff_rows = [m.i for m in self.model if isinstance(m, TransformerFusionBlock)]
         for m in self.model:
             f = m.f
+            n_before = len(plan.launches)
             if m.i in rgb_rows:                     # both streams in one paired launch sequence
                 src = in_pair if m.i == 0 else pair_out[m.i - 1]
                 pout = None
@@ -315,6 +319,7 @@ class Model(HipModule):
                 pair_out[m.i] = emit_any(m, plan, src, pout, twin=self.model[ir0 + m.i])
                 x = pair_out[m.i][0]
                 y.append(x)
+                last_launch[m.i] = last_launch[ir0 + m.i] = len(plan.launches) - 1
                 continue
             if m.i in twins:                        # already emitted with its RGB twin
                 x = pair_out[twins[m.i]][1]
@@ -337,6 +342,29 @@ class Model(HipModule):
                 out = buf[..., off:off + c]
             x = emit_any(m, plan, src, out)
             y.append(x)
+            last_launch[m.i] = len(plan.launches) - 1
+            # DMFF blocks other than the last one become side branches of the captured graph: they depend only on their
+            # two backbone rows, and nothing needs them before the head, so they overlap with the deeper backbone rows
+            if self.branch_dmff and m.i in dmff_rows[:-1] and not isinstance(f, int) and len(plan.launches) > n_before:
+                bid = len(plan.branches) + 1
+                for l in plan.launches[n_before:]:
+                    l.branch = bid
+                plan.branches[bid] = {"after": max(last_launch[j] for j in f), "join_before": None, "row": m.i}
+            elif plan.branches and dmff_rows and m.i == dmff_rows[-1] + 1:
+                for b in plan.branches.values():          # joined before the first head launch
+                    if b["join_before"] is None:
+                        b["join_before"] = n_before
+            if self.branch_dmff and isinstance(m, Detect) and not isinstance(f, int):
+                # Detect levels fed by earlier head rows (P3, P4) only need that row: their 1x1 conv + decode run as
+                # branches beside the remaining head rows and are joined at the end of the graph
+                per = (len(plan.launches) - n_before) // len(f)
+                for lvl, j in enumerate(f[:-1]):
+                    if per * len(f) != len(plan.launches) - n_before or last_launch[j] >= n_before - 1:
+                        continue
+                    bid = len(plan.branches) + 1
+                    for l in plan.launches[n_before + lvl * per:n_before + (lvl + 1) * per]:
+                        l.branch = bid
+                    plan.branches[bid] = {"after": last_launch[j], "join_before": None, "row": m.i}
         plan.outputs = x
         return plan
 

@@ -57,10 +57,11 @@ def flat_pair(t):
 
 class Launch:
     """One recorded kernel launch: fn(*args, stream)."""
-    __slots__ = ("fn", "args", "keep", "name", "flops", "bytes")
+    __slots__ = ("fn", "args", "keep", "name", "flops", "bytes", "branch")
 
     def __init__(self, fn, args, keep=(), name="", flops=0, nbytes=0):
         self.fn, self.args, self.keep, self.name, self.flops, self.bytes = fn, args, keep, name, flops, nbytes
+        self.branch = 0          # 0 = main chain; > 0 = a side branch of the captured graph (engine.Plan.branches)
 
     def __call__(self, stream_ptr):
         st = self.fn(*self.args, stream_ptr)
@@ -409,6 +410,10 @@ class Event:
 
     def record(self, stream_ptr):
         check(lib().icaf_event_record(self.ev, stream_ptr), "event_record")
+
+    def wait(self, stream_ptr):
+        """Make `stream_ptr` wait for this event (inside a capture: adds a dependency edge / joins the capture)."""
+        check(lib().icaf_stream_wait_event(stream_ptr, self.ev), "stream_wait_event")
 
     def elapsed_ms(self, stop):
         ms = C.c_float(0)

@@ -166,6 +166,7 @@ int icaf_graph_launch(void* graph_exec, icaf_stream_t s);
 int icaf_graph_destroy(void* graph_exec);
 int icaf_event_create(void** ev);
 int icaf_event_record(void* ev, icaf_stream_t s);
+int icaf_stream_wait_event(icaf_stream_t s, void* ev);         /* hipStreamWaitEvent: fork / join of capture branches */
 int icaf_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 int icaf_event_destroy(void* ev);
 int icaf_stream_sync(icaf_stream_t s);
