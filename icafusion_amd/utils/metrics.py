@@ -48,3 +48,37 @@ def ap_per_class(tp, conf, pred_cls, target_cls, plot=False, save_dir=".", names
     fn = n_l - tpn
     fp = (tpn / (p + 1e-16) - tpn).round()
     return tpn[:, i], fp[:, i], fn[:, i], p[:, i], r[:, i], ap, f1[:, i], unique_classes.astype("int32")
+
+
+def match_predictions(det, labels, iouv):
+    """TP flags of one image's detections at every IoU threshold (reference test.py:196-230).
+
+    det: (n, 6) [x1, y1, x2, y2, conf, cls]; labels: (m, 5) [cls, x1, y1, x2, y2] in the same pixel space; iouv: (T,).
+    Per class each prediction is paired with its best-IoU target; predictions are visited in index order and a target
+    is claimed by the first prediction above iouv[0] that reaches it.  Returns bool (n, T)."""
+    det, labels, iouv = np.asarray(det, np.float32), np.asarray(labels, np.float32), np.asarray(iouv, np.float32)
+    correct = np.zeros((det.shape[0], iouv.shape[0]), bool)
+    if not len(det) or not len(labels):
+        return correct
+    claimed_total = 0
+    for cls in np.unique(labels[:, 0]):
+        ti = np.flatnonzero(labels[:, 0] == cls)
+        pi = np.flatnonzero(det[:, 5] == cls)
+        if not len(pi):
+            continue
+        a, b = det[pi, :4], labels[ti, 1:5]
+        inter = (np.minimum(a[:, None, 2:], b[None, :, 2:]) - np.maximum(a[:, None, :2], b[None, :, :2])).clip(0).prod(2)
+        area_a, area_b = (a[:, 2:] - a[:, :2]).prod(1), (b[:, 2:] - b[:, :2]).prod(1)
+        iou = inter / (area_a[:, None] + area_b[None, :] - inter)
+        best, arg = iou.max(1), iou.argmax(1)
+        claimed = set()
+        for j in np.flatnonzero(best > iouv[0]):
+            t = int(ti[arg[j]])
+            if t in claimed:
+                continue
+            claimed.add(t)
+            claimed_total += 1
+            correct[pi[j]] = best[j] > iouv
+            if claimed_total == len(labels):
+                break
+    return correct
