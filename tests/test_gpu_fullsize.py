@@ -1,0 +1,99 @@
+"""BASELINE.json's configurations at FULL size on the MI355X, checked through size-independent properties (the CPU oracle
+would need minutes per batch here): every kernel on the path is per-sample, so a batch must equal its sub-batches bit
+for bit whatever tiles / kernels the shapes select; NMS output must be sorted, within bounds and idempotent; and a small
+slice of each full-size batch is still compared with the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import load_cfg                                     # noqa: E402
+from icafusion_amd.models.yolo import Model                      # noqa: E402
+from icafusion_amd.synth import synth_images, synth_state_dict   # noqa: E402
+from icafusion_amd.utils.general import nms_device, non_max_suppression   # noqa: E402
+from oracle import icaf_oracle as oracle                         # noqa: E402
+
+DEV = "cuda:0"
+
+
+def build(yaml_name, dtype, loops=1, seed=0):
+    cfg = load_cfg(yaml_name)
+    m = Model(cfg).eval()
+    sd = synth_state_dict(m, seed)
+    m.load_state_dict(sd)
+    for i in (20, 21, 22):
+        m.model[i].crosstransformer[0].loops = loops
+    m = m.to(DEV)
+    m.compute_dtype = dtype
+    return cfg, sd, m
+
+
+def check_nms_properties(z, conf, iou, multi_label=False):
+    det, count, _ = nms_device(z, conf, iou, multi_label=multi_label)
+    torch.cuda.synchronize()
+    det, count = det.cpu().numpy(), count.cpu().numpy()
+    for b in range(det.shape[0]):
+        d = det[b, :count[b]]
+        assert 0 <= count[b] <= 300
+        assert (np.diff(d[:, 4]) <= 0).all(), "detections must come out in descending confidence"
+        assert (d[:, 4] > conf).all() and (d[:, 2] >= d[:, 0]).all() and (d[:, 3] >= d[:, 1]).all()
+    # idempotence: feeding the survivors back (as xywh, obj = conf, one-hot class) keeps every one of them
+    b = 0
+    d = det[b, :count[b]]
+    if len(d):
+        nc = z.shape[2] - 5
+        back = np.zeros((1, len(d), 5 + nc), np.float32)
+        back[0, :, 0], back[0, :, 1] = (d[:, 0] + d[:, 2]) / 2, (d[:, 1] + d[:, 3]) / 2
+        back[0, :, 2], back[0, :, 3] = d[:, 2] - d[:, 0], d[:, 3] - d[:, 1]
+        back[0, :, 4] = 1.0
+        back[0, np.arange(len(d)), 5 + d[:, 5].astype(int)] = d[:, 4]
+        again = non_max_suppression(torch.from_numpy(back).to(DEV), conf * 0.5, iou, multi_label=multi_label)[0]
+        assert len(again) == len(d), "NMS of an already suppressed set must keep all of it"
+
+
+def test_config2_s_bf16_b32_640_subbatch_consistency_and_nms():
+    cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", torch.bfloat16)
+    rgb, ir = synth_images(32, 640, 640, seed=2)
+    rgb, ir = rgb.to(DEV), ir.to(DEV)
+    z = m(rgb, ir)[0]
+    for lo in (0, 24):                                   # batch 32 == its slices of 8, bit for bit
+        zs = m(rgb[lo:lo + 8].contiguous(), ir[lo:lo + 8].contiguous())[0]
+        assert torch.equal(z[lo:lo + 8], zs)
+    assert torch.isfinite(z).all()
+    check_nms_properties(z, 0.1, 0.5)
+
+
+def test_config3_l_bf16_b32_640_per_gpu_shard():
+    cfg, sd, m = build("yolov5l_Transfusion_kaist.yaml", torch.bfloat16)
+    rgb, ir = synth_images(32, 640, 640, seed=3)
+    rgb, ir = rgb.to(DEV), ir.to(DEV)
+    z = m(rgb, ir)[0]
+    zs = m(rgb[8:12].contiguous(), ir[8:12].contiguous())[0]
+    assert torch.equal(z[8:12], zs) and torch.isfinite(z).all()
+    check_nms_properties(z, 0.1, 0.5)
+
+
+def test_config4_s_512x640_loops3_b64_and_oracle_slice():
+    cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", torch.float32, loops=3)
+    rgb, ir = synth_images(64, 512, 640, seed=4)
+    z = m(rgb.to(DEV), ir.to(DEV))[0]
+    assert z.shape == (64, 20160, 6)                     # 20160 rows at 512x640
+    ref = oracle.OracleModel(cfg, sd, loops=3).forward(rgb[:2], ir[:2])[0]
+    err = (z[:2].cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-3, err                               # north_star: fp32 1e-3
+    dets = non_max_suppression(z[:2], 0.25, 0.45)
+    for d, r in zip(dets, oracle.non_max_suppression(z[:2].cpu().numpy(), 0.25, 0.45)):
+        np.testing.assert_array_equal(d.cpu().numpy(), r)           # bit-exact keep set on the same predictions
+    check_nms_properties(z, 0.001, 0.5)
+
+
+def test_config5_l_vedai_f16_1280_b16_multilabel():
+    cfg, sd, m = build("yolov5l_Transfusion_VEDAI.yaml", torch.float16)
+    rgb, ir = synth_images(16, 1280, 1280, seed=5)
+    rgb, ir = rgb.to(DEV), ir.to(DEV)
+    z = m(rgb, ir)[0]
+    assert z.shape == (16, 100800, 14) and torch.isfinite(z).all()
+    zs = m(rgb[4:6].contiguous(), ir[4:6].contiguous())[0]
+    assert torch.equal(z[4:6], zs)
+    check_nms_properties(z, 0.3, 0.5, multi_label=True)

@@ -9,7 +9,7 @@ for grp in "conv2d or first_layer or conv3x3 or preprocess" "sppf or pool_tokens
   grep -E "^(FAILED|ERROR)" gpurun_out/k_$name.log | head -20
   grep -E "AssertionError|Error:|error" gpurun_out/k_$name.log | sort | uniq -c | sort -rn | head -12
 done
-timeout 900 python -m pytest tests/test_gpu_model.py tests/test_frontends.py -q -m gpu --timeout=300 --tb=short -p no:cacheprovider > gpurun_out/model.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_model.py tests/test_frontends.py tests/test_gpu_fullsize.py -q -m gpu --timeout=300 --tb=short -p no:cacheprovider > gpurun_out/model.log 2>&1
 echo "== model: $(tail -1 gpurun_out/model.log)"
 grep -E "^(FAILED|ERROR)" gpurun_out/model.log | head -20
 grep -E "AssertionError|Error:|error|assert " gpurun_out/model.log | sort | uniq -c | sort -rn | head -20
