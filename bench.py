@@ -184,15 +184,21 @@ def main():
     total_ms = sum(v[0] for v in per_kernel.values()) / reps
     dom = max(per_kernel.items(), key=lambda kv: kv[1][0])
     dname, (dms, dflops, dbytes, dn) = dom
-    is_mfma = dflops > 0
-    if is_mfma:
-        achieved = dflops / (dms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype],
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4)}
+    # which roof bounds the dominant kernel: its algorithmic intensity against the ridge of the chip (dense MFMA peak /
+    # HBM peak = 312 FLOP/B for the 16-bit types).  Both fractions are reported.
+    tflops = dflops / (dms * 1e-3) / 1e12 if dflops else 0.0
+    gbs = dbytes / (dms * 1e-3) / 1e9
+    intensity = dflops / dbytes if dbytes else 0.0
+    ridge = PEAK_TFLOPS[args.dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
+    if dflops and intensity >= ridge:
+        roof = {"bound": "mfma", "kernel": dname, "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype],
+                "unit": "TFLOP/s", "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4)}
     else:
-        achieved = dbytes / (dms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": dname, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(achieved / PEAK_HBM_GBS, 4)}
+        roof = {"bound": "hbm", "kernel": dname, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    roof.update({"intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+                 "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / PEAK_TFLOPS[args.dtype], 4),
+                 "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)})
     roof.update({"traffic": None, "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_traffic.json)",
                  "algorithmic_bytes_per_launch": round(dbytes / dn), "avg_launch_us": round(1e3 * dms / dn, 2), "launches_per_step": dn // reps,
                  "share_of_forward_kernel_time": round(dms / reps / total_ms, 3)})
@@ -216,6 +222,11 @@ def main():
             "forward_only_pairs_per_s": round(B / (fwd_ms * 1e-3), 2),
             "forward_ms_per_batch": round(fwd_ms, 3),
             "model_tflops": round(gf * B / (fwd_ms * 1e-3) / 1e3, 2) if gf else None,
+            "forward_roofline": {      # whole forward: algorithmic FLOPs and leaf-op bytes of all launches over the replay time
+                "tflops": round(sum(v[1] for v in per_kernel.values()) / reps / (fwd_ms * 1e-3) / 1e12, 1),
+                "mfma_frac": round(sum(v[1] for v in per_kernel.values()) / reps / (fwd_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+                "gbs": round(sum(v[2] for v in per_kernel.values()) / reps / (fwd_ms * 1e-3) / 1e9, 1),
+                "hbm_frac": round(sum(v[2] for v in per_kernel.values()) / reps / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
             "roofline": roof,
             "attention_kernel": None if att is None else {
                 "tflops": round(att[1] / (att[0] * 1e-3) / 1e12, 2), "ms_per_step": round(att[0] / reps, 4),
