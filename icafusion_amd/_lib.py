@@ -29,6 +29,11 @@ class ConvArgs(C.Structure):
     ]
 
 
+class BneckArgs(C.Structure):
+    _fields_ = [("conv", ConvArgs), ("w1", C.c_void_p), ("bias1", C.c_void_p), ("w1_gs", C.c_longlong),
+                ("bias1_gs", C.c_longlong), ("Kp1", C.c_int), ("shape", C.c_int)]
+
+
 _p, _i, _ll, _f, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 # symbol -> (restype, argtypes); must list every function declared in include/icaf.h
 SIGNATURES = {
@@ -38,6 +43,7 @@ SIGNATURES = {
     "icaf_preprocess_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_preprocess_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_conv2d": (_i, [C.POINTER(ConvArgs), _p]),
+    "icaf_bottleneck": (_i, [C.POINTER(BneckArgs), _p]),
     "icaf_conv2d_kernel_name": (_i, [C.POINTER(ConvArgs), C.c_char_p, _i]),
     "icaf_sppf_pool": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_upsample_nearest": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -14,6 +14,8 @@ struct ConvP {
     unsigned int x_bytes, w_bytes;      // buffer-descriptor ranges (DMA pipeline); 0 = not representable
     float alpha_acc[2], alpha_res[2];
     const float* pre; int pre_h, pre_w, ldpre;     // optional pre-activation bilinear term (icaf.h)
+    const void* w1; const float* bias1;            // fused Bottleneck (ctile.hip, FUSE1): the 1x1 convolution in front
+    long long w1_gs, bias1_gs; int Kp1; unsigned int w1_bytes;
 };
 
 constexpr int ROWB = 64;        // bytes of K per LDS row per slice

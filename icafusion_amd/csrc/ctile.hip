@@ -27,9 +27,15 @@ template <int S, int TW> struct HaloGeom {
     static constexpr int PITCH = TW == 16 ? ((S == 2 ? 2 * HALF : HWD) + 15) / 16 * 16 : (S == 2 ? 2 * HALF : HWD);
 };
 
-template <int DT, int TH, int TW, int BN, int ACT, int S>
-__global__ __launch_bounds__(NTHREADS) void ctile_kernel(const ConvP p, const int lsp, const int lcin, const int tiles_x,
-                                                         const int tiles_per_img, const int halo_bytes) {
+// FUSE1 = true turns the kernel into a whole Bottleneck (reference models/common.py:184-194):
+//   y = x + SiLU(conv3x3(SiLU(conv1x1(x))))        (c_ -> c_ -> c_ channels, c_ = BN = 32 or 64)
+// The 1x1 convolution is evaluated on the halo patch itself (one extra MFMA stage, its c_ x c_ weights are a single
+// 128-byte slice), its SiLU output is written — zeroed outside the image, which is the 3x3's zero padding — as a second
+// LDS patch in the same swizzled layout, and the unchanged 3x3 loop reads that patch.  The intermediate tensor of the
+// two-launch form (written and re-read at full resolution) never exists; the residual is the epilogue's `res` = x.
+template <int DT, int TH, int TW, int BN, int ACT, int S, bool FUSE1>
+__device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const int lcin, const int tiles_x,
+                                           const int tiles_per_img, const int halo_bytes) {
     using E = Elem<DT>;
     using G = HaloGeom<S, TW>;
     constexpr int VEC = E::VEC;
@@ -44,8 +50,10 @@ __global__ __launch_bounds__(NTHREADS) void ctile_kernel(const ConvP p, const in
     constexpr int WSTAGE = BN * RB;
     static_assert(TM >= 1 && (TW == 32 || TW == 16) && BM % 128 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    unsigned char* halo = lds;
-    unsigned char* ring = lds + halo_bytes;
+    unsigned char* xpatch = lds;                                   // input halo patch
+    unsigned char* halo = FUSE1 ? lds + halo_bytes : lds;          // the patch the 3x3 loop reads
+    unsigned char* w1buf = lds + 2 * halo_bytes;                   // FUSE1: the 1x1 weights, BN rows x 128 bytes
+    unsigned char* ring = FUSE1 ? w1buf + BN * RB : lds + halo_bytes;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(NTHREADS) void ctile_kernel(const ConvP p, const in
             const int gy = gy0 + hy, gx = gx0 + hx;
             const bool ok = hy < HH && hx < HWD && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             const unsigned voff = ok ? img_off + (unsigned)((gy * p.W + gx) * p.ldx) * E::BYTES + (unsigned)(cs << 4) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(halo + (j << 10)), 16, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(xpatch + (j << 10)), 16, voff, 0, 0, 0);
         }
     }
 
@@ -119,11 +127,70 @@ __global__ __launch_bounds__(NTHREADS) void ctile_kernel(const ConvP p, const in
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) foff[s] = l31 * RB + (((2 * s + hi) ^ fkey) << 4);
 
+    const int gsh = 4 - lsp, smask = SP - 1;
+    const int cin_slots_mask = smask;                                  // Cin * BYTES / 16 - 1
+    if constexpr (FUSE1) {
+        static_assert(DT != ICAF_F32 && S == 1, "the fused Bottleneck exists for the 16-bit types, stride 1");
+        // ---- 1x1 convolution + SiLU over every entry of the halo patch -> second patch --------------------------------
+        const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const typename E::type*)p.w1 + g * p.w1_gs), 0, p.w1_bytes, 0x00020000);
+        const unsigned w1_off0 = ((unsigned)(wave * 8 + rsub) * (unsigned)p.Kp1 + (unsigned)(lslot * VEC)) * E::BYTES;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w1r, (lds_ptr_t)(w1buf + (wave + 4 * i) * 1024), 16,
+                                                     w1_off0 + (unsigned)(32 * i) * (unsigned)p.Kp1 * E::BYTES, 0, 0, 0);
+        wait_vmcnt<0>();
+        __syncthreads();                                               // input patch + 1x1 weights visible
+        const float* __restrict__ bias1 = p.bias1 ? p.bias1 + g * p.bias1_gs : nullptr;
+        const int nidx = HH * PITCH, nsub = (nidx + 31) >> 5;
+        const int gy0 = y0 - 1, gx0 = x0 - 1;
+        for (int j = wave; j < nsub; j += 4) {
+            f32x16 a1[TN];
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1[a][r] = 0.0f;
+            const int idx = (j << 5) + l31;
+#pragma unroll
+            for (int s = 0; s < BN / KSTEP; ++s) {                     // K = c_ input channels
+                const int slot = (idx << lsp) + (((2 * s + hi) ^ (idx >> gsh)) & cin_slots_mask);
+                const u32x4 fpx = *(const u32x4*)(xpatch + (slot << 4));
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    const u32x4 fw1 = *(const u32x4*)(w1buf + (a * 32) * RB + foff[s]);
+                    mma_step<DT>(a1[a], fw1, fpx);
+                }
+            }
+            const int hy = idx / PITCH, hx = idx - hy * PITCH;
+            const int gy = gy0 + hy, gx = gx0 + hx;
+            const bool inside = hy < HH && hx < HWD && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            if (idx < nidx) {
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int nl = a * 32 + 8 * q + 4 * hi;        // channel of this register quad
+                        float v[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (inside) {
+                            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                            if (bias1) bv = *(const f32x4*)(bias1 + nl);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = silu_f(a1[a][4 * q + e] + bv[e]);
+                        }
+                        u32x2 pk;
+                        if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
+                        else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
+                        const int slot = (idx << lsp) + (((nl >> 3) ^ (idx >> gsh)) & cin_slots_mask);
+                        *(u32x2*)(halo + (slot << 4) + ((nl & 7) << 1)) = pk;
+                    }
+            }
+        }
+        // (the first barrier of the 3x3 loop below makes the second patch visible)
+    }
+
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue_w(s, s);
 
-    const int gsh = 4 - lsp, smask = SP - 1;
-    const int cin_slots_mask = smask;                                  // Cin * BYTES / 16 - 1
     for (int c = 0; c < p.nchunks; ++c) {
         wait_vmcnt<(NS - 2) * NBW>();              // slice c (and, for c = 0, the halo patch issued before it) landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -165,6 +232,18 @@ __global__ __launch_bounds__(NTHREADS) void ctile_kernel(const ConvP p, const in
     }, 0);
 }
 
+template <int DT, int TH, int TW, int BN, int ACT, int S>
+__global__ __launch_bounds__(NTHREADS) void ctile_kernel(const ConvP p, const int lsp, const int lcin, const int tiles_x,
+                                                         const int tiles_per_img, const int halo_bytes) {
+    ctile_body<DT, TH, TW, BN, ACT, S, false>(p, lsp, lcin, tiles_x, tiles_per_img, halo_bytes);
+}
+
+template <int DT, int TH, int TW, int BN, int ACT>
+__global__ __launch_bounds__(NTHREADS) void bneck_kernel(const ConvP p, const int lsp, const int lcin, const int tiles_x,
+                                                         const int tiles_per_img, const int halo_bytes) {
+    ctile_body<DT, TH, TW, BN, ACT, 1, true>(p, lsp, lcin, tiles_x, tiles_per_img, halo_bytes);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -195,7 +274,7 @@ int ctile_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     return ICAF_OK;
 }
 
-template <int DT, int TH, int TW, int BN, int S>
+template <int DT, int TH, int TW, int BN, int S, bool FUSE1 = false>
 static int launch_ctile_cfg(const ConvP& p, int groups, hipStream_t s) {
     using G = HaloGeom<S, TW>;
     constexpr int EB = Elem<DT>::BYTES;
@@ -207,14 +286,16 @@ static int launch_ctile_cfg(const ConvP& p, int groups, hipStream_t s) {
     const int halo_bytes = ((nslots + 63) / 64) * 1024;
     const int ring = 3 * BN * 128;
     const int stage_out = BM * (BN * EB + 16);
-    int lds = halo_bytes + ring;
+    int lds = (FUSE1 ? 2 * halo_bytes + BN * 128 : halo_bytes) + ring;
     if (lds < stage_out) lds = stage_out;
     if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "ctile: %d bytes of LDS needed", lds);
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
     q.mtiles = p.B * tiles_x * tiles_y;
     q.ntiles = 1;
     q.nchunks = (p.K + 128 / EB - 1) / (128 / EB);
-    auto kern = ctile_kernel<DT, TH, TW, BN, ICAF_ACT_SILU, S>;
+    void (*kern)(const ConvP, const int, const int, const int, const int, const int);
+    if constexpr (FUSE1) kern = bneck_kernel<DT, TH, TW, BN, ICAF_ACT_SILU>;
+    else kern = ctile_kernel<DT, TH, TW, BN, ICAF_ACT_SILU, S>;
     static int attr_bytes = 0;                        // per instantiation: largest dynamic LDS size enabled so far
     if (lds > 64 * 1024 && lds > attr_bytes) {
         ICAF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -235,6 +316,23 @@ static int launch_ctile_dt(const ConvP& p, int groups, int shape, hipStream_t s)
         case 5: return launch_ctile_cfg<DT, 8, 16, 128, 1>(p, groups, s);
         default: return fail(ICAF_ERR_ARG, "ctile: unknown shape %d", shape);
     }
+}
+
+// Fused Bottleneck: shape 1 (8x32 patch, c_ = 32), 2 (8x32, c_ = 64) or 3 (8x16, c_ = 64)
+int launch_bneck(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s) {
+    int st = ctile_check(a, p, shape);
+    if (st) return st;
+    if (a->dtype == ICAF_F32) return fail(ICAF_ERR_UNSUPPORTED, "icaf_bottleneck: 16-bit types only");
+    if (a->Cin != a->Cout || (a->Cin != 32 && a->Cin != 64) || kShapes[shape - 1].bn != a->Cout || kShapes[shape - 1].s != 1)
+        return fail(ICAF_ERR_UNSUPPORTED, "icaf_bottleneck: c_ = %d -> %d with patch shape %d is not built (c_ in {32, 64})", a->Cin, a->Cout, shape);
+    if (a->dtype == ICAF_BF16) {
+        if (shape == 1) return launch_ctile_cfg<ICAF_BF16, 8, 32, 32, 1, true>(p, a->groups, s);
+        if (shape == 2) return launch_ctile_cfg<ICAF_BF16, 8, 32, 64, 1, true>(p, a->groups, s);
+        return launch_ctile_cfg<ICAF_BF16, 8, 16, 64, 1, true>(p, a->groups, s);
+    }
+    if (shape == 1) return launch_ctile_cfg<ICAF_F16, 8, 32, 32, 1, true>(p, a->groups, s);
+    if (shape == 2) return launch_ctile_cfg<ICAF_F16, 8, 32, 64, 1, true>(p, a->groups, s);
+    return launch_ctile_cfg<ICAF_F16, 8, 16, 64, 1, true>(p, a->groups, s);
 }
 
 int launch_ctile(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s) {

@@ -347,6 +347,7 @@ static const TileCfg kTiles[] = {{1, 128, 128, "128x128"}, {2, 128, 64, "128x64"
 // ctile.hip
 int ctile_check(const icaf_conv_args* a, const ConvP& p, int shape);
 int launch_ctile(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
+int launch_bneck(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
 const char* ctile_tag(int shape);
 
 //   40 + shape: 3x3 direct convolution from an LDS halo tile (ctile.hip); an explicit request that the layer cannot
@@ -530,6 +531,7 @@ static void fill(const icaf_conv_args* a, ConvP& p) {
     else { p.x_bytes = 0; p.w_bytes = 0; }
     for (int i = 0; i < 2; ++i) { p.alpha_acc[i] = a->alpha_acc[i]; p.alpha_res[i] = a->alpha_res[i]; }
     p.pre = a->pre; p.pre_h = a->pre_h; p.pre_w = a->pre_w; p.ldpre = a->ldpre;
+    p.w1 = nullptr; p.bias1 = nullptr; p.w1_gs = p.bias1_gs = 0; p.Kp1 = 0; p.w1_bytes = 0;
 }
 
 }  // namespace icaf
@@ -551,6 +553,22 @@ extern "C" int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s) {
         return a->out_dtype == ICAF_F32 ? launch_tile<ICAF_F16, ICAF_F32>(p, a->groups, tile, hs)
                                         : launch_tile<ICAF_F16, ICAF_F16>(p, a->groups, tile, hs);
     return launch_tile<ICAF_F32, ICAF_F32>(p, a->groups, tile, hs);
+}
+
+extern "C" int icaf_bottleneck(const icaf_bneck_args* b, icaf_stream_t s) {
+    if (!b || !b->w1) return fail(ICAF_ERR_ARG, "icaf_bottleneck: null pointer");
+    const icaf_conv_args* a = &b->conv;
+    int st = validate(a);
+    if (st) return st;
+    const int eb = a->dtype == ICAF_F32 ? 4 : 2;
+    if (b->Kp1 * eb != 128) return fail(ICAF_ERR_ARG, "icaf_bottleneck: the packed 1x1 weights must have 128-byte rows (Kp1 = %d)", b->Kp1);
+    if (a->pre) return fail(ICAF_ERR_ARG, "icaf_bottleneck: no pre-activation term");
+    if (a->x == a->y) return fail(ICAF_ERR_ARG, "icaf_bottleneck: in-place operation is not possible (neighbouring patches read x)");
+    ConvP p;
+    fill(a, p);
+    p.w1 = b->w1; p.bias1 = b->bias1; p.w1_gs = b->w1_gs; p.bias1_gs = b->bias1_gs; p.Kp1 = b->Kp1;
+    p.w1_bytes = (unsigned)((((long long)a->Cout + 127) / 128 * 128) * b->Kp1 * eb);
+    return launch_bneck(a, p, b->shape, S(s));
 }
 
 extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int buf_len) {

@@ -141,7 +141,7 @@ class Conv(HipModule):
             b = (b - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
         return w, b
 
-    def emit(self, plan, x, out=None, res=None, twin=None, also=(), twin_also=(), pre_term=None):
+    def emit(self, plan, x, out=None, res=None, twin=None, also=(), twin_also=(), pre_term=None, swap_halves=False):
         """Append this layer's launch.
 
         twin: the structurally identical Conv of the other backbone stream — x / out / res are then pair acts
@@ -149,7 +149,9 @@ class Conv(HipModule):
         also: further Convs with the same geometry and activation reading the same input (C3's cv1 and cv2): their
               output channels are appended to this layer's, one GEMM with N = sum of the widths (twin_also: the
               twin stream's counterparts).
-        pre_term: fp32 coarse map (B, h, w, Cout) added, bilinearly resized, before bias + activation (icaf.h)."""
+        pre_term: fp32 coarse map (B, h, w, Cout) added, bilinearly resized, before bias + activation (icaf.h).
+        swap_halves: the input view holds the two halves of the layer's input channels in swapped order (C3 after an
+              odd number of fused Bottlenecks): the weight columns are swapped to match when they are packed."""
         if self.conv.groups != 1 or self.conv.dilation != (1, 1):
             raise NotImplementedError("grouped / dilated convolutions are outside the hot path")
         kh, kw = self.conv.kernel_size
@@ -170,13 +172,16 @@ class Conv(HipModule):
             if paired:
                 rows.append((twin,) + tuple(twin_also))
             return rows
-        key_tail = (plan.dtype, plan.device, id(twin), tuple(id(e) for e in also))
+        key_tail = (plan.dtype, plan.device, id(twin), tuple(id(e) for e in also), bool(swap_halves))
 
         def pack(transform, cin_pad):
             packs = []
             for convs in streams():
                 ws, bs = zip(*(c.folded() for c in convs))
                 w, b = torch.cat(ws), torch.cat(bs)
+                if swap_halves:
+                    h = w.shape[1] // 2
+                    w = torch.cat((w[:, h:], w[:, :h]), 1)
                 wp, kp = ops.pack_conv_weight(transform(w), plan.dtype, cin_pad)
                 packs.append((wp, kp, ops.pack_bias(b, c2)))
             if not paired:
@@ -235,6 +240,39 @@ class Bottleneck(HipModule):
         return self.cv2.emit(plan, t, out=out, res=x if self.add else None,
                              twin=twin.cv2 if twin is not None else None)
 
+    fuse = True      # use the one-launch kernel (icaf_bottleneck) where it is built and measured faster
+    fuse_widths = (32,)
+
+    def fusable(self, plan, x):
+        """One-launch form: built for c_ in {32, 64} (16-bit types, 1x1 then 3x3 / s1 / p1, SiLU); USED for c_ = 32 on wide
+        maps only: measured on MI355X (both streams, batch 32) 174 us against 73 + 112 us at 160x160 / c_ = 32, but
+        155 us against 30 + 62 us at 80x80 / c_ = 64, where two LDS patches leave room for one workgroup per CU."""
+        a, b = self.cv1.conv, self.cv2.conv
+        c = a.in_channels
+        return (self.fuse and plan.dtype in (torch.bfloat16, torch.float16) and c in self.fuse_widths
+                and a.out_channels == c and b.in_channels == c and b.out_channels == c
+                and a.kernel_size == (1, 1) and a.stride == (1, 1) and _pair(a.padding) == (0, 0)
+                and b.kernel_size == (3, 3) and b.stride == (1, 1) and _pair(b.padding) == (1, 1)
+                and a.groups == 1 and b.groups == 1 and isinstance(self.cv1.act, nn.SiLU) and isinstance(self.cv2.act, nn.SiLU)
+                and x.shape[-2] >= 64)
+
+    def emit_fused(self, plan, x, out, twin=None):
+        """y = [x +] SiLU(conv3x3(SiLU(conv1x1(x)))) as ONE launch; `out` must be a different buffer (slice) than x."""
+        c = self.cv1.conv.in_channels
+        paired = twin is not None
+        mods = [self] + ([twin] if paired else [])
+
+        def make():
+            p1 = [ops.pack_conv_weight(m.cv1.folded()[0], plan.dtype) for m in mods]
+            p2 = [ops.pack_conv_weight(m.cv2.folded()[0], plan.dtype) for m in mods]
+            b1 = [ops.pack_bias(m.cv1.folded()[1], c) for m in mods]
+            b2 = [ops.pack_bias(m.cv2.folded()[1], c) for m in mods]
+            st = (lambda ts: torch.stack(ts).contiguous()) if paired else (lambda ts: ts[0])
+            return st([p[0] for p in p1]), p1[0][1], st(b1), st([p[0] for p in p2]), p2[0][1], st(b2)
+        w1, kp1, b1, w2, kp2, b2 = self._cached(("bneck", plan.dtype, plan.device, id(twin)), make)
+        plan.add(ops.bottleneck(x, w1, kp1, b1, w2, kp2, b2, out, c, self.add, 1 if c == 32 else 2))
+        return out
+
 
 class C3(HipModule):
     """CSP bottleneck with three convs (reference models/common.py:216-227).  cv1 and cv2 read the same input, so they
@@ -253,13 +291,23 @@ class C3(HipModule):
         B, H, W = x.shape[-4:-1]
         c_ = self.cv1.conv.out_channels
         paired = twin is not None
-        cat = plan.act(B, H, W, 2 * c_, pair=paired)
-        self.cv1.emit(plan, x, out=cat, twin=twin.cv1 if paired else None, also=(self.cv2,),
+        fused = [blk.fusable(plan, x) for blk in self.m]
+        # Buffer of three c_-wide slots [a | b | a']: cv1|cv2 write [a | b]; a fused Bottleneck cannot run in place (its
+        # neighbours' patches read x), so the chain ping-pongs between slot 0 and slot 2; cv3 then reads [a | b] or
+        # [b | a'] — in the second case with its weight columns swapped to match.
+        cat = plan.act(B, H, W, (3 if any(fused) else 2) * c_, pair=paired)
+        self.cv1.emit(plan, x, out=cat[..., :2 * c_], twin=twin.cv1 if paired else None, also=(self.cv2,),
                       twin_also=(twin.cv2,) if paired else ())
-        a = cat[..., :c_]
+        cur = 0
         for j, blk in enumerate(self.m):
-            blk.emit(plan, a, out=a, twin=twin.m[j] if paired else None)
-        return self.cv3.emit(plan, cat, out=out, twin=twin.cv3 if paired else None)
+            a = cat[..., cur * c_:(cur + 1) * c_]
+            if fused[j]:
+                cur = 2 - cur
+                blk.emit_fused(plan, a, cat[..., cur * c_:(cur + 1) * c_], twin=twin.m[j] if paired else None)
+            else:
+                blk.emit(plan, a, out=a, twin=twin.m[j] if paired else None)
+        src = cat[..., :2 * c_] if cur == 0 else cat[..., c_:3 * c_]
+        return self.cv3.emit(plan, src, out=out, twin=twin.cv3 if paired else None, swap_halves=cur != 0)
 
 
 class SPPF(HipModule):

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvArgs, check, lib, F32, BF16, F16, ACT_NONE, ACT_SILU, ACT_GELU  # noqa: F401
+from ._lib import BneckArgs, ConvArgs, check, lib, F32, BF16, F16, ACT_NONE, ACT_SILU, ACT_GELU  # noqa: F401
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 VEC = {torch.float32: 4, torch.bfloat16: 8, torch.float16: 8}     # elements per 16-byte vector
@@ -153,6 +153,25 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
     nbytes = groups * (B * H * W * cin * es + cout * kh * kw * cin * es + m * cout * eo
                        + (m * cout * es if res is not None else 0))
     return Launch(lib().icaf_conv2d, (C.byref(a),), keep=(a, x, w_packed, bias, y, res, pre), name=name, flops=flops,
+                  nbytes=nbytes)
+
+
+def bottleneck(x, w1_packed, kp1, bias1, w2_packed, kp2, bias2, y, c, add, shape, name="bottleneck"):
+    """Whole Bottleneck (1x1 -> 3x3 [+ x]) in one launch (icaf_bottleneck).  x, y: acts or pair acts of c channels in
+    DIFFERENT buffers; w1 / w2: packed 1x1 / 3x3 weights (stacked per stream for pair acts)."""
+    inner = conv2d(x, w2_packed, kp2, bias2, y, 3, 3, 1, 1, 1, 1, c, c, ACT_SILU, res=x if add else None, name=name)
+    b = BneckArgs()
+    C.memmove(C.byref(b.conv), C.byref(inner.keep[0]), C.sizeof(ConvArgs))
+    b.w1, b.bias1 = w1_packed.data_ptr(), bias1.data_ptr()
+    paired = x.dim() == 5
+    b.w1_gs, b.bias1_gs = (w1_packed.stride(0), bias1.stride(0)) if paired else (0, 0)
+    b.Kp1, b.shape = kp1, shape
+    B, H, W, _, _ = _act_geom(x)
+    g = 2 if paired else 1
+    flops = inner.flops + 2.0 * g * B * H * W * c * c
+    es = x.element_size()
+    nbytes = g * (B * H * W * c * es * (3 if add else 2) + (9 * c * c + c * c) * es)
+    return Launch(lib().icaf_bottleneck, (C.byref(b),), keep=(b, inner.keep, w1_packed, bias1), name=name, flops=flops,
                   nbytes=nbytes)
 
 

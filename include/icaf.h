@@ -96,6 +96,21 @@ typedef struct icaf_conv_args {
 } icaf_conv_args;
 
 int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s);
+
+/* Whole Bottleneck in one launch (models/common.py:184-194): y = [x +] SiLU(conv3x3(SiLU(conv1x1(x)))) for c_ -> c_ -> c_
+ * channels with c_ in {32, 64}, 16-bit types.  `conv` describes the 3x3 / stride 1 / pad 1 layer (x = block input,
+ * w / bias = its packed weights, y = block output — a DIFFERENT buffer than x —, res = x for the shortcut or NULL);
+ * w1 / bias1 are the packed 1x1 weights ([Np][Kp1], Kp1 = 128 bytes) applied first.  The 1x1 output never reaches HBM.
+ * shape: LDS patch 1 = 8x32 pixels (c_ = 32), 2 = 8x32 (c_ = 64), 3 = 8x16 (c_ = 64). */
+typedef struct icaf_bneck_args {
+    icaf_conv_args conv;
+    const void* w1;
+    const float* bias1;
+    long long w1_gs, bias1_gs; /* per-group strides (elements / floats) */
+    int Kp1;
+    int shape;
+} icaf_bneck_args;
+int icaf_bottleneck(const icaf_bneck_args* a, icaf_stream_t s);
 /* name of the kernel instantiation icaf_conv2d would launch for these args (host string, for profiling) */
 int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int buf_len);
 

@@ -166,6 +166,47 @@ def test_conv3x3_halo_tile_kernel(case, dt):
     assert torch.equal(outs[0], outs[1]), "halo-tile kernel and implicit GEMM must agree bit for bit"
 
 
+BNECK_CASES = [
+    # B, H, W, c, add, patch shape, paired streams
+    (2, 40, 70, 32, True, 1, False),
+    (1, 37, 45, 32, False, 1, True),
+    (2, 24, 64, 64, True, 2, True),
+    (1, 19, 33, 64, True, 3, False),
+    (2, 40, 40, 64, False, 3, True),
+]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", BNECK_CASES)
+def test_fused_bottleneck_equals_two_launches(case, dt):
+    """icaf_bottleneck (1x1 on the LDS halo patch -> 3x3 -> + x, one launch) vs the same two layers as separate
+    implicit-GEMM launches: bit-identical (same K order, same rounding points), and close to fp32 torch."""
+    B, H, W, c, add, shape, paired = case
+    G = 2 if paired else 1
+    xs = [rnd((B, c, H, W), 41 + g) for g in range(G)]
+    w1 = [rnd((c, c, 1, 1), 43 + g, 1.0 / math.sqrt(c)) for g in range(G)]
+    w2 = [rnd((c, c, 3, 3), 45 + g, 1.0 / math.sqrt(9 * c)) for g in range(G)]
+    b1 = [rnd((c,), 47 + g, 0.2) for g in range(G)]
+    b2 = [rnd((c,), 49 + g, 0.2) for g in range(G)]
+
+    def stack(ts):
+        return torch.stack(ts).contiguous() if paired else ts[0]
+    xa = stack([to_act(x, dt) for x in xs])
+    p1 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w1]
+    p2 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w2]
+    w1p, w2p = stack([p[0] for p in p1]), stack([p[0] for p in p2])
+    b1p, b2p = stack([ops.pack_bias(b.to(DEV), c) for b in b1]), stack([ops.pack_bias(b.to(DEV), c) for b in b2])
+    y_f, y_u, t = torch.zeros_like(xa), torch.zeros_like(xa), torch.zeros_like(xa)
+    run(ops.bottleneck(xa, w1p, p1[0][1], b1p, w2p, p2[0][1], b2p, y_f, c, add, shape))
+    run(ops.conv2d(xa, w1p, p1[0][1], b1p, t, 1, 1, 1, 1, 0, 0, c, c, ops.ACT_SILU))
+    run(ops.conv2d(t, w2p, p2[0][1], b2p, y_u, 3, 3, 1, 1, 1, 1, c, c, ops.ACT_SILU, res=xa if add else None))
+    assert torch.equal(y_f, y_u), "fused Bottleneck must match the two-launch form bit for bit"
+    for g in range(G):
+        tt = q(F.silu(F.conv2d(q(xs[g], dt), q(w1[g], dt), b1[g])), dt)
+        ref = F.silu(F.conv2d(tt, q(w2[g], dt), b2[g], 1, 1)) + (q(xs[g], dt) if add else 0)
+        close(from_act(y_f[g] if paired else y_f), ref, dt, f"bottleneck {case} stream {g}")
+
+
 def test_conv3x3_halo_tile_rejects_other_layers():
     x = torch.zeros((1, 8, 8, 32), dtype=torch.bfloat16, device=DEV)
     w = rnd((32, 32, 1, 1), 1)

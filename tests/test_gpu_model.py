@@ -148,6 +148,27 @@ def test_fused_dmff_tail_matches_materialised_tail():
     assert err < 1e-5, err
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_bottleneck_model_matches_two_launch_model(dtype):
+    """Fused Bottlenecks (one launch, 3-slot C3 buffer, swapped cv3 columns) vs the two-launch form: the Bottlenecks are
+    bit-identical, cv3 then sums its K in a different order, so outputs agree to 16-bit rounding noise."""
+    from icafusion_amd.models.common import Bottleneck
+    cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", 7, dtype)
+    rgb, ir = synth_images(2, 640, 640, seed=7)
+    outs = []
+    Bottleneck.fuse_widths = (32, 64)            # exercise every built width, not only the one the plan uses by default
+    for fuse in (True, False):
+        Bottleneck.fuse = fuse
+        m.invalidate()
+        names = [l.name for l in m.plan_for(2, 640, 640).launches]
+        assert ("bottleneck" in names) == fuse
+        outs.append(m(rgb.cuda(), ir.cuda())[0].float())
+    Bottleneck.fuse, Bottleneck.fuse_widths = True, (32,)
+    scale = outs[1][..., :4].abs().max().item()
+    assert (outs[0][..., :4] - outs[1][..., :4]).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 3e-3) * scale
+    assert (outs[0][..., 4:] - outs[1][..., 4:]).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 3e-3)
+
+
 def test_graph_replay_equals_eager():
     cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", seed=1, dtype=torch.bfloat16)
     rgb, ir = synth_images(2, 320, 320, seed=1)
