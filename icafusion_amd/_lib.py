@@ -42,6 +42,7 @@ SIGNATURES = {
     "icaf_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "icaf_preprocess_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_preprocess_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "icaf_stem": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _p]),
     "icaf_conv2d": (_i, [C.POINTER(ConvArgs), _p]),
     "icaf_bottleneck": (_i, [C.POINTER(BneckArgs), _p]),
     "icaf_conv2d_kernel_name": (_i, [C.POINTER(ConvArgs), C.c_char_p, _i]),

@@ -136,9 +136,10 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
             (void*)((const typename E::type*)p.w1 + g * p.w1_gs), 0, p.w1_bytes, 0x00020000);
         const unsigned w1_off0 = ((unsigned)(wave * 8 + rsub) * (unsigned)p.Kp1 + (unsigned)(lslot * VEC)) * E::BYTES;
 #pragma unroll
-        for (int i = 0; i < NBW; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w1r, (lds_ptr_t)(w1buf + (wave + 4 * i) * 1024), 16,
-                                                     w1_off0 + (unsigned)(32 * i) * (unsigned)p.Kp1 * E::BYTES, 0, 0, 0);
+        for (int i = 0; i < NBW; ++i) {
+            const unsigned voff = w1_off0 + (unsigned)(32 * i) * (unsigned)p.Kp1 * E::BYTES;     // (keep it a variable, see stem.hip)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w1r, (lds_ptr_t)(w1buf + (wave + 4 * i) * 1024), 16, voff, 0, 0, 0);
+        }
         wait_vmcnt<0>();
         __syncthreads();                                               // input patch + 1x1 weights visible
         const float* __restrict__ bias1 = p.bias1 ? p.bias1 + g * p.bias1_gs : nullptr;

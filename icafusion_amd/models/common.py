@@ -118,6 +118,8 @@ class Conv(HipModule):
         self.bn = nn.BatchNorm2d(c2)
         self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
 
+    fuse_stem = True     # image-fed 6x6/s2 layers: staging + convolution as one persistent kernel (16-bit types)
+
     def fuseforward(self, x):           # kept for API parity with Model.fuse(); same device path
         return self.forward(x)
 
@@ -193,6 +195,14 @@ class Conv(HipModule):
             assert x.pair == paired
             B, _, H, W = x.shape
             s2d = (kh, kw, sh, sw, ph, pw) == (6, 6, 2, 2, 2, 2) and H % 2 == 0 and W % 2 == 0
+            if (s2d and self.fuse_stem and plan.dtype in (torch.bfloat16, torch.float16) and c1 == 3 and c2 in (32, 64)
+                    and not also and res is None and (not x.u8 or (paired and x.c0 == 0))):
+                # staging + convolution in one persistent kernel reading the NCHW image itself (stem.hip)
+                wp, kp, bp = self._cached(("s2d",) + key_tail, lambda: pack(ops.s2d_conv_weight, 16))
+                if out is None:
+                    out = plan.act(B, H // 2, W // 2, c2, pair=paired)
+                plan.add(ops.stem(x.t, wp, kp, bp, out, c2))
+                return out
             if s2d:                       # 6x6/s2/p2 over the image == 3x3/s1/p1 over space-to-depth(image)
                 cpad = -(-4 * c1 // vec) * vec
                 pre = plan.act(B, H // 2, W // 2, cpad, pair=paired)

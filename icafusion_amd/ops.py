@@ -279,6 +279,31 @@ def preprocess_u8(img, out, mode, c0=0, name="preprocess_u8"):
                                              H, W, cpad, mode), keep=(img, out), name=name, nbytes=nb)
 
 
+def stem(img, w_packed, kp, bias, y, cout, name="stem"):
+    """Staging + 6x6/s2/p2 stem conv in one persistent kernel (icaf_stem).  img: fp32 (B, 3, H, W) / (2, B, 3, H, W)
+    [both streams], or uint8 (B, 6, H, W) [both streams]; y: act or pair act of cout channels at half resolution."""
+    u8 = img.dtype == torch.uint8
+    paired = y.dim() == 5
+    assert img.is_contiguous() and (u8 or img.dtype == torch.float32)
+    if u8:
+        assert img.dim() == 4 and paired and img.shape[1] >= 6
+        B, ctot, H, W = img.shape
+    else:
+        assert img.dim() == (5 if paired else 4)
+        B, _, H, W = img.shape[-4:]
+        ctot = 3
+    By, Ho, Wo, cy, ldy = _act_geom(y)
+    assert (By, Ho, Wo) == (B, H // 2, W // 2) and cy >= cout and w_packed.dtype == y.dtype
+    g = 2 if paired else 1
+    nb = g * B * 3 * H * W * (1 if u8 else 4) + g * B * Ho * Wo * cout * y.element_size()
+    flops = 2.0 * g * B * Ho * Wo * cout * 144
+    return Launch(lib().icaf_stem, (img.data_ptr(), int(u8), ctot, w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), ldy,
+                                    dtype_code(y.dtype), g, B, H, W, cout, kp,
+                                    w_packed.stride(0) if paired else 0, bias.stride(0) if paired else 0,
+                                    y.stride(0) if paired else 0),
+                  keep=(img, w_packed, bias, y), name=name, flops=flops, nbytes=nb)
+
+
 def sppf_pool(x, y1, y2, y3, k, name="sppf_pool"):
     x, y1, y2, y3 = flat_pair(x), flat_pair(y1), flat_pair(y2), flat_pair(y3)
     B, H, W, Cc, ldx = _act_geom(x)

@@ -54,6 +54,15 @@ int icaf_preprocess_nchw(const float* img, void* out, int dtype, int B, int C, i
 int icaf_preprocess_u8(const unsigned char* img, void* out, int dtype, int B, int Ctot, int c0, int C, int nstreams,
                        int H, int W, int Cpad, int mode, icaf_stream_t s);
 
+/* Staging + stem convolution in one persistent kernel: the 6x6 / stride 2 / pad 2 Conv(+BN+SiLU) of yaml rows 0 and 10
+ * (models/common.py:48-60) computed straight from the NCHW images (fp32 [nstreams*B][3][H][W], or img_u8 != 0: the
+ * dataloader's uint8 [B][ctot][H][W] batch, stream s = channels [3s, 3s+3), value / 255) — no staged copy of the images
+ * is written.  w: packed space-to-depth weights [Np][192] per stream (icafusion_amd.ops.s2d_conv_weight), y: NHWC
+ * [nstreams][B][H/2][W/2][ldy]; *_gs = per-stream strides in elements / floats.  16-bit types, Cout in {32, 64}. */
+int icaf_stem(const void* img, int img_u8, int ctot, const void* w, const float* bias, void* y, int ldy, int dtype,
+              int nstreams, int B, int H, int W, int Cout, int Kp, long long w_gs, long long bias_gs, long long y_gs,
+              icaf_stream_t s);
+
 /* ---- implicit-GEMM convolution / linear ------------------------------------------------------------------
  * Replaces Conv.forward / fuseforward (models/common.py:48-60: SiLU(BN(Conv2d))) with BN folded into the
  * weights (utils/torch_utils.py:182-202), nn.Linear (+GELU) inside CrossAttention / CrossTransformerBlock

@@ -308,6 +308,39 @@ def test_preprocess_u8_matches_float_path(dt, mode):
     assert torch.equal(single, pair[1])
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 48, 96, 32, True, False), (1, 44, 72, 64, False, False), (2, 64, 128, 32, True, True),
+                                  (3, 36, 40, 64, True, True)])
+def test_persistent_stem_equals_staging_plus_conv(case, dt):
+    """icaf_stem (staging + 6x6/s2 conv in one persistent kernel, image read directly) vs icaf_preprocess_* followed by
+    the 3x3 space-to-depth convolution on the implicit-GEMM kernel: bit-identical."""
+    B, H, W, cout, paired, u8 = case
+    G = 2 if paired else 1
+    g = np.random.default_rng(61)
+    ws = [rnd((cout, 3, 6, 6), 62 + i, 1.0 / math.sqrt(108)) for i in range(G)]
+    bs = [rnd((cout,), 64 + i, 0.2) for i in range(G)]
+    packs = [ops.pack_conv_weight(ops.s2d_conv_weight(w.to(DEV)), dt, 16) for w in ws]
+    st = (lambda ts: torch.stack(ts).contiguous()) if paired else (lambda ts: ts[0])
+    wp, kp, bp = st([p_[0] for p_ in packs]), packs[0][1], st([ops.pack_bias(b.to(DEV), cout) for b in bs])
+    if u8:
+        img = torch.from_numpy(g.integers(0, 256, (B, 6, H, W), dtype=np.uint8)).to(DEV)
+    else:
+        img = torch.from_numpy(g.random((G, B, 3, H, W), dtype=np.float32)).to(DEV)
+        if not paired:
+            img = img[0].contiguous()
+    shape = (G, B, H // 2, W // 2) if paired else (B, H // 2, W // 2)
+    y_f = torch.zeros((*shape, cout), dtype=dt, device=DEV)
+    y_u = torch.zeros_like(y_f)
+    pre = torch.zeros((*shape, 16), dtype=dt, device=DEV)
+    run(ops.stem(img, wp, kp, bp, y_f, cout))
+    run(ops.preprocess_u8(img, pre, 1) if u8 else ops.preprocess(img, pre, 1))
+    run(ops.conv2d(pre, wp, kp, bp, y_u, 3, 3, 1, 1, 1, 1, 16, cout, ops.ACT_SILU))
+    assert torch.equal(y_f, y_u)
+    x0 = (img[:, :3].cpu().float() / 255.0) if u8 else (img[0] if paired else img).cpu()
+    ref = F.silu(F.conv2d(q(x0, dt), q(ws[0], dt), bs[0], 2, 2))
+    close(from_act(y_f[0] if paired else y_f), ref, dt, f"stem {case}")
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_sppf_upsample_copy(dt):
     x = rnd((2, 64, 20, 12), 11)
