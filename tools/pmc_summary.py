@@ -19,7 +19,7 @@ def short(name):
     """rocprof kernel name -> the name bench.py reports (igemm instantiations that differ only in the activation
     template argument are merged, as ops.conv_kernel_name does)."""
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"icaf::igemm_dma_kernel<(\d+), (\d+), (\d+), (\d+), \d+, \d+, \d+, (\d+), (\d+)(?:, \d+)?>", name)
+    m = re.match(r"icaf::igemm_dma_kernel<(\d+), (\d+), (\d+), (\d+), \d+, \d+, \d+, (\d+), (\d+)(?:, \w+)*>", name)
     if m:
         dt, odt, bm, bn, rb, ns = map(int, m.groups())
         return f"igemm_dma{rb}x{ns}_{_DN[dt]}_{_DN[odt]}_{bm}x{bn}"
@@ -35,7 +35,7 @@ def short(name):
     if m:
         return {"preprocess_kernel": "preprocess_s2d", "pool_tokens_kernel": "dmff_pool_tokens", "upsample_merge_kernel": "dmff_upsample_merge",
                 "cross_attn_kernel": "cross_attention", "detect_decode_kernel": "detect_decode", "sppf_lds_kernel": "sppf_pool",
-                "upsample_kernel": "upsample_nearest"}.get(m.group(1), m.group(1))
+                "upsample_kernel": "upsample_nearest", "stem_kernel": "stem", "bneck_kernel": "bottleneck"}.get(m.group(1), m.group(1))
     return name[:80]
 
 
