@@ -131,8 +131,13 @@ __global__ __launch_bounds__(NTHREADS) void stem_kernel(const StemP q) {
         wait_vmcnt<0>();
     };
 
-    int pt = blockIdx.x;
-    if (pt >= q.npatch) return;
+    // XCD-aware patch walk: workgroups are dispatched round-robin over the 8 XCDs, each with a private L2.  XCD x walks
+    // the x-th contiguous eighth of the patches, so patches that share halo rows / columns (and the 128-byte lines
+    // their 8-byte-misaligned rows straddle) meet in ONE L2 instead of being fetched from HBM once per XCD.
+    const int xcd = blockIdx.x & 7, per_xcd = (q.npatch + 7) >> 3, pstride = gridDim.x >> 3;
+    const int pend = min((xcd + 1) * per_xcd, q.npatch);
+    int pt = xcd * per_xcd + (blockIdx.x >> 3);
+    if (pt >= pend) return;
     float v0[12], v1[12];
     fetch(pt, v0, v1);
 
@@ -155,8 +160,8 @@ __global__ __launch_bounds__(NTHREADS) void stem_kernel(const StemP q) {
             load_weights(stream);
             wstream = stream;
         }
-        const int pn = pt + gridDim.x;
-        const bool more = pn < q.npatch;
+        const int pn = pt + pstride;
+        const bool more = pn < pend;
         if (more) fetch(pn, v0, v1);               // next patch's image reads stay in flight during the MFMAs below
         __syncthreads();                           // current patch (and weights) visible
         const unsigned char* patch = cur ? patch1 : patch0;
@@ -208,6 +213,7 @@ static int launch_stem(const StemP& q, hipStream_t s) {
     const int per_cu = (160 * 1024) / lds < 4 ? (160 * 1024) / lds : 4;
     int grid = cus * (per_cu < 1 ? 1 : per_cu);
     if (grid > q.npatch) grid = q.npatch;
+    grid = (grid + 7) & ~7;                         // the patch walk is per XCD (8 of them)
     static bool attr = false;
     if (lds > 64 * 1024 && !attr) {
         ICAF_HIP(hipFuncSetAttribute((const void*)stem_kernel<DT, BN, U8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
