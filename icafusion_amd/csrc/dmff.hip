@@ -249,30 +249,39 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const typename Elem<DT>
                 const u32x4 kf = *(const u32x4*)(Ks + (size_t)(kt * 32 + l31) * KS + st * 32 + hi * 16);
                 mma_step<DT>(s, kf, qf[st]);
             }
-            float tmax = -INFINITY;
+            // Softmax bookkeeping in the UNSCALED score domain (scale > 0, so the max commutes): p = exp2(s*c - m*c) is one
+            // FMA + one exp2 per score.  Only the last key tile can contain padding keys, and the running maximum stops
+            // moving after the first few tiles, so the -inf masking and the rescale of O sit behind wave-uniform branches.
+            if (kt == nqt - 1 && NP != N) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float v = key < N ? s[r] * scale_l2e : -INFINITY;
-                s[r] = v;
-                tmax = fmaxf(tmax, v);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    s[r] = key < N ? s[r] : -INFINITY;
+                }
             }
+            float tmax = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
             const float m_new = fmaxf(m, tmax);
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            const float mc = m_new * scale_l2e;
             float psum = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_l2e, -mc));
                 s[r] = pv;
                 psum += pv;
             }
-            l = l * alpha + psum;
-            m = m_new;
+            if (!__all(m_new == m)) {                  // rare after the first tiles: rescale the running sum and O
+                const float alpha = __builtin_amdgcn_exp2f((m - m_new) * scale_l2e);
+                l *= alpha;
 #pragma unroll
-            for (int td = 0; td < TD; ++td)
+                for (int td = 0; td < TD; ++td)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
+                m = m_new;
+            }
+            l += psum;
 #pragma unroll
             for (int st = 0; st < PSTEPS; ++st) {
                 const u32x4 pf = pack_p<DT>(s, st);

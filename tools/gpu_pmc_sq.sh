@@ -1,0 +1,30 @@
+#!/bin/bash
+# MFMA-pipe utilisation per kernel from the SQ counters (one pass): SQ_VALU_MFMA_BUSY_CYCLES counts busy cycles summed
+# over all SIMDs, SQ_BUSY_CYCLES the kernel's busy cycles summed over the 32 shader engines (MI355X_MICROARCH.md).
+#   util = MFMA_BUSY / (SQ_BUSY / 32 * 1024 SIMDs)
+mkdir -p gpurun_out
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/pmc_sq
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/pmc_sq -o pmc -- \
+    python $R/bench.py --no-cpu-baseline --no-graph --no-overlap --steps 3 --warmup 1 "$@" > $R/gpurun_out/pmc_sq.json 2> $R/gpurun_out/pmc_sq.err
+tail -2 $R/gpurun_out/pmc_sq.err
+cd $R && python - <<'PY'
+import csv, glob, collections, json, sys
+sys.path.insert(0, "tools")
+from pmc_summary import short
+f = glob.glob("gpurun_out/pmc_sq/**/*counter_collection.csv", recursive=True)[0]
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for r in csv.DictReader(open(f)):
+    k = short(r["Kernel_Name"]); acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Counter_Name"] == "SQ_BUSY_CYCLES": n[k] += 1
+out = {}
+for k, c in acc.items():
+    if k.startswith("at::") or k.startswith("__") or "rocprim" in k or not c["SQ_BUSY_CYCLES"]: continue
+    out[k] = {"dispatches": n[k], "mfma_util": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["SQ_BUSY_CYCLES"] / 32 * 1024), 4),
+              "wave_wait_frac": round(c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1), 3),
+              "wave_issue_stall_frac": round(c["SQ_WAIT_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1), 3),
+              "wave_active_frac": round(c["SQ_ACTIVE_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1), 3)}
+json.dump({"method": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY; mfma_util = MFMA_BUSY / (SQ_BUSY / 32 * 1024)", "kernels": out}, open("gpurun_out/pmc_sq_summary.json", "w"), indent=1, sort_keys=True)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_util"]): print(f"{k:42s} {v}")
+PY
