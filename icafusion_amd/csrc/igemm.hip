@@ -27,6 +27,7 @@
 #include "conv_common.h"
 
 static_assert(sizeof(icaf_conv_args) == 208, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
+static_assert(sizeof(icaf_bneck_args) == 248, "icaf_bneck_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
 
 namespace icaf {
 
