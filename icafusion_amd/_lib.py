@@ -49,6 +49,7 @@ SIGNATURES = {
     "icaf_sppf_pool": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_upsample_nearest": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_copy_channels": (_i, [_p, _i, _p, _i, _i, _ll, _i, _p]),
+    "icaf_axpby": (_i, [_p, _i, _p, _i, _p, _i, _i, _ll, _i, _f, _f, _p]),
     "icaf_dmff_pool_tokens": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                    _f, _f, _f, _f, _p]),
     "icaf_layernorm": (_i, [_p, _p, _p, _p, _p, _p, _i, _ll, _i, _i, _f, _p]),

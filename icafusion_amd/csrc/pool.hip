@@ -203,6 +203,25 @@ __global__ __launch_bounds__(256) void copy_kernel(const u32x4* __restrict__ x, 
     }
 }
 
+// ---- y = a * x0 + b * x1 over channel slices (Add fusion block, reference models/common.py:324-331) ----------------
+template <int DT>
+__global__ __launch_bounds__(256) void axpby_kernel(const typename Elem<DT>::type* __restrict__ x0, int ld0,
+                                                    const typename Elem<DT>::type* __restrict__ x1, int ld1,
+                                                    typename Elem<DT>::type* __restrict__ y, int ldy, long long rows, int nv, float a, float b) {
+    using E = Elem<DT>;
+    const long long total = rows * nv;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(idx % nv);
+        const long long r = idx / nv;
+        float f0[E::VEC], f1[E::VEC], o[E::VEC];
+        unpack16<DT>(*(const u32x4*)(x0 + r * ld0 + v * E::VEC), f0);
+        unpack16<DT>(*(const u32x4*)(x1 + r * ld1 + v * E::VEC), f1);
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) o[j] = f0[j] * a + f1[j] * b;
+        *(u32x4*)(y + r * ldy + v * E::VEC) = pack16<DT>(o);
+    }
+}
+
 static inline unsigned grid_for(long long total) {
     long long b = (total + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;       // cap and grid-stride: 16 workgroups per CU keeps HBM queues full
@@ -288,6 +307,20 @@ extern "C" int icaf_upsample_nearest(const void* x, int ldx, void* y, int ldy, i
     const long long total = (long long)B * H * scale * W * scale * (C / vec);
     hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, S(s), (const u32x4*)x, ldx / vec, (u32x4*)y, ldy / vec, B, H, W,
                        C / vec, scale);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+extern "C" int icaf_axpby(const void* x0, int ld0, const void* x1, int ld1, void* y, int ldy, int dtype, long long rows, int C, float a,
+                          float b, icaf_stream_t s) {
+    if (!x0 || !x1 || !y) return fail(ICAF_ERR_ARG, "icaf_axpby: null pointer");
+    if (dtype < 0 || dtype > 2) return fail(ICAF_ERR_ARG, "icaf_axpby: bad dtype");
+    const int vec = vec_of(dtype);
+    if (C % vec || ld0 % vec || ld1 % vec || ldy % vec) return fail(ICAF_ERR_ARG, "icaf_axpby: C/ld must be multiples of %d", vec);
+    dim3 grid(grid_for(rows * (C / vec))), block(256);
+    if (dtype == ICAF_F32) axpby_kernel<ICAF_F32><<<grid, block, 0, S(s)>>>((const float*)x0, ld0, (const float*)x1, ld1, (float*)y, ldy, rows, C / vec, a, b);
+    else if (dtype == ICAF_BF16) axpby_kernel<ICAF_BF16><<<grid, block, 0, S(s)>>>((const unsigned short*)x0, ld0, (const unsigned short*)x1, ld1, (unsigned short*)y, ldy, rows, C / vec, a, b);
+    else axpby_kernel<ICAF_F16><<<grid, block, 0, S(s)>>>((const unsigned short*)x0, ld0, (const unsigned short*)x1, ld1, (unsigned short*)y, ldy, rows, C / vec, a, b);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }

@@ -366,6 +366,41 @@ class Concat(HipModule):
         return out
 
 
+class Add(HipModule):
+    """Weighted sum of the two streams (reference models/common.py:324-331): x[0]*w + x[1]*(1-w)."""
+
+    def __init__(self, weight=0.5):
+        super().__init__()
+        self.w = weight
+
+    def emit(self, plan, xs, out=None):
+        a, b = xs
+        if out is None:
+            out = plan.act(*a.shape)
+        plan.add(ops.axpby(a, b, out, self.w, 1 - self.w))
+        return out
+
+
+class NiNfusion(HipModule):
+    """Concat + k x k convolution (no BN, no bias) + SiLU (reference models/common.py:348-360): one GEMM over the two
+    streams' features, which Model.build_plan places as adjacent channel slices so the concat is free."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1):
+        super().__init__()
+        self.concat = Concat(dimension=1)
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p), groups=g, bias=False)
+        self.act = nn.SiLU()
+
+    # the packed-weight / launch logic is Conv's (a Conv without .bn and without bias)
+    folded = Conv.folded
+    _act_code = Conv._act_code
+    fuse_stem = False
+
+    def emit(self, plan, xs, out=None):
+        x = self.concat.emit(plan, list(xs))
+        return Conv.emit(self, plan, x, out=out)
+
+
 def emit_upsample(m, plan, x, out=None):
     """nn.Upsample(None, 2, 'nearest') rows of the head (yaml rows 24 / 28)."""
     if m.mode != "nearest" or m.scale_factor is None or float(m.scale_factor) != int(m.scale_factor):
@@ -681,6 +716,6 @@ class Detect(HipModule):
         return z, logits, raws
 
 
-__all__ = ["autopad", "Conv", "Bottleneck", "C3", "SPPF", "Concat", "LearnableCoefficient", "LearnableWeights",
+__all__ = ["autopad", "Conv", "Bottleneck", "C3", "SPPF", "Concat", "Add", "NiNfusion", "LearnableCoefficient", "LearnableWeights",
            "AdaptivePool2d", "CrossAttention", "CrossTransformerBlock", "TransformerFusionBlock", "Detect",
            "emit_upsample", "HipModule", "math"]

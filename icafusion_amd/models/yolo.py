@@ -19,12 +19,12 @@ import torch.nn as nn
 
 from .. import ops
 from ..engine import ImageIn, Plan
-from .common import (C3, SPPF, Bottleneck, Concat, Conv, Detect, HipModule, TransformerFusionBlock,  # noqa: F401
-                     emit_upsample)
+from .common import (C3, SPPF, Add, Bottleneck, Concat, Conv, Detect, HipModule, NiNfusion,  # noqa: F401
+                     TransformerFusionBlock, emit_upsample)
 
 logger = logging.getLogger(__name__)
 _NAMESPACE = {"Conv": Conv, "C3": C3, "SPPF": SPPF, "Bottleneck": Bottleneck, "Concat": Concat, "Detect": Detect,
-              "TransformerFusionBlock": TransformerFusionBlock, "nn": nn}
+              "TransformerFusionBlock": TransformerFusionBlock, "NiNfusion": NiNfusion, "Add": Add, "nn": nn}
 
 
 def make_divisible(x, divisor):
@@ -88,6 +88,13 @@ def parse_model(d, ch):
             args.append([ch[x] for x in f])
             if isinstance(args[1], int):
                 args[1] = [list(range(args[1] * 2))] * len(f)
+        elif m is NiNfusion:                                  # reference models/yolo_test.py:280-283
+            c1 = sum(ch[x] for x in f)
+            c2 = c1 // 2
+            args = [c1, c2, *args]
+        elif m is Add:                                        # :266-268 — the yaml argument is REPLACED by the channel count,
+            c2 = ch[f[0]]                                     # which therefore becomes Add's weight (kept as the reference does)
+            args = [c2]
         elif m is TransformerFusionBlock:
             c2 = ch[f[0]]
             extra = {"loops_num": args[3]} if len(args) > 3 else {}
@@ -228,8 +235,11 @@ class Model(HipModule):
                 cur = (src[0], src[1] * s, src[2] * s)
             elif isinstance(m, Concat):
                 cur = (sum(t[0] for t in src), src[0][1], src[0][2])
-            elif isinstance(m, TransformerFusionBlock):
+            elif isinstance(m, (TransformerFusionBlock, Add)):
                 cur = src[0]
+            elif isinstance(m, NiNfusion):
+                k, s_, p = m.conv.kernel_size[0], m.conv.stride[0], m.conv.padding[0]
+                cur = (m.conv.out_channels, (src[0][1] + 2 * p - k) // s_ + 1, (src[0][2] + 2 * p - k) // s_ + 1)
             elif isinstance(m, Detect):
                 cur = None
             else:
@@ -288,7 +298,8 @@ class Model(HipModule):
         # of one (B, H, W, 2C) buffer, so its 1x1 fuse conv can read cat(rgb, ir) in place (common.py, fused tail)
         dmff_pair = {}
         for m in self.model:
-            if isinstance(m, TransformerFusionBlock) and not isinstance(m.f, int) and len(m.f) == 2 and m.fuse_tail:
+            if (isinstance(m, NiNfusion) or (isinstance(m, TransformerFusionBlock) and m.fuse_tail)) \
+                    and not isinstance(m.f, int) and len(m.f) == 2:
                 i, j = m.f
                 if i in placement or j in placement or i in dmff_pair or j in dmff_pair or shapes[i] != shapes[j]:
                     continue
@@ -305,7 +316,7 @@ class Model(HipModule):
         pair_out = {}
         y, x = [], None
         last_launch = {}                            # yaml row -> index of its last launch
-        dmff_rows = [m.i for m in self.model if isinstance(m, TransformerFusionBlock)]
+        dmff_rows = [m.i for m in self.model if isinstance(m, (TransformerFusionBlock, NiNfusion, Add))]
         for m in self.model:
             f = m.f
             n_before = len(plan.launches)

@@ -333,6 +333,16 @@ def copy_channels(x, y, name="copy_channels"):
                                              B * H * W, Cc), keep=(x, y), name=name, nbytes=nb)
 
 
+def axpby(x0, x1, y, a, b, name="add_fusion"):
+    """y = a*x0 + b*x1 over acts of equal shape."""
+    B, H, W, Cc, ld0 = _act_geom(x0)
+    ld1, ldy = _act_geom(x1)[4], _act_geom(y)[4]
+    assert x1.shape == x0.shape and y.shape == x0.shape
+    nb = 3 * x0.numel() * x0.element_size()
+    return Launch(lib().icaf_axpby, (x0.data_ptr(), ld0, x1.data_ptr(), ld1, y.data_ptr(), ldy, dtype_code(x0.dtype),
+                                     B * H * W, Cc, float(a), float(b)), keep=(x0, x1, y), name=name, nbytes=nb)
+
+
 def dmff_pool_tokens(fea_rgb, fea_ir, pos_rgb, pos_ir, tokens, th, tw, kh, kw, sh, sw, w_rgb, w_ir,
                      name="dmff_pool_tokens"):
     B, H, W, Cc, ld0 = _act_geom(fea_rgb)

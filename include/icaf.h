@@ -135,6 +135,10 @@ int icaf_upsample_nearest(const void* x, int ldx, void* y, int ldy, int dtype, i
                           int scale, icaf_stream_t s);
 int icaf_copy_channels(const void* x, int ldx, void* y, int ldy, int dtype, long long rows, int C,
                        icaf_stream_t s);
+/* icaf_axpby: y = a*x0 + b*x1 over `rows` pixels of C channels — the `Add` fusion block (models/common.py:324-331:
+ * x[0]*w + x[1]*(1-w)) of the *_Add_* configs. */
+int icaf_axpby(const void* x0, int ld0, const void* x1, int ld1, void* y, int ldy, int dtype, long long rows, int C,
+               float a, float b, icaf_stream_t s);
 
 /* ---- DMFF (TransformerFusionBlock, models/common.py:762-865) ---------------------------------------------
  * icaf_dmff_pool_tokens: AdaptivePool2d avg + max (models/common.py:868-891), LearnableWeights mix

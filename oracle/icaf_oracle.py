@@ -69,6 +69,12 @@ def build_layers(cfg):
         elif kind == "TransformerFusionBlock":
             c2 = ch[f[0]]                                                # yaml's first arg is ignored (:284-286)
             p = dict(c=c2, va=args[1], ha=args[2], heads=8, loops=args[3] if len(args) > 3 else 1)
+        elif kind == "NiNfusion":                                       # models/yolo_test.py:280-283
+            c1 = sum(ch[x] for x in f)
+            c2, p = c1 // 2, dict(k=args[0], s=args[1])
+        elif kind == "Add":                                             # models/yolo_test.py:266-268: args = [c2], so the
+            c2 = ch[f[0]]                                               # "weight" of Add.__init__ is the CHANNEL COUNT
+            p = dict(w=float(c2))
         elif kind == "Detect":
             c2, p = None, dict(nc=args[0], anchors=args[1], ch=[ch[x] for x in f])
         else:
@@ -277,6 +283,11 @@ class OracleModel:
             elif kind == "TransformerFusionBlock":
                 x = dmff(src[0], src[1], sd, pre, p["va"], p["ha"], p["heads"],
                          self.loops if self.loops is not None else p["loops"])
+            elif kind == "NiNfusion":                                 # models/common.py:348-360: SiLU(conv(cat)), no BN, no bias
+                y = torch.cat(src, 1)
+                x = F.silu(F.conv2d(y, sd[pre + ".conv.weight"], None, p["s"], p["k"] // 2))
+            elif kind == "Add":                                       # models/common.py:324-331
+                x = src[0] * p["w"] + src[1] * (1 - p["w"])
             elif kind == "Detect":
                 x = detect(src, sd, pre, p["nc"], p["anchors"])
             outs.append(x)

@@ -184,6 +184,10 @@ def metrics_case(general, metrics, name):
 def main():
     torch.set_num_threads(os.cpu_count())
     yt, common, general, metrics = import_reference()
+    if "--fusion-variants-only" in sys.argv:          # the NiNfusion / Add fixtures, added later
+        model_case(yt, "model_s_add_kaist_320_b1", "yolov5s_Add_kaist.yaml", 1, 320, 320, seed=11)
+        model_case(yt, "model_n_ninfusion_flir_320_b2", "yolov5n_NiNfusion_FLIR.yaml", 2, 320, 320, seed=12)
+        return
     z_s = model_case(yt, "model_s_kaist_320_b2", "yolov5s_Transfusion_kaist.yaml", 2, 320, 320, seed=1)
     model_case(yt, "model_s_kaist_640_b1", "yolov5s_Transfusion_kaist.yaml", 1, 640, 640, seed=0)
     model_case(yt, "model_s_kaist_384x320_loops3", "yolov5s_Transfusion_kaist.yaml", 1, 384, 320, seed=2, loops=3)
@@ -199,6 +203,8 @@ def main():
     nms_case(general, "nms_l_agnostic_classes", z_l.numpy(), conf_thres=0.3, iou_thres=0.6, agnostic=True,
              classes=[0, 2, 5])
     metrics_case(general, metrics, "metrics_ap")
+    model_case(yt, "model_s_add_kaist_320_b1", "yolov5s_Add_kaist.yaml", 1, 320, 320, seed=11)
+    model_case(yt, "model_n_ninfusion_flir_320_b2", "yolov5n_NiNfusion_FLIR.yaml", 2, 320, 320, seed=12)
 
 
 if __name__ == "__main__":

@@ -364,6 +364,15 @@ POOL_CASES = [(2, 128, 40, 40, 20, 20), (1, 64, 40, 40, 16, 16), (1, 64, 64, 80,
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+def test_axpby_add_fusion(dt):
+    x0, x1 = rnd((2, 24, 9, 11), 71), rnd((2, 24, 9, 11), 72)
+    a0, a1 = to_act(x0, dt, pad_to=40), to_act(x1, dt)
+    y = torch.zeros((2, 9, 11, 24), dtype=dt, device=DEV)
+    run(ops.axpby(a0, a1, y, 128.0, -127.0))                  # the reference's Add with weight = channel count
+    close(from_act(y), q(x0, dt) * 128.0 + q(x1, dt) * -127.0, dt, "axpby")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("case", POOL_CASES)
 def test_dmff_pool_tokens_and_upsample_merge(case, dt):
     B, C, H, W, va, ha = case
