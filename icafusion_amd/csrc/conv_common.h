@@ -16,6 +16,8 @@ struct ConvP {
     const float* pre; int pre_h, pre_w, ldpre;     // optional pre-activation bilinear term (icaf.h)
     const void* w1; const float* bias1;            // fused Bottleneck (ctile.hip, FUSE1): the 1x1 convolution in front
     long long w1_gs, bias1_gs; int Kp1; unsigned int w1_bytes;
+    const void* w2; const float* bias2; void* y2;  // chained 1x1 convolution behind this layer (igemm.hip, CHAIN)
+    long long w2_gs, bias2_gs, y2_gs; int Kp2, Cout2, ldy2, vec_y2; unsigned int w2_bytes;
 };
 
 constexpr int ROWB = 64;        // bytes of K per LDS row per slice
@@ -38,7 +40,9 @@ __device__ __forceinline__ int xcd_tile(int ntile_total) {
 // row_to_m(tile_row) -> linear output pixel index (b, ho, wo), or -1 when the tile row lies outside the tensor.
 // PRE = true compiles the pre-activation bilinear term in (it costs ~40 registers, so only the few instantiations that
 // serve DMFF's fused tail carry it).
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, bool PRE, typename RowMap>
+// SECOND = true writes the tile as the output of the chained second layer (p.bias2 / y2 / ldy2 / Cout2, no residual):
+// selecting the fields here keeps ConvP in scalar registers — a modified copy of the struct would live in scratch memory.
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, bool PRE, bool SECOND = false, typename RowMap>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsigned char* lds, const ConvP& p, int g, RowMap row_to_m, int n0) {
     using E = Elem<DT>;
     using EO = Elem<ODT>;
@@ -49,8 +53,9 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
     constexpr int SO = BN * EO::BYTES + 16;  // staging row stride (bytes)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
-    const float alpha_acc = p.alpha_acc[g], alpha_res = p.alpha_res[g];
-    const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
+    const float alpha_acc = SECOND ? 1.0f : p.alpha_acc[g], alpha_res = p.alpha_res[g];
+    const float* __restrict__ bias = SECOND ? (p.bias2 ? p.bias2 + g * p.bias2_gs : nullptr) : (p.bias ? p.bias + g * p.bias_gs : nullptr);
+    const int Cout = SECOND ? p.Cout2 : p.Cout, ldy = SECOND ? p.ldy2 : p.ldy, vec_y = SECOND ? p.vec_y2 : p.vec_y;
     // pre-activation bilinear term: the four source taps and weights of this lane's TM pixels (align_corners=False:
     // src = max(0, (dst + 0.5) * in/out - 0.5), neighbours clamped), exactly as upsample_merge_kernel computes them
     const float* pt[PRE ? TM : 1][4];
@@ -84,7 +89,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
         for (int q = 0; q < 4; ++q) {
             const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;      // tile-local channel of this register quad
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias && n0 + nl < p.Cout) {        // (the packed bias is padded to a multiple of 128 >= Cout only)
+            if (bias && n0 + nl < Cout) {          // (the packed bias is padded to a multiple of 128 >= Cout only)
                 const f32x4 t = *(const f32x4*)(bias + n0 + nl);
                 bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
             }
@@ -92,7 +97,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
             for (int b = 0; b < TM; ++b) {
                 const int ml = wm * WM + b * 32 + l31;
                 float pv[4] = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (PRE) if (n0 + nl < p.Cout) {
+                if constexpr (PRE) if (n0 + nl < Cout) {
                     const f32x4 t00 = *(const f32x4*)(pt[b][0] + n0 + nl), t01 = *(const f32x4*)(pt[b][1] + n0 + nl);
                     const f32x4 t10 = *(const f32x4*)(pt[b][2] + n0 + nl), t11 = *(const f32x4*)(pt[b][3] + n0 + nl);
 #pragma unroll
@@ -119,18 +124,18 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
     }
     __syncthreads();
 
-    typename EO::type* __restrict__ yg = (typename EO::type*)p.y + g * p.y_gs;
-    const typename E::type* __restrict__ rg = p.res ? (const typename E::type*)p.res + g * p.res_gs : nullptr;
+    typename EO::type* __restrict__ yg = SECOND ? (typename EO::type*)p.y2 + g * p.y2_gs : (typename EO::type*)p.y + g * p.y_gs;
+    const typename E::type* __restrict__ rg = (!SECOND && p.res) ? (const typename E::type*)p.res + g * p.res_gs : nullptr;
     constexpr int VPR = BN / VO;                       // 16-byte vectors per staged row
     constexpr int NVEC = BM * VPR;
     for (int idx = tid; idx < NVEC; idx += NT) {
         const int row = idx / VPR, cv = idx - row * VPR;
         const int m = row_to_m(row), n = n0 + cv * VO;
-        if (m < 0 || n >= p.Cout) continue;
+        if (m < 0 || n >= Cout) continue;
         const u32x4 sv = *(const u32x4*)(lds + row * SO + cv * 16);
-        const int nvalid = (p.Cout - n) < VO ? (p.Cout - n) : VO;
-        if (!rg && p.vec_y && nvalid == VO) {        // common case: no residual — the staged vector is final
-            *(u32x4*)(yg + (long long)m * p.ldy + n) = sv;
+        const int nvalid = (Cout - n) < VO ? (Cout - n) : VO;
+        if (!rg && vec_y && nvalid == VO) {        // common case: no residual — the staged vector is final
+            *(u32x4*)(yg + (long long)m * ldy + n) = sv;
             continue;
         }
         float v[VO];
@@ -151,8 +156,8 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
                 for (int j = 0; j < nvalid; ++j) v[j] += alpha_res * E::ld(rp + j);
             }
         }
-        typename EO::type* yp = yg + (long long)m * p.ldy + n;
-        if (p.vec_y && nvalid == VO) {
+        typename EO::type* yp = yg + (long long)m * ldy + n;
+        if (vec_y && nvalid == VO) {
             *(u32x4*)yp = pack16<ODT>(v);
         } else {
             for (int j = 0; j < nvalid; ++j) EO::st(yp + j, v[j]);

@@ -270,7 +270,7 @@ int ctile_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     if (a->Cout > sh.bn) return fail(ICAF_ERR_UNSUPPORTED, "ctile %s: Cout=%d > %d", sh.tag, a->Cout, sh.bn);
     if (a->act != ICAF_ACT_SILU || a->out_dtype != a->dtype) return fail(ICAF_ERR_UNSUPPORTED, "ctile: SiLU and out dtype == dtype only");
     if (p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "ctile: operand exceeds the 2 GiB buffer-descriptor range");
-    if (a->pre) return fail(ICAF_ERR_UNSUPPORTED, "ctile: no pre-activation term");
+    if (a->pre || a->w2) return fail(ICAF_ERR_UNSUPPORTED, "ctile: no pre-activation term / chained 1x1");
     if (a->Kp % (128 / eb)) return fail(ICAF_ERR_UNSUPPORTED, "ctile: Kp must be a multiple of 128 bytes");
     return ICAF_OK;
 }

@@ -26,8 +26,8 @@
 //     buffer-descriptor range and kept selectable for A/B measurements (configuration ids 11..14).
 #include "conv_common.h"
 
-static_assert(sizeof(icaf_conv_args) == 208, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
-static_assert(sizeof(icaf_bneck_args) == 248, "icaf_bneck_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
+static_assert(sizeof(icaf_conv_args) == 272, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
+static_assert(sizeof(icaf_bneck_args) == 312, "icaf_bneck_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
 
 namespace icaf {
 
@@ -45,7 +45,11 @@ namespace icaf {
 // Loop shape: after the single barrier of a slice, ALL its fragments are read into registers (LDS latency overlaps the
 // address arithmetic), then the next slice's DMA instructions are issued in NSTEP portions between the MFMA steps, so
 // their VALU work hides under the matrix pipe instead of preceding it.
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE, bool PRE>
+// CHAIN = true appends a second, 1x1 GEMM to the tile before anything is stored (icaf.h: w2 / bias2 / y2): the SiLU'd
+// output tile is staged in LDS as bf16 / f16 exactly as it would be written to HBM, re-read as the pixel operand of
+//   y2 = SiLU(W2 . tile + bias2)     (K = this layer's channels, all inside the one N tile; W2 resident in LDS, fetched by
+// LDS-DMA while the main loop runs), and only y2 is written.  Same rounding points and K order as two launches.
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE, bool PRE, bool CHAIN = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(const ConvP p) {
     using E = Elem<DT>;
     using L = TileLds<DT, ODT, BM, BN>;
@@ -155,6 +159,28 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(c
         }
     };
 
+    // chained 1x1: its weights (BN rows x BN channels, 128-byte slices, igemm's swizzle) go to LDS behind the ring / staging
+    constexpr int RING_BYTES = NS * STAGE > L::OUT_BYTES ? NS * STAGE : L::OUT_BYTES;
+    constexpr int W2_OFF = (RING_BYTES + 1023) / 1024 * 1024;
+    constexpr int W2_SLICES = BN / 64;             // K2 = BN channels of a 16-bit type = BN/64 slices of 128 bytes
+    if constexpr (CHAIN) {
+        const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const typename E::type*)p.w2 + g * p.w2_gs), 0, p.w2_bytes, 0x00020000);
+        const int rs8 = lane >> 3;
+        auto issue_w2 = [&]() {
+#pragma unroll
+            for (int c2 = 0; c2 < W2_SLICES; ++c2)
+#pragma unroll
+                for (int i = 0; i < BN / 8 / NW; ++i) {
+                    const int j = wave + NW * i;                       // 8 weight rows per instruction
+                    const int sl = (lane & 7) ^ (((j & 1) << 2) | (rs8 >> 1));
+                    const unsigned voff = ((unsigned)(j * 8 + rs8) * (unsigned)p.Kp2 + (unsigned)(c2 * 64 + sl * 8)) * 2u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w2r, (lds_ptr_t)(lds + W2_OFF + c2 * BN * 128 + j * 1024), 16, voff, 0, 0, 0);
+                }
+        };
+        issue_w2();
+    }
+
     f32x16 acc[TN][TM];
 #pragma unroll
     for (int a = 0; a < TN; ++a)
@@ -207,7 +233,57 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(c
     wait_vmcnt<0>();                               // drain the zero-fill slices issued past the end
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    epilogue<DT, ODT, BM, BN, WM, WN, ACT, PRE>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
+    if constexpr (CHAIN) {
+        static_assert(DT != ICAF_F32 && ODT == DT && ACT == ICAF_ACT_SILU && !PRE, "chained 1x1: 16-bit SiLU layers");
+        constexpr int SO = BN * E::BYTES + 16;     // staging row stride (as the epilogue's)
+        const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
+        // (a) this layer's output tile -> LDS, rounded to the storage type
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (bias && nl < p.Cout) bv = *(const f32x4*)(bias + nl);
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = silu_f(acc[a][b][4 * q + j] + bv[j]);
+                    u32x2 pk;
+                    if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
+                    else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
+                    *(u32x2*)(lds + (wm * WM + b * 32 + l31) * SO + nl * E::BYTES) = pk;
+                }
+            }
+        __syncthreads();
+        // (b) y2 tile = W2 . tile: pixels are the rows of the staged tile, K = its BN channels
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+        const int fk2 = (l31 >> 1) & 7;
+#pragma unroll
+        for (int s2 = 0; s2 < BN / 16; ++s2) {
+            u32x4 fp2[TM], fw2[TN];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) fp2[b] = *(const u32x4*)(lds + (wm * WM + b * 32 + l31) * SO + ((2 * s2 + hi) << 4));
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+                fw2[a] = *(const u32x4*)(lds + W2_OFF + (s2 >> 2) * BN * 128 + (wn * WN + a * 32 + l31) * 128 + (((2 * (s2 & 3) + hi) ^ fk2) << 4));
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) mma_step<DT>(acc[a][b], fw2[a], fp2[b]);
+        }
+        __syncthreads();                           // the staged tile has been consumed: the epilogue may overwrite it
+        // (c) the ordinary epilogue, writing the second layer's fields of p (SECOND)
+        epilogue<DT, ODT, BM, BN, WM, WN, ICAF_ACT_SILU, false, true>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, 0);
+    } else {
+        epilogue<DT, ODT, BM, BN, WM, WN, ACT, PRE>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
+    }
 }
 
 // ===============================================================================================================
@@ -374,6 +450,12 @@ static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
     if (blocks(t) < 512 && blocks(4) > blocks(t)) t = 4;
     if (!dma_ok) return t + 10;
     const int eb = a->dtype == ICAF_F32 ? 4 : 2;
+    if (a->w2) {                                    // chained 1x1: the N tile must hold every channel of both layers
+        const int c = a->Cout > a->Cout2 ? a->Cout : a->Cout2;
+        const bool w128 = ((long long)a->Cin * eb) % 128 == 0;
+        if (c <= 64) return w128 ? 22 : 2;
+        return w128 ? 21 : 1;                       // (c > 128 is rejected at launch: W2 would not fit beside the ring)
+    }
     if (a->pre) {                                   // only tiles 1 / 2 on pipelines 0 / 2 carry the pre term
         if (t > 2) t = 2;
         return ((long long)a->Cin * eb) % 128 == 0 ? t + 20 : t;
@@ -388,18 +470,19 @@ static int set_lds_attr(KernelT kernel, int bytes) {
     return ICAF_OK;
 }
 
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE, bool PRE = false>
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE, bool PRE = false, bool CHAIN = false>
 static int launch_dma_mode(const ConvP& q, dim3 grid, hipStream_t s) {
     constexpr int ring_only = NS * (BM + BN) * RB, stage_out = TileLds<DT, ODT, BM, BN>::OUT_BYTES;
-    constexpr int ring = ring_only > stage_out ? ring_only : stage_out;
+    constexpr int ring0 = ring_only > stage_out ? ring_only : stage_out;
+    constexpr int ring = CHAIN ? (ring0 + 1023) / 1024 * 1024 + BN * BN * 2 : ring0;      // + the chained layer's weights
     static_assert(ring <= 160 * 1024, "LDS capacity");
     static bool attr_done = false;                 // one flag per instantiation
     if (!attr_done) {
-        int st = set_lds_attr(igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE, PRE>, ring);
+        int st = set_lds_attr(igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE, PRE, CHAIN>, ring);
         if (st) return st;
         attr_done = true;
     }
-    igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE, PRE><<<grid, dim3((BM / WM) * (BN / WN) * 64), ring, s>>>(q);
+    igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE, PRE, CHAIN><<<grid, dim3((BM / WM) * (BN / WN) * 64), ring, s>>>(q);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
@@ -408,6 +491,18 @@ template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int 
 static int launch_dma(const ConvP& q, dim3 grid, hipStream_t s) {
     const int eb = DT == ICAF_F32 ? 4 : 2;
     const bool whole_taps = (q.Cin * eb) % RB == 0;          // a K slice never straddles two filter taps
+    if (q.w2) {       // chained 1x1 (icaf.h): one N tile of 64 / 128 / 256 channels, tap-uniform K slices, pipelines 0 and 2
+        if constexpr (ACT == ICAF_ACT_SILU && ODT == DT && DT != ICAF_F32 && BN >= 64 && NS * RB != 384 &&
+                      ((BM / WM) * (BN / WN) == 4 ? BM == 128 : BN == 256)) {
+            constexpr int lds_need = (NS * (BM + BN) * RB > TileLds<DT, ODT, BM, BN>::OUT_BYTES ? NS * (BM + BN) * RB : TileLds<DT, ODT, BM, BN>::OUT_BYTES) + 1024 + BN * BN * 2;
+            if constexpr (lds_need <= 160 * 1024) {
+                if (whole_taps && q.Cout <= BN && q.Cout2 <= BN && !q.pre && !q.res)
+                    return launch_dma_mode<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, 2, false, true>(q, grid, s);
+            }
+        }
+        return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: the chained 1x1 needs a 16-bit SiLU layer with Cout, Cout2 <= the N tile (64 / 128 / 256), "
+                                          "Cin*bytes %% %d == 0, no residual / pre term, on pipelines 0 / 2", RB);
+    }
     if (q.pre) {      // pre-activation bilinear term (DMFF fused tail): 1x1 + SiLU on the 128-row tiles only
         if constexpr (ACT == ICAF_ACT_SILU && ODT == DT && BM == 128 && (BM / WM) * (BN / WN) == 4 && NS * RB != 384) {
             if (whole_taps && q.kh == 1 && q.kw == 1 && q.sh == 1 && q.sw == 1 && q.ph == 0 && q.pw == 0)
@@ -429,7 +524,7 @@ static int launch_act(const ConvP& q, dim3 grid, int pipe, hipStream_t s) {
         case 2: return launch_dma<DT, ODT, BM, BN, WM, WN, ACT, 128, 2>(q, grid, s);
         case 3: return launch_dma<DT, ODT, BM, BN, WM, WN, ACT, 128, 3>(q, grid, s);
         default:
-            if (q.pre) return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: `pre` is not built for the register-staged pipeline");
+            if (q.pre || q.w2) return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: `pre` / chained 1x1 are not built for the register-staged pipeline");
             igemm_kernel<DT, ODT, BM, BN, WM, WN, ACT><<<grid, dim3(NTHREADS), 0, s>>>(q);
             ICAF_LAUNCH_CHECK();
             return ICAF_OK;
@@ -503,6 +598,8 @@ static int validate(const icaf_conv_args* a) {
     if (a->ldy < a->Cout) return fail(ICAF_ERR_ARG, "icaf_conv2d: ldy < Cout");
     if (a->res && a->ldr < a->Cout) return fail(ICAF_ERR_ARG, "icaf_conv2d: ldr < Cout");
     if ((long long)a->B * a->Ho * a->Wo > 0x7fffffffLL) return fail(ICAF_ERR_ARG, "icaf_conv2d: too many output pixels");
+    if (a->w2 && (!a->y2 || a->Cout2 < 1 || a->ldy2 < a->Cout2 || a->Kp2 < a->Cout || (a->Kp2 * (a->dtype == ICAF_F32 ? 4 : 2)) % 128 || ((uintptr_t)a->w2 & 15)))
+        return fail(ICAF_ERR_ARG, "icaf_conv2d: chained 1x1 needs y2, ldy2 >= Cout2 >= 1, Kp2 >= Cout in whole 128-byte slices, aligned w2");
     if (a->pre && (a->pre_h < 1 || a->pre_w < 1 || a->ldpre < a->Cout || (a->ldpre & 3) || ((uintptr_t)a->pre & 15) || a->groups != 1))
         return fail(ICAF_ERR_ARG, "icaf_conv2d: pre needs pre_h, pre_w >= 1, ldpre >= Cout and a multiple of 4, 16-byte alignment, groups == 1");
     return ICAF_OK;
@@ -533,6 +630,10 @@ static void fill(const icaf_conv_args* a, ConvP& p) {
     for (int i = 0; i < 2; ++i) { p.alpha_acc[i] = a->alpha_acc[i]; p.alpha_res[i] = a->alpha_res[i]; }
     p.pre = a->pre; p.pre_h = a->pre_h; p.pre_w = a->pre_w; p.ldpre = a->ldpre;
     p.w1 = nullptr; p.bias1 = nullptr; p.w1_gs = p.bias1_gs = 0; p.Kp1 = 0; p.w1_bytes = 0;
+    p.w2 = a->w2; p.bias2 = a->bias2; p.y2 = a->y2; p.w2_gs = a->w2_gs; p.bias2_gs = a->bias2_gs; p.y2_gs = a->y2_gs;
+    p.Kp2 = a->Kp2; p.Cout2 = a->Cout2; p.ldy2 = a->ldy2;
+    p.vec_y2 = a->w2 && (a->ldy2 % vo == 0) && (((uintptr_t)a->y2 & 15) == 0) && ((a->y2_gs * yb) % 16 == 0);
+    p.w2_bytes = a->w2 ? (unsigned)((((long long)a->Cout2 + 127) / 128 * 128) * a->Kp2 * eb) : 0;
 }
 
 }  // namespace icaf

@@ -143,7 +143,8 @@ class Conv(HipModule):
             b = (b - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
         return w, b
 
-    def emit(self, plan, x, out=None, res=None, twin=None, also=(), twin_also=(), pre_term=None, swap_halves=False):
+    def emit(self, plan, x, out=None, res=None, twin=None, also=(), twin_also=(), pre_term=None, swap_halves=False,
+             chain=None):
         """Append this layer's launch.
 
         twin: the structurally identical Conv of the other backbone stream — x / out / res are then pair acts
@@ -152,6 +153,8 @@ class Conv(HipModule):
               output channels are appended to this layer's, one GEMM with N = sum of the widths (twin_also: the
               twin stream's counterparts).
         pre_term: fp32 coarse map (B, h, w, Cout) added, bilinearly resized, before bias + activation (icaf.h).
+        chain: (convs, twin_convs, y2) — 1x1 SiLU Convs (their outputs concatenated, e.g. the cv1 | cv2 of the C3 behind a
+              down-sampling Conv) applied to this layer's output tile inside the same launch; only y2 is written.
         swap_halves: the input view holds the two halves of the layer's input channels in swapped order (C3 after an
               odd number of fused Bottlenecks): the weight columns are swapped to match when they are packed."""
         if self.conv.groups != 1 or self.conv.dilation != (1, 1):
@@ -228,9 +231,40 @@ class Conv(HipModule):
         Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
         if out is None:
             out = plan.act(B, Ho, Wo, c2, pair=paired)
+        ch = None
+        if chain is not None:
+            convs, twin_convs, y2 = chain
+            n2 = sum(c.conv.out_channels for c in convs)
+
+            def pack2():
+                packs = []
+                for row in ([convs] + ([twin_convs] if paired else [])):
+                    ws, bs = zip(*(c.folded() for c in row))
+                    w2p, kp2 = ops.pack_conv_weight(torch.cat(ws), plan.dtype)
+                    packs.append((w2p, kp2, ops.pack_bias(torch.cat(bs), n2)))
+                if not paired:
+                    return packs[0]
+                return (torch.stack([p[0] for p in packs]).contiguous(), packs[0][1], torch.stack([p[2] for p in packs]).contiguous())
+            w2p, kp2, b2p = self._cached(("chain",) + key_tail + tuple(id(c) for c in convs), pack2)
+            ch = dict(w=w2p, kp=kp2, bias=b2p, y=y2, cout=n2)
+            out = y2[..., :c2] if y2.shape[-1] >= c2 else plan.act(B, Ho, Wo, c2, pair=paired)   # (y is ignored by the kernel)
         plan.add(ops.conv2d(x, wp, kp, bp, out, kh, kw, sh, sw, ph, pw, c1, c2, self._act_code(), res=res,
-                            name=f"conv{kh}x{kw}s{sh}", pre=pre_term))
-        return out
+                            name=f"conv{kh}x{kw}s{sh}" + ("+1x1" if ch else ""), pre=pre_term, chain=ch))
+        return y2 if ch else out
+
+    chain_fuse = True    # let a C3 behind this Conv run its cv1 | cv2 GEMM on this layer's output tile (one launch)
+
+    def chain_ok(self, plan, c3):
+        """Can the fused cv1 | cv2 GEMM of `c3` ride on this conv's output tile?  (mirrors the checks of icaf_conv2d)"""
+        k, cv = self.conv, c3.cv1.conv
+        n1, n2 = k.out_channels, 2 * cv.out_channels
+        return (self.chain_fuse and plan.dtype in (torch.bfloat16, torch.float16) and isinstance(self.act, nn.SiLU)
+                and hasattr(k, "kernel_size") and k.kernel_size == (3, 3) and k.groups == 1 and k.in_channels % 32 == 0
+                and cv.kernel_size == (1, 1) and cv.stride == (1, 1) and cv.in_channels == n1
+                and c3.cv2.conv.out_channels == cv.out_channels and isinstance(c3.cv1.act, nn.SiLU)
+                and max(n1, n2) <= self.chain_max_width)
+
+    chain_max_width = 128
 
 
 class Bottleneck(HipModule):
@@ -297,17 +331,30 @@ class C3(HipModule):
         self.cv3 = Conv(2 * c_, c2, 1)
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
 
-    def emit(self, plan, x, out=None, twin=None):
-        B, H, W = x.shape[-4:-1]
+    def emit(self, plan, x, out=None, twin=None, lead=None):
+        """lead = (Conv, twin Conv or None): the down-sampling Conv in front of this block whose output only this block
+        reads; `x` is then THAT conv's input and cv1 | cv2 run chained on its output tile (the tensor between the two
+        yaml rows is never written)."""
+        if lead is not None:
+            k = lead[0].conv
+            B = x.shape[-4]
+            H = (x.shape[-3] + 2 * k.padding[0] - k.kernel_size[0]) // k.stride[0] + 1
+            W = (x.shape[-2] + 2 * k.padding[1] - k.kernel_size[1]) // k.stride[1] + 1
+        else:
+            B, H, W = x.shape[-4:-1]
         c_ = self.cv1.conv.out_channels
         paired = twin is not None
-        fused = [blk.fusable(plan, x) for blk in self.m]
+        fused = [blk.fusable(plan, x if lead is None else torch.empty((B, H, W, 1), device="meta")) for blk in self.m]
         # Buffer of three c_-wide slots [a | b | a']: cv1|cv2 write [a | b]; a fused Bottleneck cannot run in place (its
         # neighbours' patches read x), so the chain ping-pongs between slot 0 and slot 2; cv3 then reads [a | b] or
         # [b | a'] — in the second case with its weight columns swapped to match.
         cat = plan.act(B, H, W, (3 if any(fused) else 2) * c_, pair=paired)
-        self.cv1.emit(plan, x, out=cat[..., :2 * c_], twin=twin.cv1 if paired else None, also=(self.cv2,),
-                      twin_also=(twin.cv2,) if paired else ())
+        if lead is not None:
+            lead[0].emit(plan, x, twin=lead[1], chain=((self.cv1, self.cv2), (twin.cv1, twin.cv2) if paired else None,
+                                                       cat[..., :2 * c_]))
+        else:
+            self.cv1.emit(plan, x, out=cat[..., :2 * c_], twin=twin.cv1 if paired else None, also=(self.cv2,),
+                          twin_also=(twin.cv2,) if paired else ())
         cur = 0
         for j, blk in enumerate(self.m):
             a = cat[..., cur * c_:(cur + 1) * c_]

@@ -116,7 +116,7 @@ def parse_model(d, ch):
     return nn.Sequential(*layers), sorted(save)
 
 
-def emit_any(m, plan, src, out=None, twin=None):
+def emit_any(m, plan, src, out=None, twin=None, lead=None):
     """Emit one yaml row: our HipModules, torch's nn.Upsample, or an nn.Sequential repeat of either.  `twin` is the
     same row of the other backbone stream when both run as one paired launch sequence."""
     if isinstance(m, nn.Upsample):
@@ -130,9 +130,12 @@ def emit_any(m, plan, src, out=None, twin=None):
         return src
     if not hasattr(m, "emit"):
         raise NotImplementedError(f"layer type {type(m).__name__} is outside the hot path")
+    kw = {}
     if twin is not None:
-        return m.emit(plan, src, out=out, twin=twin)
-    return m.emit(plan, src, out=out)
+        kw["twin"] = twin
+    if lead is not None:
+        kw["lead"] = lead
+    return m.emit(plan, src, out=out, **kw)
 
 
 PAIRABLE = (Conv, C3, SPPF)
@@ -314,6 +317,7 @@ class Model(HipModule):
         twins = {ir0 + k: k for k in range(run)}
         rgb_rows = set(twins.values())
         pair_out = {}
+        pending_lead = {}                           # C3 row -> ((Conv, twin Conv), conv input): rows fused into one launch
         y, x = [], None
         last_launch = {}                            # yaml row -> index of its last launch
         dmff_rows = [m.i for m in self.model if isinstance(m, (TransformerFusionBlock, NiNfusion, Add))]
@@ -322,18 +326,31 @@ class Model(HipModule):
             n_before = len(plan.launches)
             if m.i in rgb_rows:                     # both streams in one paired launch sequence
                 src = in_pair if m.i == 0 else pair_out[m.i - 1]
+                nxt = self.model[m.i + 1] if m.i + 1 < len(self.model) else None
+                if (isinstance(m, Conv) and m.i > 0 and isinstance(nxt, C3) and (m.i + 1) in rgb_rows and nxt.f == -1
+                        and m.i not in self.save and (ir0 + m.i) not in self.save and m.i not in dmff_pair
+                        and m.chain_ok(plan, nxt)):
+                    pending_lead[m.i + 1] = ((m, self.model[ir0 + m.i]), src)      # emitted together with the C3 row
+                    pair_out[m.i] = None
+                    y.append(None)
+                    last_launch[m.i] = last_launch[ir0 + m.i] = len(plan.launches) - 1
+                    continue
+                lead = None
+                if m.i in pending_lead:
+                    lead, src = pending_lead.pop(m.i)
                 pout = None
                 if m.i in dmff_pair and dmff_pair[m.i][3] == ir0 + m.i:       # pair act = the two halves of the DMFF buffer
                     buf, _, c, _ = dmff_pair[m.i]
                     Bb, h, w, _ = buf.shape
                     pout = buf.as_strided((2, Bb, h, w, c), (c, h * w * 2 * c, w * 2 * c, 2 * c, 1))
-                pair_out[m.i] = emit_any(m, plan, src, pout, twin=self.model[ir0 + m.i])
+                pair_out[m.i] = emit_any(m, plan, src, pout, twin=self.model[ir0 + m.i], lead=lead)
                 x = pair_out[m.i][0]
                 y.append(x)
                 last_launch[m.i] = last_launch[ir0 + m.i] = len(plan.launches) - 1
                 continue
             if m.i in twins:                        # already emitted with its RGB twin
-                x = pair_out[twins[m.i]][1]
+                po = pair_out[twins[m.i]]
+                x = po[1] if po is not None else None
                 y.append(x)
                 continue
             if f == -4:

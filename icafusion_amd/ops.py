@@ -111,7 +111,7 @@ def s2d_conv_weight(w4d):
 # launches
 # ------------------------------------------------------------------------------------------------------------
 def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res=None, alpha_acc=1.0,
-           alpha_res=1.0, groups=1, group_strides=None, tile=0, name="conv2d", pre=None):
+           alpha_res=1.0, groups=1, group_strides=None, tile=0, name="conv2d", pre=None, chain=None):
     """Record an implicit-GEMM conv / linear.  x, y, res are acts; for groups=2 they are the group-0 views and
     group_strides = dict(x=, w=, bias=, y=, res=) gives element strides to group 1."""
     B, H, W, cx, ldx = _act_geom(x)
@@ -147,12 +147,25 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
         Bp, hp, wp_, cp, ldp = _act_geom(pre)
         assert pre.dtype == torch.float32 and Bp == B and cp >= cout and groups == 1
         a.pre, a.pre_h, a.pre_w, a.ldpre = pre.data_ptr(), hp, wp_, ldp
+    if chain is not None:             # chained 1x1 + SiLU on the output tile (icaf.h): dict(w=, kp=, bias=, y=, cout=)
+        y2 = chain["y"]
+        B2, H2, W2, c2y, ldy2 = _act_geom(y2)
+        assert (B2, H2, W2) == (B, Ho, Wo) and c2y >= chain["cout"] and y2.dtype == x.dtype and (y2.dim() == 5) == (x.dim() == 5)
+        a.w2, a.y2 = chain["w"].data_ptr(), y2.data_ptr()
+        a.bias2 = chain["bias"].data_ptr() if chain.get("bias") is not None else None
+        a.Kp2, a.Cout2, a.ldy2 = chain["kp"], chain["cout"], ldy2
+        if x.dim() == 5:
+            a.w2_gs, a.y2_gs = chain["w"].stride(0), y2.stride(0)
+            a.bias2_gs = chain["bias"].stride(0) if chain.get("bias") is not None else 0
     m = B * Ho * Wo
     flops = 2.0 * m * cout * kh * kw * cin * groups
     es, eo = x.element_size(), y.element_size()
     nbytes = groups * (B * H * W * cin * es + cout * kh * kw * cin * es + m * cout * eo
                        + (m * cout * es if res is not None else 0))
-    return Launch(lib().icaf_conv2d, (C.byref(a),), keep=(a, x, w_packed, bias, y, res, pre), name=name, flops=flops,
+    if chain is not None:
+        flops += 2.0 * m * cout * chain["cout"] * groups
+        nbytes += groups * (m * chain["cout"] - m * cout) * eo      # y2 is written instead of y
+    return Launch(lib().icaf_conv2d, (C.byref(a),), keep=(a, x, w_packed, bias, y, res, pre, chain), name=name, flops=flops,
                   nbytes=nbytes)
 
 
@@ -182,7 +195,7 @@ CONV_PIPELINES = (0, 1, 2)        # LDS-DMA 64 B x3, register-staged, LDS-DMA 12
 
 def _conv_signature(a):
     return (a.B * a.Ho * a.Wo, a.Cout, a.Cin, a.kh, a.kw, a.sh, a.sw, a.H, a.W, a.ldx, a.ldy, a.groups, a.dtype,
-            a.out_dtype, a.act, bool(a.res), bool(a.pre))
+            a.out_dtype, a.act, bool(a.res), bool(a.pre), a.Cout2 if a.w2 else 0)
 
 
 def autotune_conv(launch, stream_ptr, reps=3):
@@ -194,21 +207,24 @@ def autotune_conv(launch, stream_ptr, reps=3):
         a.tile = _TUNE_CACHE[sig]
         return a.tile
     cands = []
-    if a.pre:                          # pre-activation term: built for tiles 128x128 / 128x64 on the LDS-DMA pipelines 0 / 2
+    if a.w2:                           # chained 1x1: one N tile covering both layers, LDS-DMA pipelines 0 / 2
+        t = 2 if max(a.Cout, a.Cout2) <= 64 else 1
+        cands = [t, t + 20]
+    elif a.pre:                          # pre-activation term: built for tiles 128x128 / 128x64 on the LDS-DMA pipelines 0 / 2
         cands = [t + 10 * pipe for pipe in (0, 2) for t in (1, 2) if not (t == 1 and (a.out_dtype == F32 or a.Cout <= 64))]
-    for pipe in (() if a.pre else CONV_PIPELINES):
+    for pipe in (() if (a.pre or a.w2) else CONV_PIPELINES):
         for t in (1, 2, 3, 4):
             if t == 1 and (a.out_dtype == F32 or a.Cout <= 64):
                 continue
             if t == 3 and a.Cout > 32:
                 continue
             cands.append(t + 10 * pipe)
-    if a.dtype != F32 and a.out_dtype == a.dtype and not a.pre:            # 8-wavefront tiles (128-byte LDS-DMA pipeline only)
+    if a.dtype != F32 and a.out_dtype == a.dtype and not a.pre and not a.w2:            # 8-wavefront tiles (128-byte LDS-DMA pipeline only)
         if a.Cout >= 128:
             cands.append(25)
         if a.Cout >= 256:
             cands.append(26)
-    if (a.kh, a.kw, a.ph, a.pw) == (3, 3, 1, 1) and a.act == ACT_SILU and a.out_dtype == a.dtype and not a.pre:
+    if (a.kh, a.kw, a.ph, a.pw) == (3, 3, 1, 1) and a.act == ACT_SILU and a.out_dtype == a.dtype and not a.pre and not a.w2:
         for shape, (bn, stride) in CTILE_SHAPES.items():       # 3x3 direct convolution from an LDS halo patch
             if a.sh == stride and a.sw == stride and a.Cout <= bn and (bn < 64 or a.Cout > bn // 2):
                 cands.append(40 + shape)

@@ -207,6 +207,52 @@ def test_fused_bottleneck_equals_two_launches(case, dt):
         close(from_act(y_f[g] if paired else y_f), ref, dt, f"bottleneck {case} stream {g}")
 
 
+CHAIN_CASES = [
+    # B, H, W, cin, c1 (3x3 layer out), c2 (chained 1x1 out), stride, tile, paired
+    (2, 40, 48, 32, 64, 64, 2, 0, False),      # backbone row 1 -> C3 cv1|cv2 (yolov5s)
+    (1, 33, 37, 64, 64, 48, 1, 22, True),      # ragged, narrower second layer
+    (2, 24, 24, 64, 128, 128, 2, 0, True),     # row 3 -> C3
+    (1, 20, 28, 128, 128, 96, 1, 21, False),
+    (1, 19, 23, 64, 96, 128, 1, 1, False),     # first layer narrower than the tile
+]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", CHAIN_CASES)
+def test_conv_with_chained_1x1_equals_two_launches(case, dt):
+    """3x3 conv + SiLU with a chained 1x1 conv + SiLU on the LDS-resident output tile (one launch, the intermediate tensor
+    never written) vs the two layers as separate launches: bit-identical, and close to fp32 torch."""
+    B, H, W, cin, c1, c2, st, tile, paired = case
+    G = 2 if paired else 1
+    xs = [rnd((B, cin, H, W), 81 + g) for g in range(G)]
+    w1 = [rnd((c1, cin, 3, 3), 83 + g, 1.0 / math.sqrt(9 * cin)) for g in range(G)]
+    w2 = [rnd((c2, c1, 1, 1), 85 + g, 1.0 / math.sqrt(c1)) for g in range(G)]
+    b1 = [rnd((c1,), 87 + g, 0.2) for g in range(G)]
+    b2 = [rnd((c2,), 89 + g, 0.2) for g in range(G)]
+    stk = (lambda ts: torch.stack(ts).contiguous()) if paired else (lambda ts: ts[0])
+    xa = stk([to_act(x, dt) for x in xs])
+    p1 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w1]
+    p2 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w2]
+    w1p, w2p = stk([p_[0] for p_ in p1]), stk([p_[0] for p_ in p2])
+    b1p, b2p = stk([ops.pack_bias(b.to(DEV), c1) for b in b1]), stk([ops.pack_bias(b.to(DEV), c2) for b in b2])
+    Ho, Wo = (H + 2 - 3) // st + 1, (W + 2 - 3) // st + 1
+    shp = (G, B, Ho, Wo) if paired else (B, Ho, Wo)
+    mid = torch.zeros((*shp, c1), dtype=dt, device=DEV)
+    y_u = torch.zeros((*shp, c2 + 8), dtype=dt, device=DEV)[..., :c2]
+    y_f = torch.zeros((*shp, c2 + 8), dtype=dt, device=DEV)[..., :c2]
+    run(ops.conv2d(xa, w1p, p1[0][1], b1p, mid, 3, 3, st, st, 1, 1, cin, c1, ops.ACT_SILU))
+    run(ops.conv2d(mid, w2p, p2[0][1], b2p, y_u, 1, 1, 1, 1, 0, 0, c1, c2, ops.ACT_SILU))
+    dummy = torch.zeros((*shp, c1), dtype=dt, device=DEV)
+    run(ops.conv2d(xa, w1p, p1[0][1], b1p, dummy, 3, 3, st, st, 1, 1, cin, c1, ops.ACT_SILU, tile=tile,
+                   chain=dict(w=w2p, kp=p2[0][1], bias=b2p, y=y_f, cout=c2)))
+    assert float(dummy.abs().max()) == 0.0, "the intermediate tensor must not be written"
+    assert torch.equal(y_f, y_u)
+    for g in range(G):
+        t = q(F.silu(F.conv2d(q(xs[g], dt), q(w1[g], dt), b1[g], st, 1)), dt)
+        ref = F.silu(F.conv2d(t, q(w2[g], dt), b2[g]))
+        close(from_act(y_f[g] if paired else y_f), ref, dt, f"chain {case} stream {g}")
+
+
 def test_conv3x3_halo_tile_rejects_other_layers():
     x = torch.zeros((1, 8, 8, 32), dtype=torch.bfloat16, device=DEV)
     w = rnd((32, 32, 1, 1), 1)
