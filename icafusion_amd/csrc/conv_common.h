@@ -17,7 +17,7 @@ struct ConvP {
     const void* w1; const float* bias1;            // fused Bottleneck (ctile.hip, FUSE1): the 1x1 convolution in front
     long long w1_gs, bias1_gs; int Kp1; unsigned int w1_bytes;
     const void* w2; const float* bias2; void* y2;  // chained 1x1 convolution behind this layer (igemm.hip, CHAIN)
-    long long w2_gs, bias2_gs, y2_gs; int Kp2, Cout2, ldy2, vec_y2; unsigned int w2_bytes;
+    long long w2_gs, bias2_gs, y2_gs; int Kp2, Cout2, ldy2, vec_y2, keep1; unsigned int w2_bytes;
 };
 
 constexpr int ROWB = 64;        // bytes of K per LDS row per slice

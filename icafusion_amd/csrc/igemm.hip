@@ -237,25 +237,30 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(c
         static_assert(DT != ICAF_F32 && ODT == DT && ACT == ICAF_ACT_SILU && !PRE, "chained 1x1: 16-bit SiLU layers");
         constexpr int SO = BN * E::BYTES + 16;     // staging row stride (as the epilogue's)
         const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
-        // (a) this layer's output tile -> LDS, rounded to the storage type
+        // (a) this layer's output tile -> LDS, rounded to the storage type (and, with keep1, written to y by the ordinary
+        //     epilogue, whose staged tile is the same thing)
+        if (p.keep1) {
+            epilogue<DT, ODT, BM, BN, WM, WN, ICAF_ACT_SILU, false>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, 0);
+        } else {
 #pragma unroll
-        for (int a = 0; a < TN; ++a)
+            for (int a = 0; a < TN; ++a)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (bias && nl < p.Cout) bv = *(const f32x4*)(bias + nl);
+                for (int q = 0; q < 4; ++q) {
+                    const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (bias && nl < p.Cout) bv = *(const f32x4*)(bias + nl);
 #pragma unroll
-                for (int b = 0; b < TM; ++b) {
-                    float v[4];
+                    for (int b = 0; b < TM; ++b) {
+                        float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = silu_f(acc[a][b][4 * q + j] + bv[j]);
-                    u32x2 pk;
-                    if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
-                    else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
-                    *(u32x2*)(lds + (wm * WM + b * 32 + l31) * SO + nl * E::BYTES) = pk;
+                        for (int j = 0; j < 4; ++j) v[j] = silu_f(acc[a][b][4 * q + j] + bv[j]);
+                        u32x2 pk;
+                        if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
+                        else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
+                        *(u32x2*)(lds + (wm * WM + b * 32 + l31) * SO + nl * E::BYTES) = pk;
+                    }
                 }
-            }
+        }
         __syncthreads();
         // (b) y2 tile = W2 . tile: pixels are the rows of the staged tile, K = its BN channels
 #pragma unroll
@@ -496,7 +501,7 @@ static int launch_dma(const ConvP& q, dim3 grid, hipStream_t s) {
                       ((BM / WM) * (BN / WN) == 4 ? BM == 128 : BN == 256)) {
             constexpr int lds_need = (NS * (BM + BN) * RB > TileLds<DT, ODT, BM, BN>::OUT_BYTES ? NS * (BM + BN) * RB : TileLds<DT, ODT, BM, BN>::OUT_BYTES) + 1024 + BN * BN * 2;
             if constexpr (lds_need <= 160 * 1024) {
-                if (whole_taps && q.Cout <= BN && q.Cout2 <= BN && !q.pre && !q.res)
+                if (whole_taps && q.Cout <= BN && q.Cout2 <= BN && !q.pre && !q.res && (!q.keep1 || (q.alpha_acc[0] == 1.0f && q.alpha_acc[1] == 1.0f)))
                     return launch_dma_mode<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, 2, false, true>(q, grid, s);
             }
         }
@@ -631,7 +636,7 @@ static void fill(const icaf_conv_args* a, ConvP& p) {
     p.pre = a->pre; p.pre_h = a->pre_h; p.pre_w = a->pre_w; p.ldpre = a->ldpre;
     p.w1 = nullptr; p.bias1 = nullptr; p.w1_gs = p.bias1_gs = 0; p.Kp1 = 0; p.w1_bytes = 0;
     p.w2 = a->w2; p.bias2 = a->bias2; p.y2 = a->y2; p.w2_gs = a->w2_gs; p.bias2_gs = a->bias2_gs; p.y2_gs = a->y2_gs;
-    p.Kp2 = a->Kp2; p.Cout2 = a->Cout2; p.ldy2 = a->ldy2;
+    p.Kp2 = a->Kp2; p.Cout2 = a->Cout2; p.ldy2 = a->ldy2; p.keep1 = a->chain_keep;
     p.vec_y2 = a->w2 && (a->ldy2 % vo == 0) && (((uintptr_t)a->y2 & 15) == 0) && ((a->y2_gs * yb) % 16 == 0);
     p.w2_bytes = a->w2 ? (unsigned)((((long long)a->Cout2 + 127) / 128 * 128) * a->Kp2 * eb) : 0;
 }

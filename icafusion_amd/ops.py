@@ -154,6 +154,7 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
         a.w2, a.y2 = chain["w"].data_ptr(), y2.data_ptr()
         a.bias2 = chain["bias"].data_ptr() if chain.get("bias") is not None else None
         a.Kp2, a.Cout2, a.ldy2 = chain["kp"], chain["cout"], ldy2
+        a.chain_keep = int(bool(chain.get("keep")))
         if x.dim() == 5:
             a.w2_gs, a.y2_gs = chain["w"].stride(0), y2.stride(0)
             a.bias2_gs = chain["bias"].stride(0) if chain.get("bias") is not None else 0
@@ -164,7 +165,7 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
                        + (m * cout * es if res is not None else 0))
     if chain is not None:
         flops += 2.0 * m * cout * chain["cout"] * groups
-        nbytes += groups * (m * chain["cout"] - m * cout) * eo      # y2 is written instead of y
+        nbytes += groups * (m * chain["cout"] - (0 if chain.get("keep") else m * cout)) * eo      # y2 is written instead of / besides y
     return Launch(lib().icaf_conv2d, (C.byref(a),), keep=(a, x, w_packed, bias, y, res, pre, chain), name=name, flops=flops,
                   nbytes=nbytes)
 
@@ -195,7 +196,7 @@ CONV_PIPELINES = (0, 1, 2)        # LDS-DMA 64 B x3, register-staged, LDS-DMA 12
 
 def _conv_signature(a):
     return (a.B * a.Ho * a.Wo, a.Cout, a.Cin, a.kh, a.kw, a.sh, a.sw, a.H, a.W, a.ldx, a.ldy, a.groups, a.dtype,
-            a.out_dtype, a.act, bool(a.res), bool(a.pre), a.Cout2 if a.w2 else 0)
+            a.out_dtype, a.act, bool(a.res), bool(a.pre), a.Cout2 if a.w2 else 0, bool(a.chain_keep))
 
 
 def autotune_conv(launch, stream_ptr, reps=3):

@@ -104,7 +104,7 @@ typedef struct icaf_conv_args {
     int pre_h, pre_w, ldpre;
     /* Optional chained 1x1 convolution + SiLU consuming this layer's output tile in place (w2 != NULL):
      *   y2 = SiLU( W2 . SiLU(A.W + bias) + bias2 )        [this layer must be SiLU, 16-bit, one N tile: Cout <= 256]
-     * The intermediate tensor is never written (y is ignored).  It is how a backbone down-sampling Conv and the fused
+     * The intermediate tensor is never written (y is ignored) unless chain_keep is set.  It is how a backbone down-sampling Conv and the fused
      * cv1|cv2 GEMM of the C3 block behind it (models/common.py:56-60 then :226) run as one launch.
      * w2: packed [Np][Kp2] with K = Cout, bias2 may be NULL, y2: NHWC with pixel stride ldy2, Cout2 <= 256 channels. */
     const void* w2;
@@ -112,6 +112,7 @@ typedef struct icaf_conv_args {
     void* y2;
     long long w2_gs, bias2_gs, y2_gs;
     int Kp2, Cout2, ldy2;
+    int chain_keep; /* != 0: y IS written as well (e.g. C3's cv1|cv2 output, whose first half also feeds the chained 1x1) */
 } icaf_conv_args;
 
 int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s);

@@ -247,6 +247,10 @@ def test_conv_with_chained_1x1_equals_two_launches(case, dt):
                    chain=dict(w=w2p, kp=p2[0][1], bias=b2p, y=y_f, cout=c2)))
     assert float(dummy.abs().max()) == 0.0, "the intermediate tensor must not be written"
     assert torch.equal(y_f, y_u)
+    y_k = torch.zeros_like(y_f)
+    run(ops.conv2d(xa, w1p, p1[0][1], b1p, dummy, 3, 3, st, st, 1, 1, cin, c1, ops.ACT_SILU, tile=tile,
+                   chain=dict(w=w2p, kp=p2[0][1], bias=b2p, y=y_k, cout=c2, keep=True)))
+    assert torch.equal(dummy, mid) and torch.equal(y_k, y_u), "chain_keep writes both layers' outputs"
     for g in range(G):
         t = q(F.silu(F.conv2d(q(xs[g], dt), q(w1[g], dt), b1[g], st, 1)), dt)
         ref = F.silu(F.conv2d(t, q(w2[g], dt), b2[g]))
