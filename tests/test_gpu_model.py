@@ -170,6 +170,20 @@ def test_fused_bottleneck_model_matches_two_launch_model(dtype):
     assert (outs[0][..., 4:] - outs[1][..., 4:]).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 3e-3)
 
 
+def test_reference_style_half_model_and_half_inputs():
+    """`model.half()` + `img.half()` exactly as detect_twostream.py:33-40,73-80 / test.py:73-75,116-118 drive the model."""
+    cfg, sd, m32 = build("yolov5s_Transfusion_kaist.yaml", 9)
+    rgb, ir = synth_images(1, 320, 320, seed=9)
+    z32 = m32(rgb.cuda(), ir.cuda())[0]
+    cfg, sd, mh = build("yolov5s_Transfusion_kaist.yaml", 9)
+    mh = mh.half()
+    assert next(mh.parameters()).dtype == torch.float16 and mh.model[-1].anchor_grid.dtype == torch.float32
+    zh = mh(rgb.cuda().half(), ir.cuda().half())[0]
+    assert zh.dtype == torch.float32 and torch.isfinite(zh).all()
+    assert (zh[..., :4] - z32[..., :4]).abs().max().item() <= 2.0            # pixels (fp16 weights + activations)
+    assert (zh[..., 4:] - z32[..., 4:]).abs().max().item() <= 1e-2
+
+
 def test_graph_replay_equals_eager():
     cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", seed=1, dtype=torch.bfloat16)
     rgb, ir = synth_images(2, 320, 320, seed=1)
