@@ -418,11 +418,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
 // ---------------------------------------------------------------------------------------------------------------
 struct TileCfg { int id, bm, bn; const char* tag; };
 static const TileCfg kTiles[] = {{1, 128, 128, "128x128"}, {2, 128, 64, "128x64"}, {3, 256, 32, "256x32"}, {4, 64, 64, "64x64"},
-                                 {5, 256, 128, "256x128"}, {6, 256, 256, "256x256"}};
+                                 {5, 256, 128, "256x128"}, {6, 256, 256, "256x256"}, {7, 0, 0, "-"}, {8, 128, 128, "128x128w8"},
+                                 {9, 128, 64, "128x64w8"}};
 
 // Launch configuration id = tile (1..4) + 10 * pipeline:
 //   pipeline 0: LDS-DMA, 64-byte slices, 3-stage ring      pipeline 1: register-staged (fallback)
 //   pipeline 2: LDS-DMA, 128-byte slices, 2-stage ring     pipeline 3: LDS-DMA, 128-byte slices, 3-stage ring
+// Tiles 8 (128x128) and 9 (128x64) are the 128-row tiles with 8 wavefronts (the tuner uses 8: +1.3 % on the forward; 9 wins
+// isolated timings but loses in the graph, where it competes with the DMFF branches for wave slots, so it is not a candidate).
 // Tiles 5 (256x128) and 6 (256x256) are 8-wavefront workgroups (one per CU, 96 / 128 KB ring) that exist only on
 // pipeline 2 for the 16-bit types: they halve the L2 -> LDS bytes per FLOP of the 128x128 tile, which is what bounds
 // the deep layers (the LDS-DMA feed tops out near 20 bytes / clock / CU).
@@ -441,7 +444,7 @@ static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
         const int pipe = a->tile / 10;
         return (pipe != 1 && !dma_ok) ? a->tile % 10 + 10 : a->tile;
     }
-    if (a->tile == 25 || a->tile == 26) return a->tile;          // validated in launch_tile
+    if (a->tile == 25 || a->tile == 26 || a->tile == 28 || a->tile == 29) return a->tile;          // validated in launch_tile
     const bool f32 = a->dtype == ICAF_F32 || a->out_dtype == ICAF_F32;
     const int N = a->Cout;
     const long long M = p.M;
@@ -574,6 +577,13 @@ static int launch_tile(const ConvP& p, int groups, int cfg, hipStream_t s) {
         case 2: return launch_cfg<DT, ODT, 128, 64, 64, 32>(p, groups, pipe, s);
         case 3: return launch_cfg<DT, ODT, 256, 32, 64, 32>(p, groups, pipe, s);
         case 4: return launch_cfg<DT, ODT, 64, 64, 32, 32>(p, groups, pipe, s);
+        case 8:                                       // 128x128 / 128x64 tiles with 8 wavefronts (64x32 / 32x32 each): more waves
+        case 9:                                       // per SIMD to hide latency, same LDS footprint as the 4-wave tiles
+            if constexpr (DT == ICAF_F32 || ODT == ICAF_F32) return fail(ICAF_ERR_UNSUPPORTED, "8-wavefront 128-row tiles exist for 16-bit types only");
+            else {
+                if (pipe != 2 || p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "8-wavefront 128-row tiles run on pipeline 2 only (ids 28 / 29)");
+                return cfg % 10 == 8 ? launch_big<DT, ODT, 128, 128, 64, 32>(p, groups, s) : launch_big<DT, ODT, 128, 64, 32, 32>(p, groups, s);
+            }
         case 5:
         case 6:
             if constexpr (DT == ICAF_F32 || ODT == ICAF_F32) return fail(ICAF_ERR_UNSUPPORTED, "tiles 256x128 / 256x256 exist for 16-bit types only");

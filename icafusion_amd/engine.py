@@ -77,7 +77,9 @@ class Plan:
         fn = ops.lib().icaf_conv2d
         for l in self.launches:             # one untimed pass first: lazy module load, attribute setup
             l(sp)
-        return [ops.autotune_conv(l, sp) for l in self.launches if l.fn is fn]
+        # in situ: each candidate is timed right after a replay of the (up to) 6 launches in front of the layer
+        return [ops.autotune_conv(l, sp, context=self.launches[max(0, i - 6):i])
+                for i, l in enumerate(self.launches) if l.fn is fn]
 
     def capture(self):
         """Capture the launch list into a hipGraph on side streams (the legacy default stream cannot capture); launches

@@ -199,9 +199,12 @@ def _conv_signature(a):
             a.out_dtype, a.act, bool(a.res), bool(a.pre), a.Cout2 if a.w2 else 0, bool(a.chain_keep))
 
 
-def autotune_conv(launch, stream_ptr, reps=3):
+def autotune_conv(launch, stream_ptr, reps=3, context=()):
     """Time every (tile, pipeline) configuration of one recorded conv launch on the device and keep the fastest.
-    All configurations walk K in the same order, so the result is bit-identical whichever is picked."""
+    All configurations walk K in the same order, so the result is bit-identical whichever is picked.
+    context: the launches that precede this one in its plan — replayed (untimed) before every timed launch so that L2 /
+    MALL hold what they hold in the real forward (the layer's input freshly written by its producers, not the layer's
+    own previous run); timing a layer against itself back to back ranks the candidates wrongly at the margin."""
     a = launch.keep[0]
     sig = _conv_signature(a)
     if sig in _TUNE_CACHE:
@@ -223,6 +226,7 @@ def autotune_conv(launch, stream_ptr, reps=3):
     if a.dtype != F32 and a.out_dtype == a.dtype and not a.pre and not a.w2:            # 8-wavefront tiles (128-byte LDS-DMA pipeline only)
         if a.Cout >= 128:
             cands.append(25)
+            cands.append(28)
         if a.Cout >= 256:
             cands.append(26)
     if (a.kh, a.kw, a.ph, a.pw) == (3, 3, 1, 1) and a.act == ACT_SILU and a.out_dtype == a.dtype and not a.pre and not a.w2:
@@ -236,11 +240,21 @@ def autotune_conv(launch, stream_ptr, reps=3):
         st = launch.fn(*launch.args, stream_ptr)
         if st != 0:
             continue
-        e0.record(stream_ptr)
-        for _ in range(reps):
-            launch.fn(*launch.args, stream_ptr)
-        e1.record(stream_ptr)
-        ms = e0.elapsed_ms(e1)
+        if context:
+            ms = 0.0
+            for _ in range(reps):
+                for l in context:
+                    l(stream_ptr)
+                e0.record(stream_ptr)
+                launch.fn(*launch.args, stream_ptr)
+                e1.record(stream_ptr)
+                ms += e0.elapsed_ms(e1)
+        else:
+            e0.record(stream_ptr)
+            for _ in range(reps):
+                launch.fn(*launch.args, stream_ptr)
+            e1.record(stream_ptr)
+            ms = e0.elapsed_ms(e1)
         if ms < best_ms:
             best, best_ms = c, ms
     a.tile = best

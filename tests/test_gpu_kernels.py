@@ -82,6 +82,11 @@ CONV_CASES = [
     (2, 23, 29, 48, 160, 3, 1, 1, ops.ACT_SILU, True, 32),
     (1, 20, 20, 24, 32, 3, 1, 1, ops.ACT_SILU, False, 33),
     (1, 13, 13, 72, 40, 3, 2, 1, ops.ACT_SILU, False, 34),
+    # 8-wavefront 128-row tiles (ids 28 / 29)
+    (2, 20, 20, 128, 256, 3, 1, 1, ops.ACT_SILU, True, 28),
+    (1, 23, 29, 64, 136, 3, 2, 1, ops.ACT_GELU, True, 28),
+    (1, 33, 17, 64, 96, 3, 1, 1, ops.ACT_SILU, True, 29),
+    (2, 40, 40, 128, 40, 1, 1, 0, ops.ACT_NONE, False, 29),
     # 8-wavefront tiles 256x128 / 256x256 (16-bit types; the fp32 run of these rows falls back to tile 2)
     (2, 20, 20, 128, 256, 3, 1, 1, ops.ACT_SILU, True, 25),
     (1, 40, 40, 64, 136, 1, 1, 0, ops.ACT_GELU, True, 25),      # ragged N on the 256x128 tile
@@ -96,7 +101,7 @@ def test_conv2d(case, dt):
     B, H, W, cin, cout, k, s, p, act, use_res, tile = case
     if tile % 10 == 1 and dt == torch.float32:
         tile += 1
-    if tile in (25, 26) and dt == torch.float32:
+    if tile in (25, 26, 28, 29) and dt == torch.float32:
         tile = 2
     x = rnd((B, cin, H, W), 1)
     w = rnd((cout, cin, k, k), 2, 1.0 / math.sqrt(cin * k * k))
