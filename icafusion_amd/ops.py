@@ -199,17 +199,9 @@ def _conv_signature(a):
             a.out_dtype, a.act, bool(a.res), bool(a.pre), a.Cout2 if a.w2 else 0, bool(a.chain_keep))
 
 
-def autotune_conv(launch, stream_ptr, reps=3, context=()):
-    """Time every (tile, pipeline) configuration of one recorded conv launch on the device and keep the fastest.
-    All configurations walk K in the same order, so the result is bit-identical whichever is picked.
-    context: the launches that precede this one in its plan — replayed (untimed) before every timed launch so that L2 /
-    MALL hold what they hold in the real forward (the layer's input freshly written by its producers, not the layer's
-    own previous run); timing a layer against itself back to back ranks the candidates wrongly at the margin."""
-    a = launch.keep[0]
-    sig = _conv_signature(a)
-    if sig in _TUNE_CACHE:
-        a.tile = _TUNE_CACHE[sig]
-        return a.tile
+def conv_candidates(a):
+    """Launch-configuration ids worth timing for one conv (ConvArgs `a`): igemm tiles x pipelines, the 8-wavefront tiles,
+    the 3x3 halo-patch kernel; chained / pre-term launches only have the configurations that are built for them."""
     cands = []
     if a.w2:                           # chained 1x1: one N tile covering both layers, LDS-DMA pipelines 0 / 2
         t = 2 if max(a.Cout, a.Cout2) <= 64 else 1
@@ -233,6 +225,21 @@ def autotune_conv(launch, stream_ptr, reps=3, context=()):
         for shape, (bn, stride) in CTILE_SHAPES.items():       # 3x3 direct convolution from an LDS halo patch
             if a.sh == stride and a.sw == stride and a.Cout <= bn and (bn < 64 or a.Cout > bn // 2):
                 cands.append(40 + shape)
+    return cands
+
+
+def autotune_conv(launch, stream_ptr, reps=3, context=()):
+    """Time every (tile, pipeline) configuration of one recorded conv launch on the device and keep the fastest.
+    All configurations walk K in the same order, so the result is bit-identical whichever is picked.
+    context: the launches that precede this one in its plan — replayed (untimed) before every timed launch so that L2 /
+    MALL hold what they hold in the real forward (the layer's input freshly written by its producers, not the layer's
+    own previous run); timing a layer against itself back to back ranks the candidates wrongly at the margin."""
+    a = launch.keep[0]
+    sig = _conv_signature(a)
+    if sig in _TUNE_CACHE:
+        a.tile = _TUNE_CACHE[sig]
+        return a.tile
+    cands = conv_candidates(a)
     best, best_ms = 0, float("inf")
     e0, e1 = Event(), Event()
     for c in cands:
