@@ -129,6 +129,10 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
 
     const int gsh = 4 - lsp, smask = SP - 1;
     const int cin_slots_mask = smask;                                  // Cin * BYTES / 16 - 1
+    // weight-ring prologue first: with FUSE1 its L2 round trip then overlaps the 1x1 stage instead of following it
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_w(s, s);
+
     if constexpr (FUSE1) {
         static_assert(DT != ICAF_F32 && S == 1, "the fused Bottleneck exists for the 16-bit types, stride 1");
         // ---- 1x1 convolution + SiLU over every entry of the halo patch -> second patch --------------------------------
@@ -188,9 +192,6 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
         }
         // (the first barrier of the 3x3 loop below makes the second patch visible)
     }
-
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue_w(s, s);
 
     for (int c = 0; c < p.nchunks; ++c) {
         wait_vmcnt<(NS - 2) * NBW>();              // slice c (and, for c = 0, the halo patch issued before it) landed
