@@ -184,6 +184,34 @@ def test_reference_style_half_model_and_half_inputs():
     assert (zh[..., 4:] - z32[..., 4:]).abs().max().item() <= 1e-2
 
 
+@pytest.mark.parametrize("shape", [(1, 320, 320), (3, 352, 416), (2, 640, 512), (5, 384, 640)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_all_fusions_on_vs_off_across_shapes(shape, dtype):
+    """Every plan-level optimisation (paired streams, persistent stem, fused Bottleneck, chained Conv -> C3, fused DMFF
+    tail, graph branches + hipGraph replay) against the plain launch-per-layer plan, on batch sizes and image sizes that
+    leave ragged patches / tiles everywhere.  16-bit results agree to rounding noise (cv3 sums K in another order)."""
+    from icafusion_amd.models.common import Bottleneck
+    B, H, W = shape
+    cfg, sd, m = build("yolov5s_Transfusion_FLIR.yaml", 13, dtype)
+    rgb, ir = synth_images(B, H, W, seed=13)
+    outs = []
+    for on in (True, False):
+        Conv.fuse_stem = Conv.chain_fuse = Bottleneck.fuse = on
+        m.pair_streams = m.branch_dmff = m.use_graph = on
+        for i in (20, 21, 22):
+            m.model[i].fuse_tail = on
+        m.invalidate()
+        names = [l.name for l in m.plan_for(B, H, W).launches]
+        assert ("stem" in names) == on and (any(n.endswith("+1x1") for n in names)) == on
+        outs.append(m(rgb.cuda(), ir.cuda())[0].float())
+    Conv.fuse_stem = Conv.chain_fuse = Bottleneck.fuse = True
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    scale = outs[1][..., :4].abs().max().item()
+    assert torch.isfinite(outs[0]).all()
+    assert (outs[0][..., :4] - outs[1][..., :4]).abs().max().item() <= tol * scale
+    assert (outs[0][..., 4:] - outs[1][..., 4:]).abs().max().item() <= tol
+
+
 def test_graph_replay_equals_eager():
     cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", seed=1, dtype=torch.bfloat16)
     rgb, ir = synth_images(2, 320, 320, seed=1)
