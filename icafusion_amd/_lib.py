@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libicaf.so")
+LIB_PATH = os.environ.get("ICAF_LIB") or os.path.join(_HERE, "lib", "libicaf.so")   # ICAF_LIB: A/B a variant build (tools/)
 
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
@@ -37,6 +37,18 @@ class BneckArgs(C.Structure):
                 ("bias1_gs", C.c_longlong), ("Kp1", C.c_int), ("shape", C.c_int)]
 
 
+class Stem2Args(C.Structure):
+    _fields_ = [("img", C.c_void_p), ("img_u8", C.c_int), ("ctot", C.c_int),
+                ("dtype", C.c_int), ("nstreams", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("w0", C.c_void_p), ("bias0", C.c_void_p), ("w0_gs", C.c_longlong), ("bias0_gs", C.c_longlong),
+                ("Kp0", C.c_int), ("C0", C.c_int),
+                ("w1", C.c_void_p), ("bias1", C.c_void_p), ("w1_gs", C.c_longlong), ("bias1_gs", C.c_longlong),
+                ("Kp1", C.c_int), ("C1", C.c_int),
+                ("w2", C.c_void_p), ("bias2", C.c_void_p), ("w2_gs", C.c_longlong), ("bias2_gs", C.c_longlong),
+                ("Kp2", C.c_int), ("C2", C.c_int),
+                ("y", C.c_void_p), ("y_gs", C.c_longlong), ("ldy", C.c_int), ("reserved", C.c_int)]
+
+
 _p, _i, _ll, _f, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 # symbol -> (restype, argtypes); must list every function declared in include/icaf.h
 SIGNATURES = {
@@ -46,6 +58,7 @@ SIGNATURES = {
     "icaf_preprocess_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_preprocess_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_stem": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _p]),
+    "icaf_stem2": (_i, [C.POINTER(Stem2Args), _p]),
     "icaf_conv2d": (_i, [C.POINTER(ConvArgs), _p]),
     "icaf_bottleneck": (_i, [C.POINTER(BneckArgs), _p]),
     "icaf_conv2d_kernel_name": (_i, [C.POINTER(ConvArgs), C.c_char_p, _i]),

@@ -48,7 +48,7 @@ def build(force=False, verbose=True):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "icaf.h"))
     srcs = sources()
-    stamp = os.path.join(LIBDIR, "libicaf.stamp")
+    stamp = LIB[:-3] + ".stamp"
     want = _digest([os.path.join(CSRC, s) for s in srcs] + headers, " ".join(COMMON) + repr(sorted(PER_FILE.items())))
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         if verbose:

@@ -85,14 +85,22 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
     }
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
+        // The four bias quads of this 32-channel block are fetched as ONE batch, unconditionally (clamped address +
+        // select): a load inside the q loop is a load -> wait -> use chain, i.e. four dependent L2 round trips per block
+        // at the end of every workgroup.  (All TN blocks at once would hold 16 * TN more registers next to acc.)
+        f32x4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * WN + a * 32 + 8 * q + 4 * hi;
+            const bool okn = bias && n < Cout;         // (the packed bias is padded to a multiple of 128 >= Cout only)
+            const float* bp = okn ? bias + n : (const float*)p.w;      // (any mapped address: the value is discarded)
+            const f32x4 t = *(const f32x4*)bp;
+            bq[q] = okn ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;      // tile-local channel of this register quad
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias && n0 + nl < Cout) {          // (the packed bias is padded to a multiple of 128 >= Cout only)
-                const f32x4 t = *(const f32x4*)(bias + n0 + nl);
-                bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
-            }
+            const float bv[4] = {bq[q][0], bq[q][1], bq[q][2], bq[q][3]};
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
                 const int ml = wm * WM + b * 32 + l31;
@@ -100,11 +108,14 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
                 if constexpr (PRE) if (n0 + nl < Cout) {
                     const f32x4 t00 = *(const f32x4*)(pt[b][0] + n0 + nl), t01 = *(const f32x4*)(pt[b][1] + n0 + nl);
                     const f32x4 t10 = *(const f32x4*)(pt[b][2] + n0 + nl), t11 = *(const f32x4*)(pt[b][3] + n0 + nl);
+                    // explicit fma sequence: left to the compiler's contraction, different instantiations (tiles) fused
+                    // these products differently and the same layer rounded differently from one tile shape to the next
+                    const float wx0 = 1.0f - plx[b], wy0 = 1.0f - ply[b];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float top = t00[j] * (1.0f - plx[b]) + t01[j] * plx[b];
-                        const float bot = t10[j] * (1.0f - plx[b]) + t11[j] * plx[b];
-                        pv[j] = top * (1.0f - ply[b]) + bot * ply[b];
+                        const float top = __builtin_fmaf(t01[j], plx[b], t00[j] * wx0);
+                        const float bot = __builtin_fmaf(t11[j], plx[b], t10[j] * wx0);
+                        pv[j] = __builtin_fmaf(bot, ply[b], top * wy0);
                     }
                 }
                 float v[4];
@@ -128,7 +139,26 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
     const typename E::type* __restrict__ rg = (!SECOND && p.res) ? (const typename E::type*)p.res + g * p.res_gs : nullptr;
     constexpr int VPR = BN / VO;                       // 16-byte vectors per staged row
     constexpr int NVEC = BM * VPR;
-    for (int idx = tid; idx < NVEC; idx += NT) {
+    constexpr int NIT = (NVEC + NT - 1) / NT;
+    // residual vectors of all of this thread's output vectors first (one batch of loads in flight instead of a
+    // load -> wait -> add -> store chain per vector)
+    u32x4 rvec[NIT];
+    bool rfast[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        rfast[it] = false;
+        if constexpr (VO == E::VEC) {
+            const int idx = tid + it * NT;
+            const int row = idx / VPR, cv = idx - row * VPR;
+            const int m = idx < NVEC ? row_to_m(row) : -1, n = n0 + cv * VO;
+            rfast[it] = rg && p.vec_r && m >= 0 && n + VO <= Cout;
+            if (rfast[it]) rvec[it] = *(const u32x4*)(rg + (long long)m * p.ldr + n);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NT;
+        if (idx >= NVEC) break;
         const int row = idx / VPR, cv = idx - row * VPR;
         const int m = row_to_m(row), n = n0 + cv * VO;
         if (m < 0 || n >= Cout) continue;
@@ -142,16 +172,16 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
         unpack16<ODT>(sv, v);
         if (rg) {
             const typename E::type* rp = rg + (long long)m * p.ldr + n;
-            if (p.vec_r && nvalid == VO) {
+            if (rfast[it]) {
                 if constexpr (VO == E::VEC) {
                     float r[VO];
-                    unpack16<DT>(*(const u32x4*)rp, r);
+                    unpack16<DT>(rvec[it], r);
 #pragma unroll
                     for (int j = 0; j < VO; ++j) v[j] += alpha_res * r[j];
-                } else {            // fp32 output of a 16-bit residual
-#pragma unroll
-                    for (int j = 0; j < VO; ++j) v[j] += alpha_res * E::ld(rp + j);
                 }
+            } else if (p.vec_r && nvalid == VO) {   // fp32 output of a 16-bit residual
+#pragma unroll
+                for (int j = 0; j < VO; ++j) v[j] += alpha_res * E::ld(rp + j);
             } else {
                 for (int j = 0; j < nvalid; ++j) v[j] += alpha_res * E::ld(rp + j);
             }
@@ -199,6 +229,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 using lds_ptr_t = __attribute__((address_space(3))) void*;
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (global loads and stores share that
+// counter on gfx9), which would stall a register prefetch of the next tile at every barrier of the current one.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 
 }  // namespace icaf

@@ -146,7 +146,15 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
         }
         wait_vmcnt<0>();
         __syncthreads();                                               // input patch + 1x1 weights visible
-        const float* __restrict__ bias1 = p.bias1 ? p.bias1 + g * p.bias1_gs : nullptr;
+        // the 1x1's bias in registers: loaded inside the loop below it would be a dependent L2 round trip per use
+        f32x4 b1r[TN][4];
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                b1r[a][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias1) b1r[a][q] = *(const f32x4*)(p.bias1 + g * p.bias1_gs + a * 32 + 8 * q + 4 * hi);
+            }
         const int nidx = HH * PITCH, nsub = (nidx + 31) >> 5;
         const int gy0 = y0 - 1, gx0 = x0 - 1;
         for (int j = wave; j < nsub; j += 4) {
@@ -177,10 +185,8 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
                         const int nl = a * 32 + 8 * q + 4 * hi;        // channel of this register quad
                         float v[4] = {0.f, 0.f, 0.f, 0.f};
                         if (inside) {
-                            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                            if (bias1) bv = *(const f32x4*)(bias1 + nl);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = silu_f(a1[a][4 * q + e] + bv[e]);
+                            for (int e = 0; e < 4; ++e) v[e] = silu_f(a1[a][4 * q + e] + b1r[a][q][e]);
                         }
                         u32x2 pk;
                         if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }

@@ -242,13 +242,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(c
         if (p.keep1) {
             epilogue<DT, ODT, BM, BN, WM, WN, ICAF_ACT_SILU, false>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, 0);
         } else {
+            f32x4 bvr[TN][4];                      // all bias quads in one batch of loads (see conv_common.h: epilogue)
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;
-                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                    if (bias && nl < p.Cout) bv = *(const f32x4*)(bias + nl);
+                    const bool okn = nl < p.Cout;
+                    bvr[a][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (bias) {
+                        const f32x4 t = *(const f32x4*)(bias + (okn ? nl : 0));
+                        bvr[a][q] = okn ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;
+                    const f32x4 bv = bvr[a][q];
 #pragma unroll
                     for (int b = 0; b < TM; ++b) {
                         float v[4];

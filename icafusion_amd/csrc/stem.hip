@@ -29,39 +29,84 @@ struct StemP {
     ConvP c;                    // y, bias, w, strides, Ho, Wo, Cout, ldy, Kp, alphas (the epilogue's view of the layer)
 };
 
-// 12 image values of one space-to-depth entry: (dy, dx, c) = 2x2 pixels x 3 channels; zero outside the image
-template <bool U8>
-__device__ __forceinline__ void load_entry(const StemP& q, int stream, int b, int gy, int gx, float (&v)[12]) {
-    const bool in = (unsigned)gy < (unsigned)(q.H >> 1) && (unsigned)gx < (unsigned)(q.W >> 1);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) v[i] = 0.0f;
-    if (!in) return;
+// One space-to-depth entry = 2x2 pixels x 3 channels.  The six 2-pixel loads are issued UNCONDITIONALLY from
+// coordinates clamped into the image and kept raw: no control flow or conversion depends on them, so they stay in
+// flight until finish_entry() — called one tile later — turns them into the 12 values (zero outside the image).
+template <bool U8> struct RawEntry;
+template <> struct RawEntry<false> { float2 r[6]; bool in; };
+template <> struct RawEntry<true> { unsigned short r[6]; bool in; };
+
+template <bool U8, class P>
+__device__ __forceinline__ void load_entry(const P& q, int stream, int b, int gy, int gx, RawEntry<U8>& e) {
+    const int hh = q.H >> 1, hw = q.W >> 1;
+    e.in = (unsigned)gy < (unsigned)hh && (unsigned)gx < (unsigned)hw;
+    const int cy = min(max(gy, 0), hh - 1), cx = min(max(gx, 0), hw - 1);
     const long long plane = (long long)q.H * q.W;
+    // wave-uniform plane base (scalar registers) + a 32-bit lane offset (the host checks that a plane is < 2 GiB)
+    const unsigned off = (unsigned)(2 * cy) * (unsigned)q.W + (unsigned)(2 * cx);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if constexpr (U8) {                                                    // W even, 2*cx even: 2-byte aligned
+            const unsigned char* base = (const unsigned char*)q.img + ((long long)b * q.ctot + 3 * stream + c) * plane;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) e.r[c * 2 + dy] = *(const unsigned short*)(base + off + (unsigned)(dy * q.W));
+        } else {                                                               // 8-byte aligned
+            const float* base = (const float*)q.img + ((long long)(stream * q.B + b) * 3 + c) * plane;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) e.r[c * 2 + dy] = *(const float2*)(base + off + (unsigned)(dy * q.W));
+        }
+    }
+}
+
+// Walk of a persistent workgroup over tiles p, p + stride, ... of a [image][tile row][tile column] grid without a
+// division per tile: position and stride are kept as mixed-radix digits and added with carries (all wave-uniform).
+struct TileWalk {
+    int img, ty, tx, s_img, s_ty, s_tx, tiles_x, tiles_y;
+    __device__ __forceinline__ void init(int pt, int stride, int tiles_x_, int tiles_y_) {
+        tiles_x = tiles_x_; tiles_y = tiles_y_;
+        const int per_img = tiles_x * tiles_y;
+        img = pt / per_img;
+        int r = pt - img * per_img;
+        ty = r / tiles_x;
+        tx = r - ty * tiles_x;
+        s_img = stride / per_img;
+        r = stride - s_img * per_img;
+        s_ty = r / tiles_x;
+        s_tx = r - s_ty * tiles_x;
+    }
+    __device__ __forceinline__ void next() {
+        tx += s_tx;
+        if (tx >= tiles_x) { tx -= tiles_x; ++ty; }
+        ty += s_ty;
+        if (ty >= tiles_y) { ty -= tiles_y; ++img; }
+        img += s_img;
+    }
+};
+
+template <bool U8>
+__device__ __forceinline__ void finish_entry(const RawEntry<U8>& e, float (&v)[12]) {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
-            const long long off = (long long)(2 * gy + dy) * q.W + 2 * gx;
             float a0, a1;
             if constexpr (U8) {
-                const unsigned char* s = (const unsigned char*)q.img + ((long long)b * q.ctot + 3 * stream + c) * plane + off;
-                const unsigned short two = *(const unsigned short*)s;          // W even, 2*gx even: 2-byte aligned
+                const unsigned short two = e.r[c * 2 + dy];
                 a0 = (float)(two & 0xff) / 255.0f;
                 a1 = (float)(two >> 8) / 255.0f;
             } else {
-                const float* s = (const float*)q.img + ((long long)(stream * q.B + b) * 3 + c) * plane + off;
-                const float2 two = *(const float2*)s;                          // 8-byte aligned
-                a0 = two.x;
-                a1 = two.y;
+                a0 = e.r[c * 2 + dy].x;
+                a1 = e.r[c * 2 + dy].y;
             }
-            v[(dy * 2 + 0) * 3 + c] = a0;                                      // channel order (dy, dx, c) of ops.s2d_conv_weight
-            v[(dy * 2 + 1) * 3 + c] = a1;
+            v[(dy * 2 + 0) * 3 + c] = e.in ? a0 : 0.0f;                        // channel order (dy, dx, c) of ops.s2d_conv_weight
+            v[(dy * 2 + 1) * 3 + c] = e.in ? a1 : 0.0f;
         }
 }
 
-template <int DT>
-__device__ __forceinline__ void store_entry(unsigned char* patch, int idx, const float (&v)[12]) {
-    float lo[8], hi4[8];
+template <int DT, bool U8>
+__device__ __forceinline__ void store_entry(unsigned char* patch, int idx, const RawEntry<U8>& e) {
+    float v[12], lo[8], hi4[8];
+    finish_entry<U8>(e, v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { lo[i] = v[i]; hi4[i] = i < 4 ? v[8 + i] : 0.0f; }
     const int key = (idx >> 3) & 1;                                            // ctile's swizzle for 2 slots per pixel
@@ -87,31 +132,25 @@ __global__ __launch_bounds__(NTHREADS) void stem_kernel(const StemP q) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ConvP& p = q.c;
 
-    auto decode = [&](int pt, int& stream, int& b, int& y0, int& x0) {
-        const int per_img = q.tiles_x * q.tiles_y, per_stream = per_img * q.B;
-        stream = pt / per_stream;
-        int r = pt - stream * per_stream;
-        b = r / per_img;
-        r -= b * per_img;
-        const int ty = r / q.tiles_x;
-        y0 = ty * ST_TH;
-        x0 = (r - ty * q.tiles_x) * ST_TW;
+    auto decode = [&](const TileWalk& t, int& stream, int& b, int& y0, int& x0) {
+        stream = t.img >= q.B;                                                 // (at most two streams)
+        b = t.img - (stream ? q.B : 0);
+        y0 = t.ty * ST_TH;
+        x0 = t.tx * ST_TW;
     };
     // each thread stages entries tid and tid + 256 of a patch
-    auto fetch = [&](int pt, float (&v0)[12], float (&v1)[12]) {
+    const int hy0 = tid / ST_HW, hx0 = tid - hy0 * ST_HW;
+    const int i1 = min(tid + NTHREADS, ST_NIDX - 1);                           // (threads past the end re-load the last entry)
+    const int hy1 = i1 / ST_HW, hx1 = i1 - hy1 * ST_HW;
+    auto fetch = [&](const TileWalk& t, RawEntry<U8>& v0, RawEntry<U8>& v1) {
         int stream, b, y0, x0;
-        decode(pt, stream, b, y0, x0);
-        const int hy0 = tid / ST_HW, hx0 = tid - hy0 * ST_HW;
+        decode(t, stream, b, y0, x0);
         load_entry<U8>(q, stream, b, y0 - 1 + hy0, x0 - 1 + hx0, v0);
-        const int i1 = tid + NTHREADS;
-        if (i1 < ST_NIDX) {
-            const int hy1 = i1 / ST_HW, hx1 = i1 - hy1 * ST_HW;
-            load_entry<U8>(q, stream, b, y0 - 1 + hy1, x0 - 1 + hx1, v1);
-        }
+        load_entry<U8>(q, stream, b, y0 - 1 + hy1, x0 - 1 + hx1, v1);
     };
-    auto commit = [&](unsigned char* patch, const float (&v0)[12], const float (&v1)[12]) {
-        store_entry<DT>(patch, tid, v0);
-        if (tid + NTHREADS < ST_NIDX) store_entry<DT>(patch, tid + NTHREADS, v1);
+    auto commit = [&](unsigned char* patch, const RawEntry<U8>& v0, const RawEntry<U8>& v1) {
+        store_entry<DT, U8>(patch, tid, v0);
+        if (tid + NTHREADS < ST_NIDX) store_entry<DT, U8>(patch, tid + NTHREADS, v1);
     };
 
     auto load_weights = [&](int stream) {
@@ -138,8 +177,10 @@ __global__ __launch_bounds__(NTHREADS) void stem_kernel(const StemP q) {
     const int pend = min((xcd + 1) * per_xcd, q.npatch);
     int pt = xcd * per_xcd + (blockIdx.x >> 3);
     if (pt >= pend) return;
-    float v0[12], v1[12];
-    fetch(pt, v0, v1);
+    TileWalk cur_t, nxt_t;
+    cur_t.init(pt, pstride, q.tiles_x, q.tiles_y);
+    RawEntry<U8> v0, v1;
+    fetch(cur_t, v0, v1);
 
     // fragment / lane constants (as ctile.hip, TW = 32, stride 1, 2 slots per pixel)
     int lbase[TM];
@@ -154,7 +195,7 @@ __global__ __launch_bounds__(NTHREADS) void stem_kernel(const StemP q) {
     commit(patch0, v0, v1);
     while (true) {
         int stream, b, y0, x0;
-        decode(pt, stream, b, y0, x0);
+        decode(cur_t, stream, b, y0, x0);
         if (stream != wstream) {                   // (re)load this stream's weights (at most twice in a workgroup's life)
             __syncthreads();                       // nobody still reads the previous weights
             load_weights(stream);
@@ -162,8 +203,10 @@ __global__ __launch_bounds__(NTHREADS) void stem_kernel(const StemP q) {
         }
         const int pn = pt + pstride;
         const bool more = pn < pend;
-        if (more) fetch(pn, v0, v1);               // next patch's image reads stay in flight during the MFMAs below
-        __syncthreads();                           // current patch (and weights) visible
+        nxt_t = cur_t;
+        nxt_t.next();
+        if (more) fetch(nxt_t, v0, v1);            // next patch's image reads stay in flight during the MFMAs below
+        lds_barrier();                             // current patch (and weights) visible
         const unsigned char* patch = cur ? patch1 : patch0;
         f32x16 acc[TN][TM];
 #pragma unroll
@@ -196,6 +239,283 @@ __global__ __launch_bounds__(NTHREADS) void stem_kernel(const StemP q) {
         commit(cur ? patch0 : patch1, v0, v1);     // (every wave passed the epilogue's barrier: nobody reads that buffer)
         cur ^= 1;
         pt = pn;
+        cur_t = nxt_t;
+    }
+}
+
+
+// ===============================================================================================================
+// stem2: yaml rows 0, 1 and the cv1 | cv2 GEMM of row 2 (10, 11, 12) in one persistent kernel (icaf.h: icaf_stem2)
+// ===============================================================================================================
+// At batch 32 the stem's output (320 x 320 x 32 channels per image and stream) is the largest tensor of the network:
+// writing it and reading it back for the next layer is 840 MB of the ~1.5 GB the first two launches move.  Here a
+// workgroup of 8 wavefronts owns a 4 x 32 tile of the SECOND convolution's output pixels and never lets t0 / t1 leave LDS:
+//   stage 0  the 11 x 67 space-to-depth halo patch of the tile is fetched from the NCHW image into registers one tile
+//            ahead (as the stem kernel does), then written to LDS as even | odd column planes: the stem taps of
+//            consecutive lanes (stem pixels two image-columns apart) then read consecutive entries;
+//   stage 1  stem GEMM over the 9 x 65 stem pixels the tile needs (K = 9 taps x 16, the stem kernel's arithmetic),
+//            bias + SiLU, zero outside the stem's output (= the next layer's zero padding), rounded to the storage type
+//            and written as ctile.hip's stride-2 halo patch (64 bytes per pixel, swizzled);
+//   stage 2  ctile's 3x3 / stride 2 loop over that patch (K = 288, weights resident in LDS), bias + SiLU, the rounded
+//            tile staged in LDS exactly as igemm's CHAIN stages it;
+//   stage 3  the chained 1x1 (K = 64) and the shared epilogue writing only y.
+// Every stage repeats the K order, MFMA step and rounding points of the kernel it replaces, so y is bit-identical to
+// icaf_stem -> icaf_conv2d(chained) (tested).  LDS: 24 KiB + 38 KiB patches + 60 KiB weights = 122 KiB, one workgroup
+// per CU; the patch walk is XCD-aware like the stem's.
+constexpr int S2_TH = 4, S2_TW = 32;                                   // tile of the 3x3/s2 layer's output pixels
+constexpr int S2_HH = 2 * S2_TH + 1, S2_HWD = 2 * S2_TW + 1;           // stem-output halo patch: 9 x 65 pixels
+constexpr int S2_HALF = (S2_HWD + 1) / 2, S2_PITCH = 2 * S2_HALF;      // 33 even | 33 odd columns per row
+constexpr int S2_NH = S2_HH * S2_PITCH;                                // 594 entries of 64 bytes
+constexpr int S2_HALO_BYTES = ((S2_NH * 4 + 63) / 64) * 1024;          // 38 KiB
+constexpr int S2_SR = S2_HH + 2, S2_SC = S2_HWD + 2;                   // space-to-depth patch under it: 11 x 67
+constexpr int S2_SHALF = (S2_SC + 1) / 2, S2_SPITCH = 2 * S2_SHALF;    // 34 | 34
+constexpr int S2_NS = S2_SR * S2_SPITCH;                               // 748 entries of 32 bytes
+constexpr int S2_S2D_BYTES = ((S2_NS * 2 + 63) / 64) * 1024;           // 24 KiB
+constexpr int S2_THREADS = 512;
+constexpr int S2_C0 = 32, S2_C1 = 64, S2_C2 = 64, S2_W1_SLICES = 5;    // K1 = 288 -> 5 slices of 128 bytes
+constexpr int S2_LDS = S2_S2D_BYTES + S2_HALO_BYTES + (3 * S2_C0 + S2_W1_SLICES * S2_C1 + S2_C2) * 128;
+
+struct Stem2P {
+    const void* img;            // as StemP
+    int ctot;
+    int B, H, W, nstreams;
+    int tiles_x, tiles_y, npatch;
+    int Hs, Ws;                 // the stem's output size (H/2, W/2)
+    const void* w0; const float* bias0; long long w0_gs, bias0_gs; int Kp0;
+    ConvP c;                    // w / bias / Kp: the 3x3 layer;  w2 / bias2 / y2 / ldy2 / Cout2: the 1x1;  Ho, Wo: output
+};
+
+template <int DT, bool U8>
+__global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
+    using E = Elem<DT>;
+    static_assert(DT != ICAF_F32, "16-bit types");
+    constexpr int RB = 128, C0 = S2_C0, C1 = S2_C1, C2 = S2_C2;
+    constexpr int SO = C1 * E::BYTES + 16;                                  // staged-tile row stride (the epilogue's)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char* s2d = lds;                                              // stage 0/1 patch; later the staged t1 tile
+    unsigned char* halo = lds + S2_S2D_BYTES;                              // stage 1/2 patch; later the output staging
+    unsigned char* w0b = halo + S2_HALO_BYTES;                             // 3 slices x C0 rows x 128 bytes
+    unsigned char* w1b = w0b + 3 * C0 * RB;                                // 5 slices x C1 rows
+    unsigned char* w2b = w1b + S2_W1_SLICES * C1 * RB;                     // 1 slice x C2 rows
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;                               // output row of the tile / channel half
+    const ConvP& p = q.c;
+
+    auto decode = [&](const TileWalk& t, int& stream, int& b, int& y0, int& x0) {
+        stream = t.img >= q.B;                                                 // (at most two streams)
+        b = t.img - (stream ? q.B : 0);
+        y0 = t.ty * S2_TH;
+        x0 = t.tx * S2_TW;
+    };
+    // space-to-depth entry e of the patch -> (row, column) in the patch; columns are stored even plane | odd plane
+    auto entry_rc = [&](int e, int& sr, int& sc) {
+        sr = e / S2_SPITCH;
+        const int rem = e - sr * S2_SPITCH, pl = rem >= S2_SHALF;
+        sc = 2 * (rem - pl * S2_SHALF) + pl;
+    };
+    int sr0, sc0, sr1, sc1;                                                // each thread stages entries tid and tid + 512
+    entry_rc(tid, sr0, sc0);
+    entry_rc(min(tid + S2_THREADS, S2_NS - 1), sr1, sc1);
+    if (sc0 >= S2_SC) sr0 = -0x10000;                                      // padding entries: outside any image -> zero
+    if (sc1 >= S2_SC) sr1 = -0x10000;
+    auto fetch = [&](const TileWalk& t, RawEntry<U8>& v0, RawEntry<U8>& v1) {
+        int stream, b, y0, x0;
+        decode(t, stream, b, y0, x0);
+        load_entry<U8>(q, stream, b, 2 * y0 - 2 + sr0, 2 * x0 - 2 + sc0, v0);
+        load_entry<U8>(q, stream, b, 2 * y0 - 2 + sr1, 2 * x0 - 2 + sc1, v1);
+    };
+    auto commit = [&](const RawEntry<U8>& v0, const RawEntry<U8>& v1) {
+        store_entry<DT, U8>(s2d, tid, v0);
+        if (tid + S2_THREADS < S2_NS) store_entry<DT, U8>(s2d, tid + S2_THREADS, v1);
+    };
+
+    // weight matrix -> LDS: `nsl` slices of `rows` rows x 128 bytes in igemm's swizzle (8 rows per DMA instruction)
+    auto dma_rows = [&](const void* base, int rows, int kp, int nsl, unsigned char* dst) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)(rows * kp * 2), 0x00020000);
+        const int rs8 = lane >> 3, per = rows >> 3;
+        for (int t = wave; t < nsl * per; t += S2_THREADS / 64) {
+            const int c = t / per, j = t - c * per;
+            const int sl = (lane & 7) ^ (((j & 1) << 2) | (rs8 >> 1));
+            const unsigned voff = ((unsigned)(j * 8 + rs8) * (unsigned)kp + (unsigned)(c * 64 + sl * 8)) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dst + (c * rows + j * 8) * RB), 16, voff, 0, 0, 0);
+        }
+    };
+    auto load_weights = [&](int stream) {
+        dma_rows((const typename E::type*)q.w0 + stream * q.w0_gs, C0, q.Kp0, 3, w0b);
+        dma_rows((const typename E::type*)p.w + stream * p.w_gs, C1, p.Kp, S2_W1_SLICES, w1b);
+        dma_rows((const typename E::type*)p.w2 + stream * p.w2_gs, C2, p.Kp2, 1, w2b);
+        wait_vmcnt<0>();
+    };
+
+    const int xcd = blockIdx.x & 7, per_xcd = (q.npatch + 7) >> 3, pstride = gridDim.x >> 3;
+    const int pend = min((xcd + 1) * per_xcd, q.npatch);
+    int pt = xcd * per_xcd + (blockIdx.x >> 3);
+    if (pt >= pend) return;
+    TileWalk cur_t, nxt_t;
+    cur_t.init(pt, pstride, q.tiles_x, q.tiles_y);
+    RawEntry<U8> v0, v1;
+    fetch(cur_t, v0, v1);
+
+    const int fkey = (l31 >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff[s] = l31 * RB + (((2 * s + hi) ^ fkey) << 4);
+    const int lb2 = wm * 2 * S2_PITCH + l31;                               // stage 2: lane's entry for tap (0, 0)
+
+    // Per-stream constants held in registers: the stem's weight fragments and the three bias vectors of this lane's
+    // channels.  (Loading a bias inside the tile loop is a dependent L2 round trip per use — with one workgroup per CU
+    // nothing else would cover it.)
+    u32x4 fw0[9];
+    f32x4 b0r[4], b1r[4], b2r[4];
+    int wstream = -1;
+    commit(v0, v1);
+    while (true) {
+        int stream, b, y0, x0;
+        decode(cur_t, stream, b, y0, x0);
+        if (stream != wstream) {                   // (re)load this stream's weights (at most twice in a workgroup's life)
+            lds_barrier();
+            load_weights(stream);
+            lds_barrier();
+            wstream = stream;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) fw0[tap] = *(const u32x4*)(w0b + (tap >> 2) * C0 * RB + foff[tap & 3]);
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                b0r[qd] = *(const f32x4*)(q.bias0 + stream * q.bias0_gs + 8 * qd + 4 * hi);
+                b1r[qd] = *(const f32x4*)(p.bias + stream * p.bias_gs + wn * 32 + 8 * qd + 4 * hi);
+                b2r[qd] = *(const f32x4*)(p.bias2 + stream * p.bias2_gs + wn * 32 + 8 * qd + 4 * hi);
+            }
+            // consume them here: otherwise the compiler's wait-count bookkeeping treats them as possibly pending at every
+            // use inside the tile loop and drains the NEXT tile's prefetch with them
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) asm volatile("" : "+v"(b0r[qd]), "+v"(b1r[qd]), "+v"(b2r[qd]));
+        }
+        const int pn = pt + pstride;
+        const bool more = pn < pend;
+        nxt_t = cur_t;
+        nxt_t.next();
+        if (more) fetch(nxt_t, v0, v1);            // next tile's image reads stay in flight during everything below
+        lds_barrier();                             // space-to-depth patch visible
+
+        // ---- stage 1: stem over the halo patch ------------------------------------------------------------------
+        {
+            for (int j = wave; j < (S2_NH + 31) / 32; j += S2_THREADS / 64) {
+                const int idx = (j << 5) + l31;
+                const int idc = idx < S2_NH ? idx : 0;
+                const int hy = idc / S2_PITCH, rem = idc - hy * S2_PITCH, pl = rem >= S2_HALF, i = rem - pl * S2_HALF;
+                int eb[3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int sc = 2 * i + pl + kx;
+                    eb[kx] = hy * S2_SPITCH + (sc & 1) * S2_SHALF + (sc >> 1);
+                }
+                f32x16 a0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a0[r] = 0.0f;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    const int e = eb[kx] + ky * S2_SPITCH;
+                    const u32x4 fp = *(const u32x4*)(s2d + (((e << 1) + (hi ^ ((e >> 3) & 1))) << 4));
+                    mma_step<DT>(a0, fw0[tap], fp);
+                }
+                const int hx = 2 * i + pl;
+                const int sy = 2 * y0 - 1 + hy, sx = 2 * x0 - 1 + hx;
+                const bool inside = hx < S2_HWD && (unsigned)sy < (unsigned)q.Hs && (unsigned)sx < (unsigned)q.Ws;
+                if (idx < S2_NH) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int nl = 8 * qd + 4 * hi;
+                        float v[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (inside) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = silu_f(a0[4 * qd + e] + b0r[qd][e]);
+                        }
+                        u32x2 pk;
+                        if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
+                        else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
+                        const int slot = (idx << 2) + (((nl >> 3) ^ (idx >> 2)) & 3);
+                        *(u32x2*)(halo + (slot << 4) + ((nl & 7) << 1)) = pk;
+                    }
+                }
+            }
+        }
+        lds_barrier();                             // halo patch visible; the space-to-depth patch is free
+
+        // ---- stage 2: 3x3 / stride 2 over the halo patch (ctile.hip's loop, weights resident) ---------------------
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9 * C0 / 16; ++k) {    // K = (tap, channel): 16 per MFMA step
+            const int tap = k >> 1, ky = tap / 3, kx = tap - 3 * ky;
+            const int idx = lb2 + ky * S2_PITCH + (kx & 1) * S2_HALF + (kx >> 1);
+            const int csl = (k & 1) * 2 + hi;
+            const u32x4 fp = *(const u32x4*)(halo + (((idx << 2) + ((csl ^ (idx >> 2)) & 3)) << 4));
+            const u32x4 fw = *(const u32x4*)(w1b + (k >> 2) * C1 * RB + (wn * 32) * RB + foff[k & 3]);
+            mma_step<DT>(acc[0][0], fw, fp);
+        }
+        {                                          // t1 tile -> LDS, rounded to the storage type (igemm CHAIN, step a)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int nl = wn * 32 + 8 * qd + 4 * hi;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[0][0][4 * qd + e] + b1r[qd][e]);
+                u32x2 pk;
+                if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
+                else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
+                *(u32x2*)(s2d + (wm * 32 + l31) * SO + nl * E::BYTES) = pk;
+            }
+        }
+        lds_barrier();
+
+        // ---- stage 3: chained 1x1 on the staged tile, then the epilogue (conv_common.h's, with the bias in registers
+        //      and LDS-only barriers so that the prefetch stays in flight) -----------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < C1 / 16; ++s2) {
+            const u32x4 fp2 = *(const u32x4*)(s2d + (wm * 32 + l31) * SO + ((2 * s2 + hi) << 4));
+            const u32x4 fw2 = *(const u32x4*)(w2b + (wn * 32) * RB + foff[s2]);
+            mma_step<DT>(acc[0][0], fw2, fp2);
+        }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {           // (every wave finished stage 2 before the barrier above: halo is free)
+            const int nl = wn * 32 + 8 * qd + 4 * hi;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[0][0][4 * qd + e] + b2r[qd][e]);
+            u32x2 pk;
+            if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
+            else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
+            *(u32x2*)(halo + (wm * 32 + l31) * SO + nl * E::BYTES) = pk;
+        }
+        lds_barrier();
+        {
+            // staged vectors -> registers, then the next tile's patch is committed BEFORE the global stores are issued:
+            // the wait for the prefetch (vmcnt counts in order) then never includes this tile's stores
+            typename E::type* __restrict__ yg = (typename E::type*)p.y2 + stream * p.y2_gs;
+            constexpr int NIT = S2_TH * S2_TW * (C2 / 8) / S2_THREADS;
+            u32x4 sv[NIT];
+            long long yoff[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * S2_THREADS, row = idx >> 3, cv = idx & 7;
+                const int gy = y0 + (row >> 5), gx = x0 + (row & 31);
+                sv[it] = *(const u32x4*)(halo + row * SO + cv * 16);
+                yoff[it] = (gy < p.Ho && gx < p.Wo && cv * 8 < p.Cout2) ? (long long)((b * p.Ho + gy) * p.Wo + gx) * p.ldy2 + cv * 8 : -1;
+            }
+            if (more) commit(v0, v1);              // (every wave passed the barrier above: the staged t1 tile is consumed)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (yoff[it] >= 0) *(u32x4*)(yg + yoff[it]) = sv[it];
+        }
+        if (!more) break;
+        pt = pn;
+        cur_t = nxt_t;
     }
 }
 
@@ -229,6 +549,7 @@ extern "C" int icaf_stem(const void* img, int img_u8, int ctot, const void* w, c
     if (!img || !w || !y) return fail(ICAF_ERR_ARG, "icaf_stem: null pointer");
     if (dtype != ICAF_BF16 && dtype != ICAF_F16) return fail(ICAF_ERR_UNSUPPORTED, "icaf_stem: 16-bit types only");
     if ((H | W) & 1) return fail(ICAF_ERR_ARG, "icaf_stem: H and W must be even");
+    if ((long long)H * W >= (1LL << 29)) return fail(ICAF_ERR_UNSUPPORTED, "icaf_stem: image plane of 2^29 or more pixels");
     if (Cout != 32 && Cout != 64) return fail(ICAF_ERR_UNSUPPORTED, "icaf_stem: built for 32 or 64 output channels (got %d)", Cout);
     if (Kp != 192) return fail(ICAF_ERR_ARG, "icaf_stem: the packed space-to-depth weights must have Kp = 192 (K = 9 x 16), got %d", Kp);
     if (nstreams < 1 || nstreams > 2 || (img_u8 && ctot < 3 * nstreams)) return fail(ICAF_ERR_ARG, "icaf_stem: bad nstreams / ctot");
@@ -253,4 +574,54 @@ extern "C" int icaf_stem(const void* img, int img_u8, int ctot, const void* w, c
     }
     if (Cout == 32) return img_u8 ? launch_stem<ICAF_F16, 32, true>(q, hs) : launch_stem<ICAF_F16, 32, false>(q, hs);
     return img_u8 ? launch_stem<ICAF_F16, 64, true>(q, hs) : launch_stem<ICAF_F16, 64, false>(q, hs);
+}
+
+template <int DT, bool U8>
+static int launch_stem2(const Stem2P& q, hipStream_t s) {
+    int dev = 0, cus = 256;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int grid = cus < q.npatch ? cus : q.npatch;     // 122 KiB of LDS: one workgroup per CU
+    grid = (grid + 7) & ~7;                         // the tile walk is per XCD (8 of them)
+    static bool attr = false;
+    if (!attr) {
+        ICAF_HIP(hipFuncSetAttribute((const void*)stem2_kernel<DT, U8>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS));
+        attr = true;
+    }
+    stem2_kernel<DT, U8><<<dim3((unsigned)grid), dim3(S2_THREADS), S2_LDS, s>>>(q);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+extern "C" int icaf_stem2(const icaf_stem2_args* a, icaf_stream_t s) {
+    if (!a || !a->img || !a->w0 || !a->w1 || !a->w2 || !a->bias0 || !a->bias1 || !a->bias2 || !a->y)
+        return fail(ICAF_ERR_ARG, "icaf_stem2: null pointer");
+    if (a->dtype != ICAF_BF16 && a->dtype != ICAF_F16) return fail(ICAF_ERR_UNSUPPORTED, "icaf_stem2: 16-bit types only");
+    if ((a->H | a->W) & 1 || a->H < 4 || a->W < 4) return fail(ICAF_ERR_ARG, "icaf_stem2: H and W must be even and >= 4");
+    if ((long long)a->H * a->W >= (1LL << 29)) return fail(ICAF_ERR_UNSUPPORTED, "icaf_stem2: image plane of 2^29 or more pixels");
+    if (a->C0 != S2_C0 || a->C1 != S2_C1 || a->C2 < 8 || a->C2 > S2_C2 || a->C2 % 8)
+        return fail(ICAF_ERR_UNSUPPORTED, "icaf_stem2: built for 32 -> 64 -> (<= 64) channels, got %d -> %d -> %d", a->C0, a->C1, a->C2);
+    if (a->Kp0 != 192 || a->Kp1 != 64 * S2_W1_SLICES || a->Kp2 != 64)
+        return fail(ICAF_ERR_ARG, "icaf_stem2: packed weights must have Kp = 192 / %d / 64, got %d / %d / %d", 64 * S2_W1_SLICES, a->Kp0, a->Kp1, a->Kp2);
+    if (a->nstreams < 1 || a->nstreams > 2 || (a->img_u8 && a->ctot < 3 * a->nstreams)) return fail(ICAF_ERR_ARG, "icaf_stem2: bad nstreams / ctot");
+    if (a->ldy % 8 || ((uintptr_t)a->y & 15) || (a->y_gs * 2) % 16) return fail(ICAF_ERR_ARG, "icaf_stem2: y must be 16-byte aligned with ldy %% 8 == 0");
+    Stem2P q;
+    memset(&q, 0, sizeof(q));
+    q.img = a->img; q.ctot = a->ctot; q.B = a->B; q.H = a->H; q.W = a->W; q.nstreams = a->nstreams;
+    q.Hs = a->H / 2; q.Ws = a->W / 2;
+    q.w0 = a->w0; q.bias0 = a->bias0; q.w0_gs = a->w0_gs; q.bias0_gs = a->bias0_gs; q.Kp0 = a->Kp0;
+    ConvP& p = q.c;
+    p.w = a->w1; p.bias = a->bias1; p.w_gs = a->w1_gs; p.bias_gs = a->bias1_gs; p.Kp = a->Kp1;
+    p.w2 = a->w2; p.bias2 = a->bias2; p.w2_gs = a->w2_gs; p.bias2_gs = a->bias2_gs; p.Kp2 = a->Kp2;
+    p.y2 = a->y; p.y2_gs = a->y_gs; p.ldy2 = a->ldy; p.Cout2 = a->C2; p.vec_y2 = 1;
+    p.B = a->B; p.H = q.Hs; p.W = q.Ws; p.Cin = S2_C0; p.Cout = S2_C1;
+    p.Ho = (q.Hs - 1) / 2 + 1; p.Wo = (q.Ws - 1) / 2 + 1;                  // 3x3 / stride 2 / pad 1
+    p.M = a->B * p.Ho * p.Wo; p.K = 9 * S2_C0; p.act = ICAF_ACT_SILU;
+    p.alpha_acc[0] = p.alpha_acc[1] = 1.0f;
+    if ((long long)a->nstreams * p.M * a->ldy >= (1LL << 31)) return fail(ICAF_ERR_UNSUPPORTED, "icaf_stem2: output exceeds 2^31 elements");
+    q.tiles_x = (p.Wo + S2_TW - 1) / S2_TW; q.tiles_y = (p.Ho + S2_TH - 1) / S2_TH;
+    q.npatch = a->nstreams * a->B * q.tiles_x * q.tiles_y;
+    hipStream_t hs = S(s);
+    if (a->dtype == ICAF_BF16) return a->img_u8 ? launch_stem2<ICAF_BF16, true>(q, hs) : launch_stem2<ICAF_BF16, false>(q, hs);
+    return a->img_u8 ? launch_stem2<ICAF_F16, true>(q, hs) : launch_stem2<ICAF_F16, false>(q, hs);
 }

@@ -252,6 +252,45 @@ class Conv(HipModule):
                             name=f"conv{kh}x{kw}s{sh}" + ("+1x1" if ch else ""), pre=pre_term, chain=ch))
         return y2 if ch else out
 
+    fuse_stem2 = True    # stem + the 3x3/s2 Conv behind it + that Conv's chained cv1 | cv2 as ONE persistent kernel
+
+    def stem2_ok(self, plan, x, nxt, c3):
+        """self = image-fed 6x6/s2 stem, nxt = the Conv behind it, c3 = the C3 behind that: can icaf_stem2 run all three?
+        (mirrors its argument checks: 16-bit, 3 -> 32 -> 64 -> 2 x 32 channels, i.e. the yolov5s width)"""
+        k0, k1 = self.conv, getattr(nxt, "conv", None)
+        if not (self.fuse_stem2 and self.fuse_stem and isinstance(x, ImageIn) and x.pair and isinstance(nxt, Conv)
+                and plan.dtype in (torch.bfloat16, torch.float16) and (not x.u8 or x.c0 == 0)):
+            return False
+        _, _, H, W = x.shape
+        return ((k0.kernel_size, k0.stride, _pair(k0.padding), k0.in_channels, k0.out_channels) == ((6, 6), (2, 2), (2, 2), 3, 32)
+                and k0.groups == 1 and isinstance(self.act, nn.SiLU) and H % 2 == 0 and W % 2 == 0
+                and (k1.kernel_size, k1.stride, _pair(k1.padding), k1.in_channels, k1.out_channels) == ((3, 3), (2, 2), (1, 1), 32, 64)
+                and nxt.chain_ok(plan, c3) and 2 * c3.cv1.conv.out_channels == 64)
+
+    def emit_stem2(self, plan, x, twin, nxt, nxt_twin, convs, twin_convs, y2):
+        """Rows 0-2a of both streams as one launch; y2 = the pair act the C3's cv1 | cv2 write."""
+        key_tail = (plan.dtype, plan.device, id(twin))
+
+        def stack(packs):
+            return (torch.stack([p[0] for p in packs]).contiguous(), packs[0][1], torch.stack([p[2] for p in packs]).contiguous())
+
+        def pack_row(rows, transform, cin_pad):
+            packs = []
+            for convs_ in rows:
+                ws, bs = zip(*(c.folded() for c in convs_))
+                w, b = torch.cat(ws), torch.cat(bs)
+                wp, kp = ops.pack_conv_weight(transform(w), plan.dtype, cin_pad)
+                packs.append((wp, kp, ops.pack_bias(b, w.shape[0])))
+            return stack(packs)
+        w0, kp0, b0 = self._cached(("s2d",) + key_tail + ((), False), lambda: pack_row([(self,), (twin,)], ops.s2d_conv_weight, 16))
+        w1, kp1, b1 = nxt._cached(("std",) + (plan.dtype, plan.device, id(nxt_twin), (), False),
+                                  lambda: pack_row([(nxt,), (nxt_twin,)], lambda w: w, None))
+        w2, kp2, b2 = nxt._cached(("chain",) + (plan.dtype, plan.device, id(nxt_twin), (), False) + tuple(id(c) for c in convs),
+                                  lambda: pack_row([convs, twin_convs], lambda w: w, None))
+        n2 = sum(c.conv.out_channels for c in convs)
+        plan.add(ops.stem2(x.t, w0, kp0, b0, w1, kp1, b1, w2, kp2, b2, y2, self.conv.out_channels, nxt.conv.out_channels, n2))
+        return y2
+
     chain_fuse = True    # let a C3 behind this Conv run its cv1 | cv2 GEMM on this layer's output tile (one launch)
 
     def chain_ok(self, plan, c3):
@@ -335,7 +374,10 @@ class C3(HipModule):
         """lead = (Conv, twin Conv or None): the down-sampling Conv in front of this block whose output only this block
         reads; `x` is then THAT conv's input and cv1 | cv2 run chained on its output tile (the tensor between the two
         yaml rows is never written)."""
-        if lead is not None:
+        if lead is not None and len(lead) == 4:        # (Conv, twin, stem, stem twin): x is the image pair itself
+            B, _, H, W = x.shape
+            H, W = (H // 2 - 1) // 2 + 1, (W // 2 - 1) // 2 + 1
+        elif lead is not None:
             k = lead[0].conv
             B = x.shape[-4]
             H = (x.shape[-3] + 2 * k.padding[0] - k.kernel_size[0]) // k.stride[0] + 1
@@ -349,7 +391,9 @@ class C3(HipModule):
         # neighbours' patches read x), so the chain ping-pongs between slot 0 and slot 2; cv3 then reads [a | b] or
         # [b | a'] — in the second case with its weight columns swapped to match.
         cat = plan.act(B, H, W, (3 if any(fused) else 2) * c_, pair=paired)
-        if lead is not None:
+        if lead is not None and len(lead) == 4:
+            lead[2].emit_stem2(plan, x, lead[3], lead[0], lead[1], (self.cv1, self.cv2), (twin.cv1, twin.cv2), cat[..., :2 * c_])
+        elif lead is not None:
             lead[0].emit(plan, x, twin=lead[1], chain=((self.cv1, self.cv2), (twin.cv1, twin.cv2) if paired else None,
                                                        cat[..., :2 * c_]))
         else:

@@ -317,6 +317,7 @@ class Model(HipModule):
         twins = {ir0 + k: k for k in range(run)}
         rgb_rows = set(twins.values())
         pair_out = {}
+        pending_stem = None
         pending_lead = {}                           # C3 row -> ((Conv, twin Conv), conv input): rows fused into one launch
         y, x = [], None
         last_launch = {}                            # yaml row -> index of its last launch
@@ -327,6 +328,22 @@ class Model(HipModule):
             if m.i in rgb_rows:                     # both streams in one paired launch sequence
                 src = in_pair if m.i == 0 else pair_out[m.i - 1]
                 nxt = self.model[m.i + 1] if m.i + 1 < len(self.model) else None
+                nx2 = self.model[m.i + 2] if m.i + 2 < len(self.model) else None
+                if (m.i == 0 and isinstance(m, Conv) and isinstance(nx2, C3) and {1, 2} <= rgb_rows and nxt.f == -1
+                        and nx2.f == -1 and not ({0, 1, ir0, ir0 + 1} & (set(self.save) | set(dmff_pair)))
+                        and m.stem2_ok(plan, src, nxt, nx2)):
+                    pending_stem = (m, self.model[ir0])             # rows 0-2a become one launch, emitted with the C3 row
+                    pair_out[0] = None
+                    y.append(None)
+                    last_launch[0] = last_launch[ir0] = len(plan.launches) - 1
+                    continue
+                if m.i == 1 and pending_stem is not None:
+                    pending_lead[2] = ((m, self.model[ir0 + 1]) + pending_stem, in_pair)
+                    pending_stem = None
+                    pair_out[1] = None
+                    y.append(None)
+                    last_launch[1] = last_launch[ir0 + 1] = len(plan.launches) - 1
+                    continue
                 if (isinstance(m, Conv) and m.i > 0 and isinstance(nxt, C3) and (m.i + 1) in rgb_rows and nxt.f == -1
                         and m.i not in self.save and (ir0 + m.i) not in self.save and m.i not in dmff_pair
                         and m.chain_ok(plan, nxt)):

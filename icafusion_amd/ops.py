@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import BneckArgs, ConvArgs, check, lib, F32, BF16, F16, ACT_NONE, ACT_SILU, ACT_GELU  # noqa: F401
+from ._lib import BneckArgs, ConvArgs, Stem2Args, check, lib, F32, BF16, F16, ACT_NONE, ACT_SILU, ACT_GELU  # noqa: F401
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 VEC = {torch.float32: 4, torch.bfloat16: 8, torch.float16: 8}     # elements per 16-byte vector
@@ -340,6 +340,37 @@ def stem(img, w_packed, kp, bias, y, cout, name="stem"):
                                     w_packed.stride(0) if paired else 0, bias.stride(0) if paired else 0,
                                     y.stride(0) if paired else 0),
                   keep=(img, w_packed, bias, y), name=name, flops=flops, nbytes=nb)
+
+
+def stem2(img, w0, kp0, b0, w1, kp1, b1, w2, kp2, b2, y, c0, c1, c2, name="stem+conv3x3s2+1x1"):
+    """Stem, the 3x3/s2 conv behind it and a chained 1x1 in one persistent kernel (icaf_stem2): img as `stem`; w0 / w1 /
+    w2: the packed weights of the three layers (stacked per stream for a pair act y); y: (B, H/4, W/4, >= c2) act."""
+    u8 = img.dtype == torch.uint8
+    paired = y.dim() == 5
+    assert img.is_contiguous() and (u8 or img.dtype == torch.float32)
+    if u8:
+        assert img.dim() == 4 and paired and img.shape[1] >= 6
+        B, ctot, H, W = img.shape
+    else:
+        assert img.dim() == (5 if paired else 4)
+        B, _, H, W = img.shape[-4:]
+        ctot = 3
+    By, Ho, Wo, cy, ldy = _act_geom(y)
+    assert (By, Ho, Wo) == (B, (H // 2 - 1) // 2 + 1, (W // 2 - 1) // 2 + 1) and cy >= c2
+    assert w0.dtype == w1.dtype == w2.dtype == y.dtype
+    a = Stem2Args()
+    a.img, a.img_u8, a.ctot = img.data_ptr(), int(u8), ctot
+    a.dtype, a.nstreams, a.B, a.H, a.W = dtype_code(y.dtype), 2 if paired else 1, B, H, W
+    for k, (w, b, kp, c) in enumerate(((w0, b0, kp0, c0), (w1, b1, kp1, c1), (w2, b2, kp2, c2))):
+        setattr(a, f"w{k}", w.data_ptr()); setattr(a, f"bias{k}", b.data_ptr())
+        setattr(a, f"w{k}_gs", w.stride(0) if paired else 0); setattr(a, f"bias{k}_gs", b.stride(0) if paired else 0)
+        setattr(a, f"Kp{k}", kp); setattr(a, f"C{k}", c)
+    a.y, a.y_gs, a.ldy = y.data_ptr(), y.stride(0) if paired else 0, ldy
+    g = a.nstreams
+    hs, ws = H // 2, W // 2
+    flops = 2.0 * g * B * (hs * ws * c0 * 144 + Ho * Wo * (c1 * 9 * c0 + c2 * c1))
+    nb = g * B * (3 * H * W * (1 if u8 else 4) + Ho * Wo * c2 * y.element_size())
+    return Launch(lib().icaf_stem2, (C.byref(a),), keep=(a, img, w0, b0, w1, b1, w2, b2, y), name=name, flops=flops, nbytes=nb)
 
 
 def sppf_pool(x, y1, y2, y3, k, name="sppf_pool"):

@@ -63,6 +63,25 @@ int icaf_stem(const void* img, int img_u8, int ctot, const void* w, const float*
               int nstreams, int B, int H, int W, int Cout, int Kp, long long w_gs, long long bias_gs, long long y_gs,
               icaf_stream_t s);
 
+/* Yaml rows 0-2 (10-12) up to the C3's first GEMM in ONE persistent kernel — the three layers every image pixel goes
+ * through at the highest resolutions (models/common.py:48-60, 216-227; models/transformer/yolov5s_*.yaml rows 0-2):
+ *   t0 = SiLU(conv6x6/s2/p2(img) + bias0)          C0 channels at H/2 x W/2   (the stem, as icaf_stem)
+ *   t1 = SiLU(conv3x3/s2/p1(t0) + bias1)           C1 channels at H/4 x W/4
+ *   y  = SiLU(W2 . t1 + bias2)                     C2 channels (the C3's cv1 | cv2), NHWC [nstreams][B][H/4][W/4][ldy]
+ * t0 and t1 live in LDS only (rounded to the storage type exactly where the three-launch form writes them, so the
+ * result is bit-identical to icaf_stem -> icaf_conv2d with a chained 1x1).  Weights are the packed matrices of those
+ * launches: w0 [Np][192] (space-to-depth), w1 [Np][Kp1] (k = ky, kx, c0), w2 [Np][Kp2]; *_gs = per-stream strides.
+ * Built for C0 = 32, C1 = 64, C2 <= 64 (yolov5s), 16-bit types. */
+typedef struct icaf_stem2_args {
+    const void* img; int img_u8, ctot;             /* as icaf_stem */
+    int dtype, nstreams, B, H, W;
+    const void* w0; const float* bias0; long long w0_gs, bias0_gs; int Kp0, C0;
+    const void* w1; const float* bias1; long long w1_gs, bias1_gs; int Kp1, C1;
+    const void* w2; const float* bias2; long long w2_gs, bias2_gs; int Kp2, C2;
+    void* y; long long y_gs; int ldy, reserved;
+} icaf_stem2_args;
+int icaf_stem2(const icaf_stem2_args* a, icaf_stream_t s);
+
 /* ---- implicit-GEMM convolution / linear ------------------------------------------------------------------
  * Replaces Conv.forward / fuseforward (models/common.py:48-60: SiLU(BN(Conv2d))) with BN folded into the
  * weights (utils/torch_utils.py:182-202), nn.Linear (+GELU) inside CrossAttention / CrossTransformerBlock

@@ -396,6 +396,66 @@ def test_persistent_stem_equals_staging_plus_conv(case, dt):
     close(from_act(y_f[0] if paired else y_f), ref, dt, f"stem {case}")
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 64, 256, 64, True, False), (1, 44, 72, 48, False, False), (2, 136, 130, 64, True, True),
+                                  (3, 36, 40, 64, True, True), (1, 320, 320, 64, True, False)])
+def test_stem2_equals_stem_then_chained_conv(case, dt):
+    """icaf_stem2 (stem + 3x3/s2 conv + chained 1x1 in one persistent kernel; the two intermediate tensors stay in LDS) vs
+    icaf_stem followed by icaf_conv2d with the chained 1x1: bit-identical, and close to fp32 torch.  Sizes cover tiles cut
+    by the image border, odd stem / output sizes (H/2 or W/2 odd), one and two streams, uint8 and fp32 images."""
+    B, H, W, c2, paired, u8 = case
+    G = 2 if paired else 1
+    g = np.random.default_rng(161)
+    w0 = [rnd((32, 3, 6, 6), 162 + i, 1.0 / math.sqrt(108)) for i in range(G)]
+    w1 = [rnd((64, 32, 3, 3), 164 + i, 1.0 / math.sqrt(288)) for i in range(G)]
+    w2 = [rnd((c2, 64, 1, 1), 166 + i, 1.0 / 8) for i in range(G)]
+    b0 = [rnd((32,), 168 + i, 0.2) for i in range(G)]
+    b1 = [rnd((64,), 170 + i, 0.2) for i in range(G)]
+    b2 = [rnd((c2,), 172 + i, 0.2) for i in range(G)]
+    st = (lambda ts: torch.stack(ts).contiguous()) if paired else (lambda ts: ts[0])
+    p0 = [ops.pack_conv_weight(ops.s2d_conv_weight(w.to(DEV)), dt, 16) for w in w0]
+    p1 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w1]
+    p2 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w2]
+    w0p, w1p, w2p = (st([p_[0] for p_ in ps]) for ps in (p0, p1, p2))
+    b0p, b1p, b2p = (st([ops.pack_bias(b.to(DEV), n) for b in bs]) for bs, n in ((b0, 32), (b1, 64), (b2, c2)))
+    if u8:
+        img = torch.from_numpy(g.integers(0, 256, (B, 6, H, W), dtype=np.uint8)).to(DEV)
+    else:
+        img = torch.from_numpy(g.random((G, B, 3, H, W), dtype=np.float32)).to(DEV)
+        if not paired:
+            img = img[0].contiguous()
+    Hs, Ws = H // 2, W // 2
+    Ho, Wo = (Hs - 1) // 2 + 1, (Ws - 1) // 2 + 1
+    lead = (G, B) if paired else (B,)
+    t0 = torch.zeros((*lead, Hs, Ws, 32), dtype=dt, device=DEV)
+    dummy = torch.zeros((*lead, Ho, Wo, 64), dtype=dt, device=DEV)
+    y_u = torch.zeros((*lead, Ho, Wo, c2 + 8), dtype=dt, device=DEV)[..., :c2]
+    y_f = torch.full((*lead, Ho, Wo, c2 + 8), 7.0, dtype=dt, device=DEV)
+    run(ops.stem(img, w0p, p0[0][1], b0p, t0, 32))
+    run(ops.conv2d(t0, w1p, p1[0][1], b1p, dummy, 3, 3, 2, 2, 1, 1, 32, 64, ops.ACT_SILU,
+                   chain=dict(w=w2p, kp=p2[0][1], bias=b2p, y=y_u, cout=c2)))
+    run(ops.stem2(img, w0p, p0[0][1], b0p, w1p, p1[0][1], b1p, w2p, p2[0][1], b2p, y_f[..., :c2], 32, 64, c2))
+    assert torch.equal(y_f[..., :c2], y_u)
+    assert bool((y_f[..., c2:] == 7.0).all()), "channels beyond C2 must not be written"
+    x0 = (img[:, :3].cpu().float() / 255.0) if u8 else (img[0] if paired else img).cpu()
+    t = q(F.silu(F.conv2d(q(x0, dt), q(w0[0], dt), b0[0], 2, 2)), dt)
+    t = q(F.silu(F.conv2d(t, q(w1[0], dt), b1[0], 2, 1)), dt)
+    ref = F.silu(F.conv2d(t, q(w2[0], dt), b2[0]))
+    close(from_act(y_f[0][..., :c2] if paired else y_f[..., :c2]), ref, dt, f"stem2 {case}", factor=2.0)
+
+
+def test_stem2_rejects_other_widths():
+    img = torch.zeros((1, 3, 32, 32), dtype=torch.float32, device=DEV)
+    dt = torch.bfloat16
+    w0, kp0 = ops.pack_conv_weight(ops.s2d_conv_weight(torch.zeros((32, 3, 6, 6), device=DEV)), dt, 16)
+    w1, kp1 = ops.pack_conv_weight(torch.zeros((64, 32, 3, 3), device=DEV), dt)
+    w2, kp2 = ops.pack_conv_weight(torch.zeros((128, 64, 1, 1), device=DEV), dt)
+    b = ops.pack_bias(torch.zeros(128, device=DEV), 128)
+    y = torch.zeros((1, 8, 8, 128), dtype=dt, device=DEV)
+    with pytest.raises(ops._lib.IcafError, match="built for 32 -> 64"):
+        run(ops.stem2(img, w0, kp0, b, w1, kp1, b, w2, kp2, b, y, 32, 64, 128))
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_sppf_upsample_copy(dt):
     x = rnd((2, 64, 20, 12), 11)

@@ -202,7 +202,7 @@ def test_all_fusions_on_vs_off_across_shapes(shape, dtype):
             m.model[i].fuse_tail = on
         m.invalidate()
         names = [l.name for l in m.plan_for(B, H, W).launches]
-        assert ("stem" in names) == on and (any(n.endswith("+1x1") for n in names)) == on
+        assert any(n.startswith("stem") for n in names) == on and (any(n.endswith("+1x1") for n in names)) == on
         outs.append(m(rgb.cuda(), ir.cuda())[0].float())
     Conv.fuse_stem = Conv.chain_fuse = Bottleneck.fuse = True
     tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
@@ -210,6 +210,28 @@ def test_all_fusions_on_vs_off_across_shapes(shape, dtype):
     assert torch.isfinite(outs[0]).all()
     assert (outs[0][..., :4] - outs[1][..., :4]).abs().max().item() <= tol * scale
     assert (outs[0][..., 4:] - outs[1][..., 4:]).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("shape", [(2, 320, 320), (3, 352, 416), (1, 640, 512)])
+@pytest.mark.parametrize("u8", [False, True])
+def test_stem2_plan_is_bit_identical_to_three_launch_plan(shape, u8):
+    """Rows 0-2a as one persistent kernel (Conv.fuse_stem2) vs stem -> conv3x3/s2 with chained cv1 | cv2: the whole
+    network output is bit-identical (the intermediate tensors are rounded at the same points), fp32 and uint8 inputs."""
+    B, H, W = shape
+    cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", 17, torch.bfloat16)
+    rgb, ir = synth_images(B, H, W, seed=17)
+    img6 = (torch.cat((rgb, ir), 1) * 255).round().to(torch.uint8).cuda()
+    outs = []
+    try:
+        for on in (True, False):
+            Conv.fuse_stem2 = on
+            m.invalidate()
+            names = [l.name for l in m.plan_for(B, H, W, u8=u8).launches]
+            assert (names[0] == "stem+conv3x3s2+1x1") == on
+            outs.append((m.forward_u8(img6) if u8 else m(rgb.cuda(), ir.cuda()))[0].clone())
+    finally:
+        Conv.fuse_stem2 = True
+    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
 
 
 def test_graph_replay_equals_eager():
