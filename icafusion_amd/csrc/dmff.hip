@@ -75,6 +75,87 @@ __global__ __launch_bounds__(256) void pool_tokens_kernel(const typename Elem<DT
     }
 }
 
+// Overlapping windows (AdaptivePool2d picks kernel = H - (out-1)*stride > stride whenever H is not a multiple of the token
+// grid: P4 of a 640x640 input pools 10x10 windows at stride 2): with one thread per output element every input pixel is
+// read kh*kw/(sh*sw) times — 25x the tensor through L2 for that level, which took longer than the P3 level four times its
+// size.  Sum and max are separable, so a workgroup owning one token ROW (g, b, oy)
+//   1. reduces its kh input rows vertically, one (column, 16-byte channel vector) item per thread and coalesced across
+//      the vectors of a pixel, into fp32 column sums / maxima in LDS  (each pixel is read kh/sh times, not kh*kw/(sh*sw));
+//   2. reduces kw columns per token horizontally from LDS, applies the LearnableWeights mix and the positional embedding.
+// Consecutive token rows (which share kh - sh input rows) run on ONE XCD, so the re-reads hit its L2.
+template <int DT>
+__global__ __launch_bounds__(256) void pool_tokens_rows_kernel(const typename Elem<DT>::type* __restrict__ f0, int ld0,
+                                                               const typename Elem<DT>::type* __restrict__ f1, int ld1,
+                                                               const float* __restrict__ pos0, const float* __restrict__ pos1,
+                                                               typename Elem<DT>::type* __restrict__ tok, int B, int H, int W, int C,
+                                                               int th, int tw, int kh, int kw, int sh, int sw, float w1_0, float w2_0,
+                                                               float w1_1, float w2_1) {
+    using E = Elem<DT>;
+    constexpr int V = E::VEC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int nv = C / V, nitem = W * nv;
+    float* csum = (float*)lds_raw;                     // [W * nv][V]
+    float* cmax = csum + (size_t)nitem * V;            // [W * nv][V]
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7, ix = bid >> 3;
+    const int row = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + ix;      // (as conv_common.h: xcd_tile)
+    const int g = row / (B * th), r = row - g * (B * th), b = r / th, oy = r - b * th;
+    const typename E::type* f = g ? f1 : f0;
+    const int ld = g ? ld1 : ld0;
+    const typename E::type* frow = f + ((long long)b * H + oy * sh) * W * ld;
+    for (int item = threadIdx.x; item < nitem; item += 256) {
+        const int x = item / nv, v = item - x * nv;
+        const typename E::type* p0 = frow + (long long)x * ld + v * V;
+        float sum[V], mx[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { sum[j] = 0.0f; mx[j] = -INFINITY; }
+        for (int d0 = 0; d0 < kh; d0 += 4) {           // four rows in flight
+            u32x4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (d0 + u < kh) raw[u] = *(const u32x4*)(p0 + (long long)(d0 + u) * W * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (d0 + u < kh) {
+                    float t[V];
+                    unpack16<DT>(raw[u], t);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) { sum[j] += t[j]; mx[j] = fmaxf(mx[j], t[j]); }
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+            *(f32x4*)(csum + (size_t)item * V + j) = f32x4{sum[j], sum[j + 1], sum[j + 2], sum[j + 3]};
+            *(f32x4*)(cmax + (size_t)item * V + j) = f32x4{mx[j], mx[j + 1], mx[j + 2], mx[j + 3]};
+        }
+    }
+    __syncthreads();
+    const float inv_area = 1.0f / (float)(kh * kw);
+    const float w1 = g ? w1_1 : w1_0, w2 = g ? w2_1 : w2_0;
+    const int N = th * tw;
+    for (int o = threadIdx.x; o < tw * nv; o += 256) {
+        const int ox = o / nv, v = o - ox * nv;
+        float sum[V], mx[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { sum[j] = 0.0f; mx[j] = -INFINITY; }
+        for (int dx = 0; dx < kw; ++dx) {
+            const size_t it = (size_t)((ox * sw + dx) * nv + v) * V;
+#pragma unroll
+            for (int j = 0; j < V; j += 4) {
+                const f32x4 a = *(const f32x4*)(csum + it + j), m = *(const f32x4*)(cmax + it + j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sum[j + e] += a[e]; mx[j + e] = fmaxf(mx[j + e], m[e]); }
+            }
+        }
+        const int n = oy * tw + ox;
+        const float* pos = (g ? pos1 : pos0) + (long long)n * C + v * V;
+        float out[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) out[j] = (sum[j] * inv_area) * w1 + mx[j] * w2 + pos[j];
+        *(u32x4*)(tok + (((long long)g * B + b) * N + n) * C + v * V) = pack16<DT>(out);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: one wavefront per token row, values held in registers, two-pass statistics
 // ---------------------------------------------------------------------------------------------------------------
@@ -419,6 +500,18 @@ template <int DT>
 int run_pool_tokens(const void* f0, int ld0, const void* f1, int ld1, const float* p0, const float* p1, void* tok, int B, int H, int W, int C,
                     int th, int tw, int kh, int kw, int sh, int sw, float a0, float b0, float a1, float b1, hipStream_t s) {
     using T = typename Elem<DT>::type;
+    const size_t rows_lds = (size_t)W * C * 2 * sizeof(float);        // fp32 column sums + maxima of one token row
+    if ((kh > sh || kw > sw) && rows_lds <= 160 * 1024) {             // overlapping windows: separable, one token row per workgroup
+        static size_t attr_bytes = 0;
+        if (rows_lds > 64 * 1024 && rows_lds > attr_bytes) {
+            ICAF_HIP(hipFuncSetAttribute((const void*)pool_tokens_rows_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
+            attr_bytes = rows_lds;
+        }
+        pool_tokens_rows_kernel<DT><<<dim3((unsigned)(2 * B * th)), dim3(256), rows_lds, s>>>((const T*)f0, ld0, (const T*)f1, ld1, p0, p1, (T*)tok,
+                                                                                             B, H, W, C, th, tw, kh, kw, sh, sw, a0, b0, a1, b1);
+        ICAF_LAUNCH_CHECK();
+        return ICAF_OK;
+    }
     const long long total = 2LL * B * th * tw * (C / Elem<DT>::VEC);
     pool_tokens_kernel<DT><<<dim3(grid_for(total)), dim3(256), 0, s>>>((const T*)f0, ld0, (const T*)f1, ld1, p0, p1, (T*)tok, B, H, W, C, th,
                                                                         tw, kh, kw, sh, sw, a0, b0, a1, b1);
