@@ -1,13 +1,12 @@
 #!/bin/bash
 # bench + rocprofv3 kernel-trace stats of the same command (summaries are copied to profiles/ by hand afterwards).
-# The igemm tile choices of the first run are cached in gpurun_out/tune.json so the profiled runs launch the same kernels.
+# Both runs load the committed igemm tile choices (profiles/tune_cache.json), so the profiled run launches the same kernels.
 mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-rm -f gpurun_out/tune.json
-timeout 900 python bench.py --tune-cache gpurun_out/tune.json "$@" > gpurun_out/bench.json 2> gpurun_out/bench.err
+timeout 900 python bench.py "$@" > gpurun_out/bench.json 2> gpurun_out/bench.err
 tail -c 6000 gpurun_out/bench.json; tail -5 gpurun_out/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --tune-cache $R/gpurun_out/tune.json "$@" --no-cpu-baseline > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py "$@" --no-cpu-baseline > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err
 tail -3 $R/gpurun_out/prof.err
 f=$(find $R/gpurun_out/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cut -c1-160 "$f" | head -25

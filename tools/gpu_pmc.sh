@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic per kernel from the L2 memory-side counters, one counter per pass (FETCH_SIZE and WRITE_SIZE do not fit
 # together: MI355X_MICROARCH.md "rocprofv3 PMC slots").  Kernel-trace only — no other trace domain is combined with --pmc.
-# Run after tools/gpu_bench.sh (re-uses gpurun_out/tune.json so the same igemm instantiations are measured).
+# Loads the committed igemm tile choices (profiles/tune_cache.json): the same instantiations as tools/gpu_bench.sh.
 # Summary: gpurun_out/pmc_summary.json (copied to profiles/pmc_traffic.json by hand; bench.py reads roofline.traffic there).
 mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o pmc -- \
-      python $R/bench.py --tune-cache $R/gpurun_out/tune.json --no-cpu-baseline --no-graph --no-overlap --steps 3 --warmup 1 "$@" > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.err
+      python $R/bench.py --no-cpu-baseline --no-graph --no-overlap --steps 3 --warmup 1 "$@" > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.err
   tail -2 $R/gpurun_out/pmc_$c.err
 done
 cd $R

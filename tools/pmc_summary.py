@@ -19,10 +19,11 @@ def short(name):
     """rocprof kernel name -> the name bench.py reports (igemm instantiations that differ only in the activation
     template argument are merged, as ops.conv_kernel_name does)."""
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"icaf::igemm_dma_kernel<(\d+), (\d+), (\d+), (\d+), \d+, \d+, \d+, (\d+), (\d+)(?:, \w+)*>", name)
+    m = re.match(r"icaf::igemm_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), \d+, (\d+), (\d+)(?:, \w+)*>", name)
     if m:
-        dt, odt, bm, bn, rb, ns = map(int, m.groups())
-        return f"igemm_dma{rb}x{ns}_{_DN[dt]}_{_DN[odt]}_{bm}x{bn}"
+        dt, odt, bm, bn, wm, wn, rb, ns = map(int, m.groups())
+        w8 = "w8" if bm == 128 and (bm // wm) * (bn // wn) == 8 else ""          # 8-wavefront build of a 128-row tile
+        return f"igemm_dma{rb}x{ns}_{_DN[dt]}_{_DN[odt]}_{bm}x{bn}{w8}"
     m = re.match(r"icaf::igemm_kernel<(\d+), (\d+), (\d+), (\d+),", name)
     if m:
         dt, odt, bm, bn = map(int, m.groups())
@@ -35,7 +36,8 @@ def short(name):
     if m:
         return {"preprocess_kernel": "preprocess_s2d", "pool_tokens_kernel": "dmff_pool_tokens", "upsample_merge_kernel": "dmff_upsample_merge",
                 "cross_attn_kernel": "cross_attention", "detect_decode_kernel": "detect_decode", "sppf_lds_kernel": "sppf_pool",
-                "upsample_kernel": "upsample_nearest", "stem_kernel": "stem", "bneck_kernel": "bottleneck"}.get(m.group(1), m.group(1))
+                "upsample_kernel": "upsample_nearest", "stem_kernel": "stem", "bneck_kernel": "bottleneck",
+                "stem2_kernel": "stem+conv3x3s2+1x1", "pool_tokens_rows_kernel": "dmff_pool_tokens"}.get(m.group(1), m.group(1))
     return name[:80]
 
 
