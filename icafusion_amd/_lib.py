@@ -34,7 +34,8 @@ class ConvArgs(C.Structure):
 
 class BneckArgs(C.Structure):
     _fields_ = [("conv", ConvArgs), ("w1", C.c_void_p), ("bias1", C.c_void_p), ("w1_gs", C.c_longlong),
-                ("bias1_gs", C.c_longlong), ("Kp1", C.c_int), ("shape", C.c_int)]
+                ("bias1_gs", C.c_longlong), ("Kp1", C.c_int), ("shape", C.c_int),
+                ("x2", C.c_void_p), ("x2_gs", C.c_longlong), ("ldx2", C.c_int), ("reserved", C.c_int)]
 
 
 class Stem2Args(C.Structure):

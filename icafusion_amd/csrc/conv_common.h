@@ -18,6 +18,7 @@ struct ConvP {
     long long w1_gs, bias1_gs; int Kp1; unsigned int w1_bytes;
     const void* w2; const float* bias2; void* y2;  // chained 1x1 convolution behind this layer (igemm.hip, CHAIN)
     long long w2_gs, bias2_gs, y2_gs; int Kp2, Cout2, ldy2, vec_y2, keep1; unsigned int w2_bytes;
+    const void* x2; long long x2_gs; int ldx2;     // fused Bottleneck + cv3 (ctile.hip, CHAIN3): the cv2 half of cv3's input
 };
 
 constexpr int ROWB = 64;        // bytes of K per LDS row per slice

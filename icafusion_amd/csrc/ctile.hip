@@ -33,7 +33,13 @@ template <int S, int TW> struct HaloGeom {
 // 128-byte slice), its SiLU output is written — zeroed outside the image, which is the 3x3's zero padding — as a second
 // LDS patch in the same swizzled layout, and the unchanged 3x3 loop reads that patch.  The intermediate tensor of the
 // two-launch form (written and re-read at full resolution) never exists; the residual is the epilogue's `res` = x.
-template <int DT, int TH, int TW, int BN, int ACT, int S, bool FUSE1>
+// CHAIN3 = true (with FUSE1, c_ = BN = 32) appends the C3's cv3 to the Bottleneck (reference models/common.py:226:
+//   cv3(cat(m(cv1(x)), cv2(x)))): the Bottleneck's output tile — residual added and rounded to the storage type exactly
+// as it would be written — is placed beside the cv2 half of the same pixels (fetched from HBM) in an LDS tile, which is
+// the pixel operand of the 2c_ -> Cout2 1x1 (weights resident in LDS); only cv3's output is written (p.w2 / bias2 / y2,
+// p.x2 = the cv2 half).  Channel order of the tile = [cv2 | m] (the order the three-slot C3 buffer presents after one
+// fused Bottleneck; the weights are packed to match), K order and MFMA step as igemm: bit-identical to the two launches.
+template <int DT, int TH, int TW, int BN, int ACT, int S, bool FUSE1, bool CHAIN3 = false>
 __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const int lcin, const int tiles_x,
                                            const int tiles_per_img, const int halo_bytes) {
     using E = Elem<DT>;
@@ -54,6 +60,7 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
     unsigned char* halo = FUSE1 ? lds + halo_bytes : lds;          // the patch the 3x3 loop reads
     unsigned char* w1buf = lds + 2 * halo_bytes;                   // FUSE1: the 1x1 weights, BN rows x 128 bytes
     unsigned char* ring = FUSE1 ? w1buf + BN * RB : lds + halo_bytes;
+    unsigned char* w3buf = ring + NS * WSTAGE;                     // CHAIN3: cv3's weights, 2*BN rows x 128 bytes
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,6 +151,15 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
             const unsigned voff = w1_off0 + (unsigned)(32 * i) * (unsigned)p.Kp1 * E::BYTES;     // (keep it a variable, see stem.hip)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w1r, (lds_ptr_t)(w1buf + (wave + 4 * i) * 1024), 16, voff, 0, 0, 0);
         }
+        if constexpr (CHAIN3) {
+            const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((const typename E::type*)p.w2 + g * p.w2_gs), 0, p.w2_bytes, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 2 * NBW; ++i) {
+                const unsigned voff = ((unsigned)(wave * 8 + rsub + 32 * i) * (unsigned)p.Kp2 + (unsigned)(lslot * VEC)) * E::BYTES;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w3r, (lds_ptr_t)(w3buf + (wave + 4 * i) * 1024), 16, voff, 0, 0, 0);
+            }
+        }
         wait_vmcnt<0>();
         __syncthreads();                                               // input patch + 1x1 weights visible
         // the 1x1's bias in registers: loaded inside the loop below it would be a dependent L2 round trip per use
@@ -232,12 +248,95 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    epilogue<DT, DT, BM, BN, WM, BN, ACT, false>(acc, lds, p, g, [&](int row) {
+    auto row_to_m = [&](int row) {
         const int st = row >> 5, r = row & 31;
         const int py = TW == 32 ? st : st * 2 + (r >> 4), px = TW == 32 ? r : (r & 15);
         const int gy = y0 + py, gx = x0 + px;
         return (gy < p.Ho && gx < p.Wo) ? (b * p.Ho + gy) * p.Wo + gx : -1;
-    }, 0);
+    };
+    if constexpr (CHAIN3) {
+        static_assert(FUSE1 && TN == 1 && BN == 32, "cv3 chained behind the fused Bottleneck: c_ = 32");
+        constexpr int N3 = 2 * BN, SO3 = N3 * E::BYTES + 16;           // tile row: [cv2 | m], stride as the epilogue's
+        unsigned char* T = lds;                                        // (both patches are free: every wave left the 3x3 loop)
+        // (a) SiLU(acc + bias) -> tile columns [BN, 2BN), rounded to the storage type (what the epilogue stages)
+        {
+            const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
+            f32x4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = bias ? *(const f32x4*)(bias + 8 * q + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = 8 * q + 4 * hi;
+#pragma unroll
+                for (int bb = 0; bb < TM; ++bb) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT>(acc[0][bb][4 * q + j] + bq[q][j]) * p.alpha_acc[g];
+                    u32x2 pk;
+                    if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
+                    else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
+                    *(u32x2*)(T + (wave * WM + bb * 32 + l31) * SO3 + (BN + nl) * E::BYTES) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        // (b) + residual (the Bottleneck's input), rounded as the two-launch form stores it; the cv2 half beside it
+        {
+            constexpr int VPR = BN / VEC, NIT = BM * VPR / NTHREADS;   // 4 vectors per row and half, 4 rows per thread
+            const typename E::type* __restrict__ rg = p.res ? (const typename E::type*)p.res + g * p.res_gs : nullptr;
+            const typename E::type* __restrict__ x2g = (const typename E::type*)p.x2 + g * p.x2_gs;
+            u32x4 rv[NIT], cv2v[NIT];
+            int mrow[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * NTHREADS, row = idx / VPR, cv = idx - row * VPR;
+                mrow[it] = row_to_m(row);
+                const long long mm = mrow[it] < 0 ? 0 : mrow[it];
+                rv[it] = rg ? *(const u32x4*)(rg + mm * p.ldr + cv * VEC) : u32x4{0u, 0u, 0u, 0u};
+                cv2v[it] = *(const u32x4*)(x2g + mm * p.ldx2 + cv * VEC);
+            }
+            const float alpha_res = p.alpha_res[g];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * NTHREADS, row = idx / VPR, cv = idx - row * VPR;
+                unsigned char* trow = T + row * SO3;
+                *(u32x4*)(trow + cv * 16) = cv2v[it];
+                if (rg) {
+                    float v[VEC], r[VEC];
+                    unpack16<DT>(*(const u32x4*)(trow + (VPR + cv) * 16), v);
+                    unpack16<DT>(rv[it], r);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) v[j] += alpha_res * r[j];
+                    *(u32x4*)(trow + (VPR + cv) * 16) = pack16<DT>(v);
+                }
+            }
+        }
+        __syncthreads();
+        // (c) cv3 = W3 . tile  (K = 2 c_ = 64: four MFMA steps)
+        f32x16 acc3[2][TM];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < TM; ++bb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[a][bb][r] = 0.0f;
+#pragma unroll
+        for (int s3 = 0; s3 < N3 / KSTEP; ++s3) {
+            u32x4 fp3[TM], fw3[2];
+#pragma unroll
+            for (int bb = 0; bb < TM; ++bb) fp3[bb] = *(const u32x4*)(T + (wave * WM + bb * 32 + l31) * SO3 + ((2 * s3 + hi) << 4));
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fw3[a] = *(const u32x4*)(w3buf + (a * 32) * RB + foff[s3]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < TM; ++bb) mma_step<DT>(acc3[a][bb], fw3[a], fp3[bb]);
+        }
+        __syncthreads();                           // the tile has been consumed: the epilogue may overwrite it
+        epilogue<DT, DT, BM, N3, WM, N3, ICAF_ACT_SILU, false, true>(acc3, lds, p, g, row_to_m, 0);
+    } else {
+        epilogue<DT, DT, BM, BN, WM, BN, ACT, false>(acc, lds, p, g, row_to_m, 0);
+    }
 }
 
 template <int DT, int TH, int TW, int BN, int ACT, int S>
@@ -246,10 +345,10 @@ __global__ __launch_bounds__(NTHREADS) void ctile_kernel(const ConvP p, const in
     ctile_body<DT, TH, TW, BN, ACT, S, false>(p, lsp, lcin, tiles_x, tiles_per_img, halo_bytes);
 }
 
-template <int DT, int TH, int TW, int BN, int ACT>
+template <int DT, int TH, int TW, int BN, int ACT, bool CHAIN3 = false>
 __global__ __launch_bounds__(NTHREADS) void bneck_kernel(const ConvP p, const int lsp, const int lcin, const int tiles_x,
                                                          const int tiles_per_img, const int halo_bytes) {
-    ctile_body<DT, TH, TW, BN, ACT, 1, true>(p, lsp, lcin, tiles_x, tiles_per_img, halo_bytes);
+    ctile_body<DT, TH, TW, BN, ACT, 1, true, CHAIN3>(p, lsp, lcin, tiles_x, tiles_per_img, halo_bytes);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -277,12 +376,12 @@ int ctile_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     if (a->Cout > sh.bn) return fail(ICAF_ERR_UNSUPPORTED, "ctile %s: Cout=%d > %d", sh.tag, a->Cout, sh.bn);
     if (a->act != ICAF_ACT_SILU || a->out_dtype != a->dtype) return fail(ICAF_ERR_UNSUPPORTED, "ctile: SiLU and out dtype == dtype only");
     if (p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "ctile: operand exceeds the 2 GiB buffer-descriptor range");
-    if (a->pre || a->w2) return fail(ICAF_ERR_UNSUPPORTED, "ctile: no pre-activation term / chained 1x1");
+    if (a->pre) return fail(ICAF_ERR_UNSUPPORTED, "ctile: no pre-activation term");
     if (a->Kp % (128 / eb)) return fail(ICAF_ERR_UNSUPPORTED, "ctile: Kp must be a multiple of 128 bytes");
     return ICAF_OK;
 }
 
-template <int DT, int TH, int TW, int BN, int S, bool FUSE1 = false>
+template <int DT, int TH, int TW, int BN, int S, bool FUSE1 = false, bool CHAIN3 = false>
 static int launch_ctile_cfg(const ConvP& p, int groups, hipStream_t s) {
     using G = HaloGeom<S, TW>;
     constexpr int EB = Elem<DT>::BYTES;
@@ -293,8 +392,9 @@ static int launch_ctile_cfg(const ConvP& p, int groups, hipStream_t s) {
     const int nslots = (HH * G::PITCH) << lsp;
     const int halo_bytes = ((nslots + 63) / 64) * 1024;
     const int ring = 3 * BN * 128;
-    const int stage_out = BM * (BN * EB + 16);
-    int lds = (FUSE1 ? 2 * halo_bytes + BN * 128 : halo_bytes) + ring;
+    const int stage_out = BM * ((CHAIN3 ? 2 : 1) * BN * EB + 16);
+    if (CHAIN3 && stage_out > 2 * halo_bytes) return fail(ICAF_ERR_UNSUPPORTED, "icaf_bottleneck: the cv3 tile does not fit over the two patches");
+    int lds = (FUSE1 ? 2 * halo_bytes + BN * 128 : halo_bytes) + ring + (CHAIN3 ? 2 * BN * 128 : 0);
     if (lds < stage_out) lds = stage_out;
     if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "ctile: %d bytes of LDS needed", lds);
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
@@ -302,7 +402,7 @@ static int launch_ctile_cfg(const ConvP& p, int groups, hipStream_t s) {
     q.ntiles = 1;
     q.nchunks = (p.K + 128 / EB - 1) / (128 / EB);
     void (*kern)(const ConvP, const int, const int, const int, const int, const int);
-    if constexpr (FUSE1) kern = bneck_kernel<DT, TH, TW, BN, ICAF_ACT_SILU>;
+    if constexpr (FUSE1) kern = bneck_kernel<DT, TH, TW, BN, ICAF_ACT_SILU, CHAIN3>;
     else kern = ctile_kernel<DT, TH, TW, BN, ICAF_ACT_SILU, S>;
     static int attr_bytes = 0;                        // per instantiation: largest dynamic LDS size enabled so far
     if (lds > 64 * 1024 && lds > attr_bytes) {
@@ -333,6 +433,12 @@ int launch_bneck(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t
     if (a->dtype == ICAF_F32) return fail(ICAF_ERR_UNSUPPORTED, "icaf_bottleneck: 16-bit types only");
     if (a->Cin != a->Cout || (a->Cin != 32 && a->Cin != 64) || kShapes[shape - 1].bn != a->Cout || kShapes[shape - 1].s != 1)
         return fail(ICAF_ERR_UNSUPPORTED, "icaf_bottleneck: c_ = %d -> %d with patch shape %d is not built (c_ in {32, 64})", a->Cin, a->Cout, shape);
+    if (a->w2) {          // cv3 chained behind the Bottleneck: c_ = 32 (shape 1), 64 output channels or fewer, with a residual or not
+        if (shape != 1 || a->Cout2 > 64 || a->Kp2 != 64 || !p.x2 || p.ldx2 % 8 || ((uintptr_t)p.x2 & 15) || !p.vec_r && a->res)
+            return fail(ICAF_ERR_UNSUPPORTED, "icaf_bottleneck: chained cv3 needs patch shape 1 (c_ = 32), Cout2 <= 64, Kp2 = 64, an aligned cv2 half");
+        if (a->dtype == ICAF_BF16) return launch_ctile_cfg<ICAF_BF16, 8, 32, 32, 1, true, true>(p, a->groups, s);
+        return launch_ctile_cfg<ICAF_F16, 8, 32, 32, 1, true, true>(p, a->groups, s);
+    }
     if (a->dtype == ICAF_BF16) {
         if (shape == 1) return launch_ctile_cfg<ICAF_BF16, 8, 32, 32, 1, true>(p, a->groups, s);
         if (shape == 2) return launch_ctile_cfg<ICAF_BF16, 8, 32, 64, 1, true>(p, a->groups, s);
@@ -346,6 +452,7 @@ int launch_bneck(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t
 int launch_ctile(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s) {
     int st = ctile_check(a, p, shape);
     if (st) return st;
+    if (a->w2) return fail(ICAF_ERR_UNSUPPORTED, "ctile: no chained 1x1 (icaf_bottleneck chains the C3's cv3)");
     if (a->dtype == ICAF_BF16) return launch_ctile_dt<ICAF_BF16>(p, a->groups, shape, s);
     if (a->dtype == ICAF_F16) return launch_ctile_dt<ICAF_F16>(p, a->groups, shape, s);
     return launch_ctile_dt<ICAF_F32>(p, a->groups, shape, s);

@@ -27,7 +27,7 @@
 #include "conv_common.h"
 
 static_assert(sizeof(icaf_conv_args) == 272, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
-static_assert(sizeof(icaf_bneck_args) == 312, "icaf_bneck_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
+static_assert(sizeof(icaf_bneck_args) == 336, "icaf_bneck_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
 
 namespace icaf {
 
@@ -638,6 +638,7 @@ static void fill(const icaf_conv_args* a, ConvP& p) {
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.ldx = a->ldx; p.Ho = a->Ho; p.Wo = a->Wo; p.Cout = a->Cout;
     p.ldy = a->ldy; p.kh = a->kh; p.kw = a->kw; p.sh = a->sh; p.sw = a->sw; p.ph = a->ph; p.pw = a->pw; p.ldr = a->ldr;
     p.Kp = a->Kp; p.act = a->act;
+    p.x2 = nullptr; p.x2_gs = 0; p.ldx2 = 0;
     p.M = a->B * a->Ho * a->Wo;
     p.K = a->kh * a->kw * a->Cin;
     const int bk = a->dtype == ICAF_F32 ? 16 : 32;
@@ -697,6 +698,7 @@ extern "C" int icaf_bottleneck(const icaf_bneck_args* b, icaf_stream_t s) {
     fill(a, p);
     p.w1 = b->w1; p.bias1 = b->bias1; p.w1_gs = b->w1_gs; p.bias1_gs = b->bias1_gs; p.Kp1 = b->Kp1;
     p.w1_bytes = (unsigned)((((long long)a->Cout + 127) / 128 * 128) * b->Kp1 * eb);
+    p.x2 = b->x2; p.x2_gs = b->x2_gs; p.ldx2 = b->ldx2;
     return launch_bneck(a, p, b->shape, S(s));
 }
 

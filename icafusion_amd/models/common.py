@@ -339,11 +339,29 @@ class Bottleneck(HipModule):
                 and a.groups == 1 and b.groups == 1 and isinstance(self.cv1.act, nn.SiLU) and isinstance(self.cv2.act, nn.SiLU)
                 and x.shape[-2] >= 64)
 
-    def emit_fused(self, plan, x, out, twin=None):
-        """y = [x +] SiLU(conv3x3(SiLU(conv1x1(x)))) as ONE launch; `out` must be a different buffer (slice) than x."""
+    def emit_fused(self, plan, x, out, twin=None, cv3=None):
+        """y = [x +] SiLU(conv3x3(SiLU(conv1x1(x)))) as ONE launch; `out` must be a different buffer (slice) than x.
+        cv3 = (Conv, twin Conv or None, x2, y3): the C3's cv3 rides on the launch — x2 is the cv2 half of its input, y3 its
+        output; the Bottleneck's own output is then never written (`out` is ignored)."""
         c = self.cv1.conv.in_channels
         paired = twin is not None
         mods = [self] + ([twin] if paired else [])
+        tail = None
+        if cv3 is not None:
+            k3, k3t, x2, y3 = cv3
+
+            def pack3():          # K columns in the order [cv2 | m]: exactly Conv.emit(swap_halves=True)'s packing (shared cache key)
+                packs = []
+                for cv in [k3] + ([k3t] if paired else []):
+                    w, b = cv.folded()
+                    h = w.shape[1] // 2
+                    wp, kp = ops.pack_conv_weight(torch.cat((w[:, h:], w[:, :h]), 1), plan.dtype)
+                    packs.append((wp, kp, ops.pack_bias(b, w.shape[0])))
+                if not paired:
+                    return packs[0]
+                return (torch.stack([p[0] for p in packs]).contiguous(), packs[0][1], torch.stack([p[2] for p in packs]).contiguous())
+            w3, kp3, b3 = k3._cached(("std", plan.dtype, plan.device, id(k3t), (), True), pack3)
+            tail = dict(w=w3, kp=kp3, bias=b3, y=y3, cout=k3.conv.out_channels, x2=x2)
 
         def make():
             p1 = [ops.pack_conv_weight(m.cv1.folded()[0], plan.dtype) for m in mods]
@@ -353,8 +371,8 @@ class Bottleneck(HipModule):
             st = (lambda ts: torch.stack(ts).contiguous()) if paired else (lambda ts: ts[0])
             return st([p[0] for p in p1]), p1[0][1], st(b1), st([p[0] for p in p2]), p2[0][1], st(b2)
         w1, kp1, b1, w2, kp2, b2 = self._cached(("bneck", plan.dtype, plan.device, id(twin)), make)
-        plan.add(ops.bottleneck(x, w1, kp1, b1, w2, kp2, b2, out, c, self.add, 1 if c == 32 else 2))
-        return out
+        plan.add(ops.bottleneck(x, w1, kp1, b1, w2, kp2, b2, None if tail else out, c, self.add, 1 if c == 32 else 2, cv3=tail))
+        return tail["y"] if tail else out
 
 
 class C3(HipModule):
@@ -369,6 +387,8 @@ class C3(HipModule):
         self.cv2 = Conv(c1, c_, 1, 1)
         self.cv3 = Conv(2 * c_, c2, 1)
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
+
+    fuse_cv3 = True      # n = 1, c_ = 32: Bottleneck + cv3 as one launch (icaf_bottleneck with a chained cv3)
 
     def emit(self, plan, x, out=None, twin=None, lead=None):
         """lead = (Conv, twin Conv or None): the down-sampling Conv in front of this block whose output only this block
@@ -390,7 +410,10 @@ class C3(HipModule):
         # Buffer of three c_-wide slots [a | b | a']: cv1|cv2 write [a | b]; a fused Bottleneck cannot run in place (its
         # neighbours' patches read x), so the chain ping-pongs between slot 0 and slot 2; cv3 then reads [a | b] or
         # [b | a'] — in the second case with its weight columns swapped to match.
-        cat = plan.act(B, H, W, (3 if any(fused) else 2) * c_, pair=paired)
+        k3 = self.cv3.conv
+        tail3 = (self.fuse_cv3 and len(self.m) == 1 and fused[0] and c_ == 32 and k3.out_channels <= 64 and k3.kernel_size == (1, 1)
+                 and k3.stride == (1, 1) and k3.groups == 1 and k3.in_channels == 2 * c_ and isinstance(self.cv3.act, nn.SiLU))
+        cat = plan.act(B, H, W, (3 if any(fused) and not tail3 else 2) * c_, pair=paired)
         if lead is not None and len(lead) == 4:
             lead[2].emit_stem2(plan, x, lead[3], lead[0], lead[1], (self.cv1, self.cv2), (twin.cv1, twin.cv2), cat[..., :2 * c_])
         elif lead is not None:
@@ -399,6 +422,11 @@ class C3(HipModule):
         else:
             self.cv1.emit(plan, x, out=cat[..., :2 * c_], twin=twin.cv1 if paired else None, also=(self.cv2,),
                           twin_also=(twin.cv2,) if paired else ())
+        if tail3:         # the single fused Bottleneck carries cv3 as well: cat(m, cv2) and m never reach HBM
+            if out is None:
+                out = plan.act(B, H, W, k3.out_channels, pair=paired)
+            return self.m[0].emit_fused(plan, cat[..., :c_], None, twin=twin.m[0] if paired else None,
+                                        cv3=(self.cv3, twin.cv3 if paired else None, cat[..., c_:2 * c_], out))
         cur = 0
         for j, blk in enumerate(self.m):
             a = cat[..., cur * c_:(cur + 1) * c_]

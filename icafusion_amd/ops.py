@@ -170,10 +170,15 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
                   nbytes=nbytes)
 
 
-def bottleneck(x, w1_packed, kp1, bias1, w2_packed, kp2, bias2, y, c, add, shape, name="bottleneck"):
+def bottleneck(x, w1_packed, kp1, bias1, w2_packed, kp2, bias2, y, c, add, shape, name="bottleneck", cv3=None):
     """Whole Bottleneck (1x1 -> 3x3 [+ x]) in one launch (icaf_bottleneck).  x, y: acts or pair acts of c channels in
-    DIFFERENT buffers; w1 / w2: packed 1x1 / 3x3 weights (stacked per stream for pair acts)."""
-    inner = conv2d(x, w2_packed, kp2, bias2, y, 3, 3, 1, 1, 1, 1, c, c, ACT_SILU, res=x if add else None, name=name)
+    DIFFERENT buffers; w1 / w2: packed 1x1 / 3x3 weights (stacked per stream for pair acts).
+    cv3 = dict(w=, kp=, bias=, y=, cout=, x2=): the C3's cv3 rides on the block — x2 is the cv2 half of its input, w its
+    packed weights with K columns ordered [cv2 | m]; only cv3's output (y of the dict) is written and `y` may be None."""
+    if cv3 is not None and y is None:
+        y = cv3["y"][..., :c]                     # (ignored by the kernel; satisfies the argument checks)
+    inner = conv2d(x, w2_packed, kp2, bias2, y, 3, 3, 1, 1, 1, 1, c, c, ACT_SILU, res=x if add else None, name=name,
+                   chain=None if cv3 is None else dict(w=cv3["w"], kp=cv3["kp"], bias=cv3["bias"], y=cv3["y"], cout=cv3["cout"]))
     b = BneckArgs()
     C.memmove(C.byref(b.conv), C.byref(inner.keep[0]), C.sizeof(ConvArgs))
     b.w1, b.bias1 = w1_packed.data_ptr(), bias1.data_ptr()
@@ -185,8 +190,15 @@ def bottleneck(x, w1_packed, kp1, bias1, w2_packed, kp2, bias2, y, c, add, shape
     flops = inner.flops + 2.0 * g * B * H * W * c * c
     es = x.element_size()
     nbytes = g * (B * H * W * c * es * (3 if add else 2) + (9 * c * c + c * c) * es)
-    return Launch(lib().icaf_bottleneck, (C.byref(b),), keep=(b, inner.keep, w1_packed, bias1), name=name, flops=flops,
-                  nbytes=nbytes)
+    if cv3 is not None:
+        x2 = cv3["x2"]
+        B2, H2, W2, c2, ldx2 = _act_geom(x2)
+        assert (B2, H2, W2) == (B, H, W) and c2 >= c and x2.dtype == x.dtype and (x2.dim() == 5) == paired
+        b.x2, b.ldx2, b.x2_gs = x2.data_ptr(), ldx2, x2.stride(0) if paired else 0
+        nbytes = g * (B * H * W * es * (2 * c + cv3["cout"]) + (10 * c * c + 2 * c * cv3["cout"]) * es)
+        flops += 2.0 * g * B * H * W * c * cv3["cout"]          # (conv2d counted K = c for the chained layer; cv3 has K = 2c)
+    return Launch(lib().icaf_bottleneck, (C.byref(b),), keep=(b, inner.keep, w1_packed, bias1, cv3), name=name + ("+cv3" if cv3 else ""),
+                  flops=flops, nbytes=nbytes)
 
 
 _TUNE_CACHE = {}

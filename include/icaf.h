@@ -140,7 +140,12 @@ int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s);
  * channels with c_ in {32, 64}, 16-bit types.  `conv` describes the 3x3 / stride 1 / pad 1 layer (x = block input,
  * w / bias = its packed weights, y = block output — a DIFFERENT buffer than x —, res = x for the shortcut or NULL);
  * w1 / bias1 are the packed 1x1 weights ([Np][Kp1], Kp1 = 128 bytes) applied first.  The 1x1 output never reaches HBM.
- * shape: LDS patch 1 = 8x32 pixels (c_ = 32), 2 = 8x32 (c_ = 64), 3 = 8x16 (c_ = 64). */
+ * shape: LDS patch 1 = 8x32 pixels (c_ = 32), 2 = 8x32 (c_ = 64), 3 = 8x16 (c_ = 64).
+ * With conv.w2 != NULL (shape 1 only) the C3's cv3 rides on the block (models/common.py:226):
+ *   y2 = SiLU( W2 . cat(x2, [x +] SiLU(conv3x3(...))) + bias2 )
+ * x2 = the cv2 half of cv3's input (NHWC, c_ channels, pixel stride ldx2), W2 packed [Np][64] with its K columns in the
+ * order [cv2 | m]; only y2 (conv.y2 / ldy2 / Cout2 <= 64) is written — conv.y is ignored.  Bit-identical to icaf_bottleneck
+ * followed by the 1x1 icaf_conv2d. */
 typedef struct icaf_bneck_args {
     icaf_conv_args conv;
     const void* w1;
@@ -148,6 +153,9 @@ typedef struct icaf_bneck_args {
     long long w1_gs, bias1_gs; /* per-group strides (elements / floats) */
     int Kp1;
     int shape;
+    const void* x2;
+    long long x2_gs;
+    int ldx2, reserved;
 } icaf_bneck_args;
 int icaf_bottleneck(const icaf_bneck_args* a, icaf_stream_t s);
 /* name of the kernel instantiation icaf_conv2d would launch for these args (host string, for profiling) */

@@ -212,6 +212,50 @@ def test_fused_bottleneck_equals_two_launches(case, dt):
         close(from_act(y_f[g] if paired else y_f), ref, dt, f"bottleneck {case} stream {g}")
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 64, 96, 64, True, True), (1, 70, 90, 64, True, False), (3, 72, 64, 48, False, True),
+                                  (1, 160, 160, 64, False, False)])
+def test_bottleneck_with_chained_cv3_equals_two_launches(case, dt):
+    """icaf_bottleneck with the C3's cv3 riding on it (the Bottleneck output and cat(m, cv2) stay in LDS) vs icaf_bottleneck
+    followed by the 1x1 cv3 over the [cv2 | m] slots of the C3 buffer: bit-identical; ragged patches, shortcut on / off,
+    one and two streams."""
+    B, H, W, c3, add, paired = case
+    c = 32
+    G = 2 if paired else 1
+    xs = [rnd((B, 3 * c, H, W), 201 + g) for g in range(G)]            # slots [a | b | a'] of the C3 buffer (a' overwritten)
+    w1 = [rnd((c, c, 1, 1), 203 + g, 1.0 / math.sqrt(c)) for g in range(G)]
+    w2 = [rnd((c, c, 3, 3), 205 + g, 1.0 / math.sqrt(9 * c)) for g in range(G)]
+    w3 = [rnd((c3, 2 * c, 1, 1), 207 + g, 1.0 / math.sqrt(2 * c)) for g in range(G)]      # columns [m | cv2], as C3.cv3's
+    b1, b2 = [rnd((c,), 209 + g, 0.2) for g in range(G)], [rnd((c,), 211 + g, 0.2) for g in range(G)]
+    b3 = [rnd((c3,), 213 + g, 0.2) for g in range(G)]
+    st = (lambda ts: torch.stack(ts).contiguous()) if paired else (lambda ts: ts[0])
+    cat = st([to_act(x, dt) for x in xs])
+    p1 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w1]
+    p2 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w2]
+    p3 = [ops.pack_conv_weight(torch.cat((w[:, c:], w[:, :c]), 1).to(DEV), dt) for w in w3]     # -> [cv2 | m]
+    w1p, w2p, w3p = (st([p_[0] for p_ in ps]) for ps in (p1, p2, p3))
+    b1p, b2p, b3p = (st([ops.pack_bias(b.to(DEV), n) for b in bs]) for bs, n in ((b1, c), (b2, c), (b3, c3)))
+    a, bhalf, a2 = cat[..., :c], cat[..., c:2 * c], cat[..., 2 * c:]
+    lead = (G, B) if paired else (B,)
+    y_u = torch.zeros((*lead, H, W, c3), dtype=dt, device=DEV)
+    y_f = torch.full((*lead, H, W, c3 + 8), 7.0, dtype=dt, device=DEV)
+    run(ops.bottleneck(a, w1p, p1[0][1], b1p, w2p, p2[0][1], b2p, a2, c, add, 1))
+    run(ops.conv2d(cat[..., c:], w3p, p3[0][1], b3p, y_u, 1, 1, 1, 1, 0, 0, 2 * c, c3, ops.ACT_SILU))
+    m_out = a2.clone()
+    a2.fill_(3.0)                                                      # the fused launch must not need (or write) slot a'
+    run(ops.bottleneck(a, w1p, p1[0][1], b1p, w2p, p2[0][1], b2p, None, c, add, 1,
+                       cv3=dict(w=w3p, kp=p3[0][1], bias=b3p, y=y_f[..., :c3], cout=c3, x2=bhalf)))
+    assert torch.equal(y_f[..., :c3], y_u)
+    assert bool((y_f[..., c3:] == 7.0).all()) and bool((a2 == 3.0).all())
+    for g in range(G):
+        x = q(xs[g], dt)
+        t = q(F.silu(F.conv2d(x[:, :c], q(w1[g], dt), b1[g])), dt)
+        mref = q(F.silu(F.conv2d(t, q(w2[g], dt), b2[g], 1, 1)) + (x[:, :c] if add else 0), dt)
+        ref = F.silu(F.conv2d(torch.cat((mref, x[:, c:2 * c]), 1), q(w3[g], dt), b3[g]))
+        close(from_act(y_f[g][..., :c3] if paired else y_f[..., :c3]), ref, dt, f"bneck+cv3 {case} stream {g}", factor=2.0)
+        close(from_act(m_out[g] if paired else m_out), mref, dt, f"bneck {case} stream {g}", factor=2.0)
+
+
 CHAIN_CASES = [
     # B, H, W, cin, c1 (3x3 layer out), c2 (chained 1x1 out), stride, tile, paired
     (2, 40, 48, 32, 64, 64, 2, 0, False),      # backbone row 1 -> C3 cv1|cv2 (yolov5s)

@@ -234,6 +234,26 @@ def test_stem2_plan_is_bit_identical_to_three_launch_plan(shape, u8):
     assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("shape", [(2, 320, 320), (3, 352, 416)])
+def test_bottleneck_cv3_plan_is_bit_identical(shape):
+    """C3 of row 2 with Bottleneck + cv3 as one launch (C3.fuse_cv3) vs Bottleneck launch + cv3 launch: identical output."""
+    from icafusion_amd.models.common import C3
+    B, H, W = shape
+    cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", 19, torch.bfloat16)
+    rgb, ir = synth_images(B, H, W, seed=19)
+    outs = []
+    try:
+        for on in (True, False):
+            C3.fuse_cv3 = on
+            m.invalidate()
+            names = [l.name for l in m.plan_for(B, H, W).launches]
+            assert ("bottleneck+cv3" in names) == on
+            outs.append(m(rgb.cuda(), ir.cuda())[0].clone())
+    finally:
+        C3.fuse_cv3 = True
+    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
+
+
 def test_graph_replay_equals_eager():
     cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", seed=1, dtype=torch.bfloat16)
     rgb, ir = synth_images(2, 320, 320, seed=1)

@@ -26,7 +26,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(handle, name)
     assert handle.icaf_version() >= 100
     assert ctypes.sizeof(_lib.ConvArgs) == 272      # static_assert'ed on the C side (igemm.hip)
-    assert ctypes.sizeof(_lib.BneckArgs) == 312
+    assert ctypes.sizeof(_lib.BneckArgs) == 336
 
 
 def test_yaml_generator_is_in_sync():
