@@ -32,6 +32,8 @@ def short(name):
     if m:
         dt, th, tw, bn, st = map(int, m.groups())
         return f"ctile_{_DN[dt]}_{th}x{tw}n{bn}" + ("s2" if st == 2 else "")
+    if re.match(r"icaf::bneck_kernel<[^>]*, true>", name):
+        return "bottleneck+cv3"
     m = re.match(r"icaf::(\w+)(<[^>]*>)?", name)
     if m:
         return {"preprocess_kernel": "preprocess_s2d", "pool_tokens_kernel": "dmff_pool_tokens", "upsample_merge_kernel": "dmff_upsample_merge",
