@@ -43,7 +43,9 @@ __device__ __forceinline__ int xcd_tile(int ntile_total) {
 // serve DMFF's fused tail carry it).
 // SECOND = true writes the tile as the output of the chained second layer (p.bias2 / y2 / ldy2 / Cout2, no residual):
 // selecting the fields here keeps ConvP in scalar registers — a modified copy of the struct would live in scratch memory.
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, bool PRE, bool SECOND = false, typename RowMap>
+// WB = true writes every final output vector (residual included) back into the staged LDS tile as well: igemm's chained
+// 1x1 then consumes, as its pixel operand, exactly what this layer stores.
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, bool PRE, bool SECOND = false, bool WB = false, typename RowMap>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsigned char* lds, const ConvP& p, int g, RowMap row_to_m, int n0) {
     using E = Elem<DT>;
     using EO = Elem<ODT>;
@@ -188,6 +190,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
             }
         }
         typename EO::type* yp = yg + (long long)m * ldy + n;
+        if constexpr (WB) *(u32x4*)(lds + row * SO + cv * 16) = pack16<ODT>(v);
         if (vec_y && nvalid == VO) {
             *(u32x4*)yp = pack16<ODT>(v);
         } else {

@@ -239,8 +239,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(c
         const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
         // (a) this layer's output tile -> LDS, rounded to the storage type (and, with keep1, written to y by the ordinary
         //     epilogue, whose staged tile is the same thing)
-        if (p.keep1) {
-            epilogue<DT, ODT, BM, BN, WM, WN, ICAF_ACT_SILU, false>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, 0);
+        if (p.keep1) {            // (a residual — the Bottleneck shortcut — is added by the epilogue and written back to the tile)
+            epilogue<DT, ODT, BM, BN, WM, WN, ICAF_ACT_SILU, false, false, true>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, 0);
         } else {
             f32x4 bvr[TN][4];                      // all bias quads in one batch of loads (see conv_common.h: epilogue)
 #pragma unroll
@@ -516,12 +516,13 @@ static int launch_dma(const ConvP& q, dim3 grid, hipStream_t s) {
                       ((BM / WM) * (BN / WN) == 4 ? BM == 128 : BN == 256)) {
             constexpr int lds_need = (NS * (BM + BN) * RB > TileLds<DT, ODT, BM, BN>::OUT_BYTES ? NS * (BM + BN) * RB : TileLds<DT, ODT, BM, BN>::OUT_BYTES) + 1024 + BN * BN * 2;
             if constexpr (lds_need <= 160 * 1024) {
-                if (whole_taps && q.Cout <= BN && q.Cout2 <= BN && !q.pre && !q.res && (!q.keep1 || (q.alpha_acc[0] == 1.0f && q.alpha_acc[1] == 1.0f)))
+                if (whole_taps && q.Cout <= BN && q.Cout2 <= BN && !q.pre && (!q.res || q.keep1) &&
+                    (!q.keep1 || (q.alpha_acc[0] == 1.0f && q.alpha_acc[1] == 1.0f)))
                     return launch_dma_mode<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, 2, false, true>(q, grid, s);
             }
         }
         return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: the chained 1x1 needs a 16-bit SiLU layer with Cout, Cout2 <= the N tile (64 / 128 / 256), "
-                                          "Cin*bytes %% %d == 0, no residual / pre term, on pipelines 0 / 2", RB);
+                                          "Cin*bytes %% %d == 0, no pre term, a residual only together with chain_keep, on pipelines 0 / 2", RB);
     }
     if (q.pre) {      // pre-activation bilinear term (DMFF fused tail): 1x1 + SiLU on the 128-row tiles only
         if constexpr (ACT == ICAF_ACT_SILU && ODT == DT && BM == 128 && (BM / WM) * (BN / WN) == 4 && NS * RB != 384) {

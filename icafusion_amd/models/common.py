@@ -153,8 +153,10 @@ class Conv(HipModule):
               output channels are appended to this layer's, one GEMM with N = sum of the widths (twin_also: the
               twin stream's counterparts).
         pre_term: fp32 coarse map (B, h, w, Cout) added, bilinearly resized, before bias + activation (icaf.h).
-        chain: (convs, twin_convs, y2) — 1x1 SiLU Convs (their outputs concatenated, e.g. the cv1 | cv2 of the C3 behind a
-              down-sampling Conv) applied to this layer's output tile inside the same launch; only y2 is written.
+        chain: (convs, twin_convs, y2[, keep]) — 1x1 SiLU Convs (their outputs concatenated, e.g. the cv1 | cv2 of the C3
+              behind a down-sampling Conv) applied to this layer's output tile inside the same launch; only y2 is written —
+              unless keep is set: then `out` (residual included) is written too and the 1x1 consumes it as stored (a
+              Bottleneck's 3x3 followed by the next Bottleneck's 1x1).
         swap_halves: the input view holds the two halves of the layer's input channels in swapped order (C3 after an
               odd number of fused Bottlenecks): the weight columns are swapped to match when they are packed."""
         if self.conv.groups != 1 or self.conv.dilation != (1, 1):
@@ -233,7 +235,8 @@ class Conv(HipModule):
             out = plan.act(B, Ho, Wo, c2, pair=paired)
         ch = None
         if chain is not None:
-            convs, twin_convs, y2 = chain
+            convs, twin_convs, y2 = chain[:3]
+            keep = len(chain) > 3 and bool(chain[3])
             n2 = sum(c.conv.out_channels for c in convs)
 
             def pack2():
@@ -246,11 +249,12 @@ class Conv(HipModule):
                     return packs[0]
                 return (torch.stack([p[0] for p in packs]).contiguous(), packs[0][1], torch.stack([p[2] for p in packs]).contiguous())
             w2p, kp2, b2p = self._cached(("chain",) + key_tail + tuple(id(c) for c in convs), pack2)
-            ch = dict(w=w2p, kp=kp2, bias=b2p, y=y2, cout=n2)
-            out = y2[..., :c2] if y2.shape[-1] >= c2 else plan.act(B, Ho, Wo, c2, pair=paired)   # (y is ignored by the kernel)
+            ch = dict(w=w2p, kp=kp2, bias=b2p, y=y2, cout=n2, keep=keep)
+            if not keep:
+                out = y2[..., :c2] if y2.shape[-1] >= c2 else plan.act(B, Ho, Wo, c2, pair=paired)   # (y is ignored by the kernel)
         plan.add(ops.conv2d(x, wp, kp, bp, out, kh, kw, sh, sw, ph, pw, c1, c2, self._act_code(), res=res,
                             name=f"conv{kh}x{kw}s{sh}" + ("+1x1" if ch else ""), pre=pre_term, chain=ch))
-        return y2 if ch else out
+        return (out if ch["keep"] else y2) if ch else out
 
     fuse_stem2 = True    # stem + the 3x3/s2 Conv behind it + that Conv's chained cv1 | cv2 as ONE persistent kernel
 
@@ -304,6 +308,15 @@ class Conv(HipModule):
                 and max(n1, n2) <= self.chain_max_width)
 
     chain_max_width = 128
+
+    def chain_ok_1x1(self, plan, nxt):
+        """Can the 1x1 SiLU Conv `nxt` (the next Bottleneck's cv1) ride on this 3x3 layer's output tile, this layer's output
+        (shortcut included) being written as well?  (icaf_conv2d: chain_keep)"""
+        k, kn = self.conv, nxt.conv
+        return (self.chain_fuse and plan.dtype in (torch.bfloat16, torch.float16) and isinstance(self.act, nn.SiLU)
+                and isinstance(nxt.act, nn.SiLU) and k.kernel_size == (3, 3) and k.groups == 1 and k.in_channels % 64 == 0
+                and kn.kernel_size == (1, 1) and kn.stride == (1, 1) and kn.groups == 1 and kn.in_channels == k.out_channels
+                and max(k.out_channels, kn.out_channels) <= self.chain_max_width)
 
 
 class Bottleneck(HipModule):
@@ -389,6 +402,7 @@ class C3(HipModule):
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
 
     fuse_cv3 = True      # n = 1, c_ = 32: Bottleneck + cv3 as one launch (icaf_bottleneck with a chained cv3)
+    chain_bottlenecks = True     # n > 1: a Bottleneck's 3x3 (+ shortcut) and the next Bottleneck's 1x1 as one launch
 
     def emit(self, plan, x, out=None, twin=None, lead=None):
         """lead = (Conv, twin Conv or None): the down-sampling Conv in front of this block whose output only this block
@@ -428,13 +442,21 @@ class C3(HipModule):
             return self.m[0].emit_fused(plan, cat[..., :c_], None, twin=twin.m[0] if paired else None,
                                         cv3=(self.cv3, twin.cv3 if paired else None, cat[..., c_:2 * c_], out))
         cur = 0
+        t_next = None                       # the next Bottleneck's 1x1 output, when the previous 3x3 launch produced it
         for j, blk in enumerate(self.m):
             a = cat[..., cur * c_:(cur + 1) * c_]
+            tw = twin.m[j] if paired else None
             if fused[j]:
                 cur = 2 - cur
-                blk.emit_fused(plan, a, cat[..., cur * c_:(cur + 1) * c_], twin=twin.m[j] if paired else None)
-            else:
-                blk.emit(plan, a, out=a, twin=twin.m[j] if paired else None)
+                blk.emit_fused(plan, a, cat[..., cur * c_:(cur + 1) * c_], twin=tw)
+                continue
+            nxt = self.m[j + 1] if j + 1 < len(self.m) and not fused[j + 1] else None
+            t = t_next if t_next is not None else blk.cv1.emit(plan, a, twin=tw.cv1 if paired else None)
+            t_next, ch = None, None
+            if nxt is not None and self.chain_bottlenecks and blk.cv2.chain_ok_1x1(plan, nxt.cv1):
+                t_next = plan.act(B, H, W, nxt.cv1.conv.out_channels, pair=paired)
+                ch = ((nxt.cv1,), (twin.m[j + 1].cv1,) if paired else None, t_next, True)
+            blk.cv2.emit(plan, t, out=a, res=a if blk.add else None, twin=tw.cv2 if paired else None, chain=ch)
         src = cat[..., :2 * c_] if cur == 0 else cat[..., c_:3 * c_]
         return self.cv3.emit(plan, src, out=out, twin=twin.cv3 if paired else None, swap_halves=cur != 0)
 

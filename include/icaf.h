@@ -131,7 +131,8 @@ typedef struct icaf_conv_args {
     void* y2;
     long long w2_gs, bias2_gs, y2_gs;
     int Kp2, Cout2, ldy2;
-    int chain_keep; /* != 0: y IS written as well (e.g. C3's cv1|cv2 output, whose first half also feeds the chained 1x1) */
+    int chain_keep; /* != 0: y IS written as well; only then may `res` be set: the chained 1x1 consumes y as stored, residual
+                     * included (a Bottleneck's 3x3 + shortcut followed by the next Bottleneck's 1x1, models/common.py:193-194) */
 } icaf_conv_args;
 
 int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s);

@@ -306,6 +306,37 @@ def test_conv_with_chained_1x1_equals_two_launches(case, dt):
         close(from_act(y_f[g] if paired else y_f), ref, dt, f"chain {case} stream {g}")
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 40, 48, 64, 0, True), (1, 33, 37, 64, 22, False), (2, 20, 24, 128, 0, True), (1, 21, 19, 128, 21, False)])
+def test_bottleneck_3x3_with_shortcut_chained_to_next_1x1(case, dt):
+    """A Bottleneck's 3x3 conv + shortcut (written IN PLACE over its own residual) with the next Bottleneck's 1x1 chained on the
+    tile (chain_keep + res): both outputs bit-identical to the two launches."""
+    B, H, W, c, tile, paired = case
+    G = 2 if paired else 1
+    ts = [rnd((B, c, H, W), 231 + g) for g in range(G)]                # the 1x1's output feeding the 3x3
+    rs = [rnd((B, c, H, W), 233 + g) for g in range(G)]                # block input = residual, overwritten by the output
+    w1 = [rnd((c, c, 3, 3), 235 + g, 1.0 / math.sqrt(9 * c)) for g in range(G)]
+    w2 = [rnd((c, c, 1, 1), 237 + g, 1.0 / math.sqrt(c)) for g in range(G)]
+    b1, b2 = [rnd((c,), 239 + g, 0.2) for g in range(G)], [rnd((c,), 241 + g, 0.2) for g in range(G)]
+    stk = (lambda xs: torch.stack(xs).contiguous()) if paired else (lambda xs: xs[0])
+    ta = stk([to_act(t, dt) for t in ts])
+    p1 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w1]
+    p2 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w2]
+    w1p, w2p = stk([p_[0] for p_ in p1]), stk([p_[0] for p_ in p2])
+    b1p, b2p = stk([ops.pack_bias(b.to(DEV), c) for b in b1]), stk([ops.pack_bias(b.to(DEV), c) for b in b2])
+    a_u, a_f = stk([to_act(r, dt) for r in rs]), stk([to_act(r, dt) for r in rs])
+    n_u, n_f = torch.zeros_like(a_u), torch.zeros_like(a_u)
+    run(ops.conv2d(ta, w1p, p1[0][1], b1p, a_u, 3, 3, 1, 1, 1, 1, c, c, ops.ACT_SILU, res=a_u))
+    run(ops.conv2d(a_u, w2p, p2[0][1], b2p, n_u, 1, 1, 1, 1, 0, 0, c, c, ops.ACT_SILU))
+    run(ops.conv2d(ta, w1p, p1[0][1], b1p, a_f, 3, 3, 1, 1, 1, 1, c, c, ops.ACT_SILU, res=a_f, tile=tile,
+                   chain=dict(w=w2p, kp=p2[0][1], bias=b2p, y=n_f, cout=c, keep=True)))
+    assert torch.equal(a_f, a_u) and torch.equal(n_f, n_u)
+    for g in range(G):
+        m = q(F.silu(F.conv2d(q(ts[g], dt), q(w1[g], dt), b1[g], 1, 1)), dt) + q(rs[g], dt)
+        close(from_act(a_f[g] if paired else a_f), m, dt, f"3x3+res {case}", factor=2.0)
+        close(from_act(n_f[g] if paired else n_f), F.silu(F.conv2d(q(m, dt), q(w2[g], dt), b2[g])), dt, f"next 1x1 {case}", factor=2.0)
+
+
 def test_conv3x3_halo_tile_rejects_other_layers():
     x = torch.zeros((1, 8, 8, 32), dtype=torch.bfloat16, device=DEV)
     w = rnd((32, 32, 1, 1), 1)

@@ -254,6 +254,26 @@ def test_bottleneck_cv3_plan_is_bit_identical(shape):
     assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("name", ["yolov5s_Transfusion_kaist.yaml", "yolov5l_Transfusion_kaist.yaml"])
+def test_chained_bottlenecks_plan_is_bit_identical(name):
+    """C3 blocks with n > 1: each Bottleneck's 3x3 (+ shortcut) launch also computes the next Bottleneck's 1x1
+    (C3.chain_bottlenecks) vs separate launches: identical output."""
+    from icafusion_amd.models.common import C3
+    cfg, sd, m = build(name, 23, torch.bfloat16)
+    rgb, ir = synth_images(2, 320, 352, seed=23)
+    outs, counts = [], []
+    try:
+        for on in (True, False):
+            C3.chain_bottlenecks = on
+            m.invalidate()
+            counts.append(len(m.plan_for(2, 320, 352).launches))
+            outs.append(m(rgb.cuda(), ir.cuda())[0].clone())
+    finally:
+        C3.chain_bottlenecks = True
+    assert counts[0] < counts[1]
+    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
+
+
 def test_graph_replay_equals_eager():
     cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", seed=1, dtype=torch.bfloat16)
     rgb, ir = synth_images(2, 320, 320, seed=1)
