@@ -25,7 +25,7 @@ class ConvArgs(C.Structure):
         ("ldr", C.c_int), ("Kp", C.c_int), ("act", C.c_int), ("dtype", C.c_int), ("out_dtype", C.c_int),
         ("alpha_acc", C.c_float * 2), ("alpha_res", C.c_float * 2),
         ("tile", C.c_int),
-        ("pre", C.c_void_p), ("pre_h", C.c_int), ("pre_w", C.c_int), ("ldpre", C.c_int),
+        ("pre", C.c_void_p), ("pre_h", C.c_int), ("pre_w", C.c_int), ("ldpre", C.c_int), ("pre_mode", C.c_int),
         ("w2", C.c_void_p), ("bias2", C.c_void_p), ("y2", C.c_void_p),
         ("w2_gs", C.c_longlong), ("bias2_gs", C.c_longlong), ("y2_gs", C.c_longlong),
         ("Kp2", C.c_int), ("Cout2", C.c_int), ("ldy2", C.c_int), ("chain_keep", C.c_int),

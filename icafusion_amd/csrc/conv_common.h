@@ -13,7 +13,7 @@ struct ConvP {
     int vec_y, vec_r;
     unsigned int x_bytes, w_bytes;      // buffer-descriptor ranges (DMA pipeline); 0 = not representable
     float alpha_acc[2], alpha_res[2];
-    const float* pre; int pre_h, pre_w, ldpre;     // optional pre-activation bilinear term (icaf.h)
+    const float* pre; int pre_h, pre_w, ldpre, pre_mode;   // optional pre-activation term, bilinear / nearest (icaf.h)
     const void* w1; const float* bias1;            // fused Bottleneck (ctile.hip, FUSE1): the 1x1 convolution in front
     long long w1_gs, bias1_gs; int Kp1; unsigned int w1_bytes;
     const void* w2; const float* bias2; void* y2;  // chained 1x1 convolution behind this layer (igemm.hip, CHAIN)
@@ -64,6 +64,12 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
     const float* pt[PRE ? TM : 1][4];
     float plx[PRE ? TM : 1], ply[PRE ? TM : 1];
     if constexpr (PRE) {
+        // No fp contraction in the bilinear arithmetic (here and where the term is evaluated below): left to the compiler,
+        // different instantiations (tiles) fused these products differently, so the same layer rounded differently from one
+        // tile shape to the next and a batch shard stopped being bit-identical to the same rows of the full batch.  (Writing
+        // the fmas out with __builtin_fmaf instead produced a 128x64 / 64-byte-pipeline kernel with wrong, run-to-run
+        // varying results at large grids — tools/probes/pre_check.py.)
+#pragma clang fp contract(off)
         const float sy = (float)p.pre_h / (float)p.Ho, sx = (float)p.pre_w / (float)p.Wo;
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
@@ -76,9 +82,14 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
             int y0 = (int)fy, x0 = (int)fx;
             y0 = y0 < p.pre_h - 1 ? y0 : p.pre_h - 1;
             x0 = x0 < p.pre_w - 1 ? x0 : p.pre_w - 1;
-            const int y1 = y0 < p.pre_h - 1 ? y0 + 1 : y0, x1 = x0 < p.pre_w - 1 ? x0 + 1 : x0;
+            int y1 = y0 < p.pre_h - 1 ? y0 + 1 : y0, x1 = x0 < p.pre_w - 1 ? x0 + 1 : x0;
             ply[b] = fy - (float)y0;
             plx[b] = fx - (float)x0;
+            if (p.pre_mode == 1) {                 // nearest: one tap with weight 1 — the fma sequence below returns it exactly
+                y0 = y1 = (int)((long long)ho * p.pre_h / p.Ho);
+                x0 = x1 = (int)((long long)wo * p.pre_w / p.Wo);
+                ply[b] = plx[b] = 0.0f;
+            }
             const float* base = p.pre + (long long)bi * p.pre_h * p.pre_w * p.ldpre;
             pt[b][0] = base + (long long)(y0 * p.pre_w + x0) * p.ldpre;
             pt[b][1] = base + (long long)(y0 * p.pre_w + x1) * p.ldpre;
@@ -111,14 +122,15 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
                 if constexpr (PRE) if (n0 + nl < Cout) {
                     const f32x4 t00 = *(const f32x4*)(pt[b][0] + n0 + nl), t01 = *(const f32x4*)(pt[b][1] + n0 + nl);
                     const f32x4 t10 = *(const f32x4*)(pt[b][2] + n0 + nl), t11 = *(const f32x4*)(pt[b][3] + n0 + nl);
-                    // explicit fma sequence: left to the compiler's contraction, different instantiations (tiles) fused
-                    // these products differently and the same layer rounded differently from one tile shape to the next
-                    const float wx0 = 1.0f - plx[b], wy0 = 1.0f - ply[b];
+                    {
+#pragma clang fp contract(off)
+                        const float wx0 = 1.0f - plx[b], wy0 = 1.0f - ply[b];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float top = __builtin_fmaf(t01[j], plx[b], t00[j] * wx0);
-                        const float bot = __builtin_fmaf(t11[j], plx[b], t10[j] * wx0);
-                        pv[j] = __builtin_fmaf(bot, ply[b], top * wy0);
+                        for (int j = 0; j < 4; ++j) {
+                            const float top = t00[j] * wx0 + t01[j] * plx[b];
+                            const float bot = t10[j] * wx0 + t11[j] * plx[b];
+                            pv[j] = top * wy0 + bot * ply[b];
+                        }
                     }
                 }
                 float v[4];
@@ -180,13 +192,13 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
                     float r[VO];
                     unpack16<DT>(rvec[it], r);
 #pragma unroll
-                    for (int j = 0; j < VO; ++j) v[j] += alpha_res * r[j];
+                    for (int j = 0; j < VO; ++j) v[j] = __builtin_fmaf(alpha_res, r[j], v[j]);
                 }
             } else if (p.vec_r && nvalid == VO) {   // fp32 output of a 16-bit residual
 #pragma unroll
-                for (int j = 0; j < VO; ++j) v[j] += alpha_res * E::ld(rp + j);
+                for (int j = 0; j < VO; ++j) v[j] = __builtin_fmaf(alpha_res, E::ld(rp + j), v[j]);
             } else {
-                for (int j = 0; j < nvalid; ++j) v[j] += alpha_res * E::ld(rp + j);
+                for (int j = 0; j < nvalid; ++j) v[j] = __builtin_fmaf(alpha_res, E::ld(rp + j), v[j]);
             }
         }
         typename EO::type* yp = yg + (long long)m * ldy + n;

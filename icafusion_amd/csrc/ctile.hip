@@ -306,7 +306,7 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
                     unpack16<DT>(*(const u32x4*)(trow + (VPR + cv) * 16), v);
                     unpack16<DT>(rv[it], r);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) v[j] += alpha_res * r[j];
+                    for (int j = 0; j < VEC; ++j) v[j] = __builtin_fmaf(alpha_res, r[j], v[j]);      // (as the shared epilogue)
                     *(u32x4*)(trow + (VPR + cv) * 16) = pack16<DT>(v);
                 }
             }

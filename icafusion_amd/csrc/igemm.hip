@@ -628,6 +628,7 @@ static int validate(const icaf_conv_args* a) {
     if ((long long)a->B * a->Ho * a->Wo > 0x7fffffffLL) return fail(ICAF_ERR_ARG, "icaf_conv2d: too many output pixels");
     if (a->w2 && (!a->y2 || a->Cout2 < 1 || a->ldy2 < a->Cout2 || a->Kp2 < a->Cout || (a->Kp2 * (a->dtype == ICAF_F32 ? 4 : 2)) % 128 || ((uintptr_t)a->w2 & 15)))
         return fail(ICAF_ERR_ARG, "icaf_conv2d: chained 1x1 needs y2, ldy2 >= Cout2 >= 1, Kp2 >= Cout in whole 128-byte slices, aligned w2");
+    if (a->pre && (a->pre_mode < 0 || a->pre_mode > 1)) return fail(ICAF_ERR_ARG, "icaf_conv2d: pre_mode must be 0 (bilinear) or 1 (nearest)");
     if (a->pre && (a->pre_h < 1 || a->pre_w < 1 || a->ldpre < a->Cout || (a->ldpre & 3) || ((uintptr_t)a->pre & 15) || a->groups != 1))
         return fail(ICAF_ERR_ARG, "icaf_conv2d: pre needs pre_h, pre_w >= 1, ldpre >= Cout and a multiple of 4, 16-byte alignment, groups == 1");
     return ICAF_OK;
@@ -657,7 +658,7 @@ static void fill(const icaf_conv_args* a, ConvP& p) {
     if (xb < 0x7fffff00LL && wb < 0x7fffff00LL) { p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb; }
     else { p.x_bytes = 0; p.w_bytes = 0; }
     for (int i = 0; i < 2; ++i) { p.alpha_acc[i] = a->alpha_acc[i]; p.alpha_res[i] = a->alpha_res[i]; }
-    p.pre = a->pre; p.pre_h = a->pre_h; p.pre_w = a->pre_w; p.ldpre = a->ldpre;
+    p.pre = a->pre; p.pre_h = a->pre_h; p.pre_w = a->pre_w; p.ldpre = a->ldpre; p.pre_mode = a->pre_mode;
     p.w1 = nullptr; p.bias1 = nullptr; p.w1_gs = p.bias1_gs = 0; p.Kp1 = 0; p.w1_bytes = 0;
     p.w2 = a->w2; p.bias2 = a->bias2; p.y2 = a->y2; p.w2_gs = a->w2_gs; p.bias2_gs = a->bias2_gs; p.y2_gs = a->y2_gs;
     p.Kp2 = a->Kp2; p.Cout2 = a->Cout2; p.ldy2 = a->ldy2; p.keep1 = a->chain_keep;

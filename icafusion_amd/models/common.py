@@ -144,7 +144,7 @@ class Conv(HipModule):
         return w, b
 
     def emit(self, plan, x, out=None, res=None, twin=None, also=(), twin_also=(), pre_term=None, swap_halves=False,
-             chain=None):
+             chain=None, pre_nearest=False, cin_slice=None):
         """Append this layer's launch.
 
         twin: the structurally identical Conv of the other backbone stream — x / out / res are then pair acts
@@ -152,7 +152,10 @@ class Conv(HipModule):
         also: further Convs with the same geometry and activation reading the same input (C3's cv1 and cv2): their
               output channels are appended to this layer's, one GEMM with N = sum of the widths (twin_also: the
               twin stream's counterparts).
-        pre_term: fp32 coarse map (B, h, w, Cout) added, bilinearly resized, before bias + activation (icaf.h).
+        pre_term: fp32 coarse map (B, h, w, Cout) added, bilinearly resized (pre_nearest: nearest), before bias + activation
+              (icaf.h).
+        cin_slice: (k0, k1) — use only these input-channel columns of the weights (x then has k1 - k0 channels): the
+              full-resolution half of a 1x1 conv over cat(up(a), b), whose other half arrives as the nearest pre_term.
         chain: (convs, twin_convs, y2[, keep]) — 1x1 SiLU Convs (their outputs concatenated, e.g. the cv1 | cv2 of the C3
               behind a down-sampling Conv) applied to this layer's output tile inside the same launch; only y2 is written —
               unless keep is set: then `out` (residual included) is written too and the 1x1 consumes it as stored (a
@@ -166,6 +169,8 @@ class Conv(HipModule):
         ph, pw = _pair(self.conv.padding)
         c1 = self.conv.in_channels
         c2 = self.conv.out_channels + sum(e.conv.out_channels for e in also)
+        if cin_slice is not None:
+            assert (kh, kw) == (1, 1) and not swap_halves and 0 <= cin_slice[0] < cin_slice[1] <= c1
         for e in also:
             assert (e.conv.kernel_size, e.conv.stride, _pair(e.conv.padding), e.conv.in_channels, e._act_code()) == \
                    ((kh, kw), (sh, sw), (ph, pw), c1, self._act_code()), "fused convs must share geometry"
@@ -180,6 +185,8 @@ class Conv(HipModule):
                 rows.append((twin,) + tuple(twin_also))
             return rows
         key_tail = (plan.dtype, plan.device, id(twin), tuple(id(e) for e in also), bool(swap_halves))
+        if cin_slice is not None:
+            key_tail += (tuple(cin_slice),)
 
         def pack(transform, cin_pad):
             packs = []
@@ -189,6 +196,8 @@ class Conv(HipModule):
                 if swap_halves:
                     h = w.shape[1] // 2
                     w = torch.cat((w[:, h:], w[:, :h]), 1)
+                if cin_slice is not None:
+                    w = w[:, cin_slice[0]:cin_slice[1]]
                 wp, kp = ops.pack_conv_weight(transform(w), plan.dtype, cin_pad)
                 packs.append((wp, kp, ops.pack_bias(b, c2)))
             if not paired:
@@ -224,6 +233,8 @@ class Conv(HipModule):
                 x, c1 = pre, cpad
         else:
             assert (x.dim() == 5) == paired
+            if cin_slice is not None:
+                c1 = cin_slice[1] - cin_slice[0]
             if x.shape[-1] != c1:
                 raise ValueError(f"Conv expects {c1} input channels, got {x.shape[-1]}")
             if c1 % vec:
@@ -253,7 +264,7 @@ class Conv(HipModule):
             if not keep:
                 out = y2[..., :c2] if y2.shape[-1] >= c2 else plan.act(B, Ho, Wo, c2, pair=paired)   # (y is ignored by the kernel)
         plan.add(ops.conv2d(x, wp, kp, bp, out, kh, kw, sh, sw, ph, pw, c1, c2, self._act_code(), res=res,
-                            name=f"conv{kh}x{kw}s{sh}" + ("+1x1" if ch else ""), pre=pre_term, chain=ch))
+                            name=f"conv{kh}x{kw}s{sh}" + ("+1x1" if ch else ""), pre=pre_term, chain=ch, pre_nearest=pre_nearest))
         return (out if ch["keep"] else y2) if ch else out
 
     fuse_stem2 = True    # stem + the 3x3/s2 Conv behind it + that Conv's chained cv1 | cv2 as ONE persistent kernel
@@ -408,6 +419,10 @@ class C3(HipModule):
         """lead = (Conv, twin Conv or None): the down-sampling Conv in front of this block whose output only this block
         reads; `x` is then THAT conv's input and cv1 | cv2 run chained on its output tile (the tensor between the two
         yaml rows is never written)."""
+        vcat = x if isinstance(x, VirtualCat) else None
+        if vcat is not None:
+            assert lead is None and twin is None
+            x = vcat.other
         if lead is not None and len(lead) == 4:        # (Conv, twin, stem, stem twin): x is the image pair itself
             B, _, H, W = x.shape
             H, W = (H // 2 - 1) // 2 + 1, (W // 2 - 1) // 2 + 1
@@ -433,6 +448,20 @@ class C3(HipModule):
         elif lead is not None:
             lead[0].emit(plan, x, twin=lead[1], chain=((self.cv1, self.cv2), (twin.cv1, twin.cv2) if paired else None,
                                                        cat[..., :2 * c_]))
+        elif vcat is not None:
+            # cv(cat(up(a), b)) = SiLU(up(Wa . a) + Wb . b + bias): the 1x1 commutes with the nearest up-sampling, so the
+            # a-half of cv1 | cv2 runs at LOW resolution (fp32 out, a quarter of the pixels) and enters the GEMM over b as its
+            # nearest-resized pre-activation term; nn.Upsample's output and the Concat buffer are never written or read.
+            ca, cb = vcat.low.shape[-1], vcat.other.shape[-1]
+
+            def make_a():
+                w = torch.cat([self.cv1.folded()[0], self.cv2.folded()[0]])[:, :ca]
+                return ops.pack_conv_weight(w, plan.dtype)
+            wa, kpa = self._cached(("upterm", plan.dtype, plan.device, ca), make_a)
+            Bl, hl, wl, _ = vcat.low.shape
+            P = plan.empty((Bl, hl, wl, 2 * c_), torch.float32)
+            plan.add(ops.conv2d(vcat.low, wa, kpa, None, P, 1, 1, 1, 1, 0, 0, ca, 2 * c_, ops.ACT_NONE, name="c3_up_term"))
+            self.cv1.emit(plan, x, out=cat[..., :2 * c_], also=(self.cv2,), pre_term=P, pre_nearest=True, cin_slice=(ca, ca + cb))
         else:
             self.cv1.emit(plan, x, out=cat[..., :2 * c_], twin=twin.cv1 if paired else None, also=(self.cv2,),
                           twin_also=(twin.cv2,) if paired else ())
@@ -481,6 +510,16 @@ class SPPF(HipModule):
         self.cv1.emit(plan, x, out=cat[..., :c_], twin=twin.cv1 if paired else None)
         plan.add(ops.sppf_pool(cat[..., :c_], cat[..., c_:2 * c_], cat[..., 2 * c_:3 * c_], cat[..., 3 * c_:], k))
         return self.cv2.emit(plan, cat, out=out, twin=twin.cv2 if paired else None)
+
+
+class VirtualCat:
+    """cat(nearest_up(low, scale), other) that is never materialised: a C3 consumes it (C3.emit)."""
+
+    def __init__(self, low, scale, other):
+        self.low, self.scale, self.other = low, scale, other
+        B, h, w, _ = low.shape
+        assert other.shape[:3] == (B, h * scale, w * scale)
+        self.shape = (B, h * scale, w * scale, low.shape[3] + other.shape[3])
 
 
 class Concat(HipModule):

@@ -20,7 +20,7 @@ import torch.nn as nn
 from .. import ops
 from ..engine import ImageIn, Plan
 from .common import (C3, SPPF, Add, Bottleneck, Concat, Conv, Detect, HipModule, NiNfusion,  # noqa: F401
-                     TransformerFusionBlock, emit_upsample)
+                     TransformerFusionBlock, VirtualCat, emit_upsample)
 
 logger = logging.getLogger(__name__)
 _NAMESPACE = {"Conv": Conv, "C3": C3, "SPPF": SPPF, "Bottleneck": Bottleneck, "Concat": Concat, "Detect": Detect,
@@ -190,6 +190,7 @@ class Model(HipModule):
         self.use_graph = False       # replay each plan as one hipGraph launch
         self.pair_streams = True     # run structurally identical RGB / IR backbone rows as one groups=2 launch
         self.branch_dmff = True      # capture the shallow DMFF blocks as parallel branches of the hipGraph
+        self.fold_upsample = True    # Upsample -> Concat -> C3: run the up-sampled half of the C3's 1x1 at low resolution
         self.static_outputs = False  # return views of plan-owned buffers instead of clones
 
     # -- reference API ----------------------------------------------------------------------------------------
@@ -283,10 +284,27 @@ class Model(HipModule):
             plan.inputs = [imgs[0], imgs[1]]
             in_pair, in_rgb, in_ir = ImageIn(imgs), ImageIn(imgs[0]), ImageIn(imgs[1])
         shapes = self._layer_shapes(B, H, W)
+        # nn.Upsample -> Concat([-1, j]) -> C3 (head rows 24-26, 28-30): the C3's first 1x1 commutes with the nearest
+        # up-sampling, so neither the up-sampled tensor nor the concat buffer is materialised (C3.emit, VirtualCat)
+        virtual = {}                                # Concat row -> Upsample row
+        if self.fold_upsample:
+            used = {}
+            for m in self.model:
+                for j in ([m.f] if isinstance(m.f, int) else m.f):
+                    used.setdefault(m.i - 1 if j == -1 else j, []).append(m.i)
+            for m in self.model:
+                nxt = self.model[m.i + 1] if m.i + 1 < len(self.model) else None
+                nx2 = self.model[m.i + 2] if m.i + 2 < len(self.model) else None
+                if (isinstance(m, nn.Upsample) and m.f == -1 and m.i > 0 and m.mode == "nearest" and m.scale_factor is not None
+                        and float(m.scale_factor) == int(m.scale_factor) and isinstance(nxt, Concat) and nxt.d == 1
+                        and not isinstance(nxt.f, int) and len(nxt.f) == 2 and nxt.f[0] == -1 and isinstance(nxt.f[1], int)
+                        and nxt.f[1] >= 0 and isinstance(nx2, C3) and nx2.f == -1 and used.get(m.i) == [nxt.i]
+                        and used.get(nxt.i) == [nx2.i]):
+                    virtual[nxt.i] = m.i
         # Concat placement: producer layer index -> (concat buffer, channel offset)
         placement, cat_bufs = {}, {}
         for m in self.model:
-            if isinstance(m, Concat) and not isinstance(m.f, int):
+            if isinstance(m, Concat) and not isinstance(m.f, int) and m.i not in virtual:
                 srcs = [m.i - 1 if j == -1 else j for j in m.f]
                 if any(s in placement for s in srcs):
                     continue                       # a producer can live in only one concat buffer
@@ -378,6 +396,17 @@ class Model(HipModule):
                 src = y[f]
             else:
                 src = [x if j == -1 else y[j] for j in f]
+            if m.i + 1 in virtual and virtual[m.i + 1] == m.i:          # the Upsample row: nothing to launch
+                x = (src, int(m.scale_factor))
+                y.append(x)
+                last_launch[m.i] = len(plan.launches) - 1
+                continue
+            if m.i in virtual:                                          # its Concat: a description of cat(up(low), other)
+                (low, scale), other = src
+                x = VirtualCat(low, scale, other)
+                y.append(x)
+                last_launch[m.i] = len(plan.launches) - 1
+                continue
             out = None
             if m.i in placement:
                 buf, off, c = placement[m.i]

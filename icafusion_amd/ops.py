@@ -111,7 +111,7 @@ def s2d_conv_weight(w4d):
 # launches
 # ------------------------------------------------------------------------------------------------------------
 def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res=None, alpha_acc=1.0,
-           alpha_res=1.0, groups=1, group_strides=None, tile=0, name="conv2d", pre=None, chain=None):
+           alpha_res=1.0, groups=1, group_strides=None, tile=0, name="conv2d", pre=None, chain=None, pre_nearest=False):
     """Record an implicit-GEMM conv / linear.  x, y, res are acts; for groups=2 they are the group-0 views and
     group_strides = dict(x=, w=, bias=, y=, res=) gives element strides to group 1."""
     B, H, W, cx, ldx = _act_geom(x)
@@ -147,6 +147,7 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
         Bp, hp, wp_, cp, ldp = _act_geom(pre)
         assert pre.dtype == torch.float32 and Bp == B and cp >= cout and groups == 1
         a.pre, a.pre_h, a.pre_w, a.ldpre = pre.data_ptr(), hp, wp_, ldp
+        a.pre_mode = int(bool(pre_nearest))     # nearest: the map is the low-resolution half of a 1x1 conv over cat(up(a), b)
     if chain is not None:             # chained 1x1 + SiLU on the output tile (icaf.h): dict(w=, kp=, bias=, y=, cout=)
         y2 = chain["y"]
         B2, H2, W2, c2y, ldy2 = _act_geom(y2)
@@ -208,7 +209,7 @@ CONV_PIPELINES = (0, 1, 2)        # LDS-DMA 64 B x3, register-staged, LDS-DMA 12
 
 def _conv_signature(a):
     return (a.B * a.Ho * a.Wo, a.Cout, a.Cin, a.kh, a.kw, a.sh, a.sw, a.H, a.W, a.ldx, a.ldy, a.groups, a.dtype,
-            a.out_dtype, a.act, bool(a.res), bool(a.pre), a.Cout2 if a.w2 else 0, bool(a.chain_keep))
+            a.out_dtype, a.act, bool(a.res), bool(a.pre) + a.pre_mode, a.Cout2 if a.w2 else 0, bool(a.chain_keep))
 
 
 def conv_candidates(a):

@@ -121,6 +121,9 @@ typedef struct icaf_conv_args {
      * convolution commutes with the (linear) resize, so conv(cat(f + up(t))) = conv(cat(f)) + up(conv(cat(t))). */
     const float* pre;
     int pre_h, pre_w, ldpre;
+    int pre_mode; /* 0: bilinear (align_corners=False); 1: nearest, src = floor(dst * pre_h / Ho) — nn.Upsample('nearest') in
+                   * front of a Concat feeding a 1x1 conv (head rows 24-26 / 28-30): W.cat(up(a), b) = up(Wa.a) + Wb.b, so
+                   * the low-resolution product Wa.a is the `pre` map of the GEMM over b and neither up(a) nor the concat exist */
     /* Optional chained 1x1 convolution + SiLU consuming this layer's output tile in place (w2 != NULL):
      *   y2 = SiLU( W2 . SiLU(A.W + bias) + bias2 )        [this layer must be SiLU, 16-bit, one N tile: Cout <= 256]
      * The intermediate tensor is never written (y is ignored) unless chain_keep is set.  It is how a backbone down-sampling Conv and the fused

@@ -97,3 +97,57 @@ def test_config5_l_vedai_f16_1280_b16_multilabel():
     zs = m(rgb[4:6].contiguous(), ir[4:6].contiguous())[0]
     assert torch.equal(z[4:6], zs)
     check_nms_properties(z, 0.3, 0.5, multi_label=True)
+
+
+def test_every_launch_configuration_is_bit_identical_at_full_grid():
+    """Whatever (tile, pipeline) the tuner picks for a layer, the layer must produce the same bits — otherwise a batch shard
+    differs from the same rows of the full batch as soon as the two batch sizes are tuned differently.  Checked per conv
+    launch of the yolov5s plan at batch 16 / 640x640 (large grids: a kernel that was only wrong there, and from run to run,
+    passed every small-size test), and every pre-activation-term launch also against a torch evaluation of the same layer."""
+    import torch.nn.functional as F
+    from icafusion_amd import ops
+    cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", torch.bfloat16, seed=3)
+    m.autotune = False
+    B = 16
+    plan = m.plan_for(B, 640, 640, DEV)
+    rgb, ir = synth_images(B, 640, 640, seed=3)
+    plan.inputs[0].copy_(rgb.to(DEV)); plan.inputs[1].copy_(ir.to(DEV))
+    sp = ops.current_stream_ptr()
+    checked = 0
+    for i, l in enumerate(plan.launches):
+        is_conv = l.fn is ops.lib().icaf_conv2d
+        snap = l.keep[4].clone() if is_conv and l.keep[0].res and l.keep[0].res == l.keep[0].y else None   # in place over its residual
+        l(sp); torch.cuda.synchronize()
+        if not is_conv:
+            continue
+        a, x, wp, bias, y, res, pre, chain = l.keep
+        outs = [y] + ([chain["y"]] if chain else [])
+        ref_out = None
+        if pre is not None:                          # torch evaluation of y = SiLU(x . W^T + bias + resize(pre))
+            N, K = a.Cout, a.Cin
+            t = x.float().reshape(-1, x.shape[-1])[:, :K] @ wp[:N, :K].float().t() + bias[:N]
+            kw = dict(mode="nearest") if a.pre_mode == 1 else dict(mode="bilinear", align_corners=False)
+            up = F.interpolate(pre.permute(0, 3, 1, 2), size=(a.Ho, a.Wo), **kw).permute(0, 2, 3, 1).reshape(-1, pre.shape[-1])[:, :N]
+            ref_out = F.silu(t + up).reshape(y.shape)
+        first = None
+        for c in ops.conv_candidates(a):
+            a.tile = c
+            if snap is not None:
+                y.copy_(snap)
+            if l.fn(*l.args, sp) != 0:
+                continue
+            torch.cuda.synchronize()
+            got = [o.clone() for o in outs]
+            if ref_out is not None:
+                err = (got[0].float() - ref_out).abs().max().item() / ref_out.abs().max().item()
+                assert err < 2e-2, f"launch {i} ({l.name}) configuration {c}: rel err {err:.3e} vs torch"
+            if first is None:
+                first, c0 = got, c
+            else:
+                assert all(torch.equal(g, r) for g, r in zip(got, first)), f"launch {i} ({l.name}): configuration {c} != {c0}"
+            checked += 1
+        a.tile = 0
+        if snap is not None:
+            y.copy_(snap)
+        l(sp); torch.cuda.synchronize()
+    assert checked > 150

@@ -347,6 +347,28 @@ def test_conv3x3_halo_tile_rejects_other_layers():
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", [(2, 11, 15, 2, 200, 0), (1, 7, 9, 3, 64, 2), (2, 10, 10, 2, 40, 22)])
+def test_conv2d_nearest_pre_term_is_conv_over_upsampled_concat(case, dt):
+    """SiLU(W . cat(up(a), b) + bias) computed as SiLU(up(Wa . a) + Wb . b + bias): the a-half at LOW resolution (fp32 out)
+    enters the GEMM over b as its nearest-resized pre-activation term (pre_mode 1) — the head's Upsample -> Concat -> C3."""
+    B, h, w, s, cout, tile = case
+    ca, cb, H, W = 64, 128, h * s, w * s
+    a_, b_ = rnd((B, ca, h, w), 41), rnd((B, cb, H, W), 42)
+    wt = rnd((cout, ca + cb, 1, 1), 43, 1.0 / math.sqrt(ca + cb))
+    bias = rnd((cout,), 44, 0.2)
+    aa, ba = to_act(a_, dt), to_act(b_, dt, pad_to=cb + 32)
+    wa, kpa = ops.pack_conv_weight(wt[:, :ca].to(DEV), dt)
+    wb, kpb = ops.pack_conv_weight(wt[:, ca:].to(DEV), dt)
+    bp = ops.pack_bias(bias.to(DEV), cout)
+    P = torch.zeros((B, h, w, cout), dtype=torch.float32, device=DEV)
+    y = torch.zeros((B, H, W, cout), dtype=dt, device=DEV)
+    run(ops.conv2d(aa, wa, kpa, None, P, 1, 1, 1, 1, 0, 0, ca, cout, ops.ACT_NONE))
+    run(ops.conv2d(ba, wb, kpb, bp, y, 1, 1, 1, 1, 0, 0, cb, cout, ops.ACT_SILU, pre=P, pre_nearest=True, tile=tile))
+    cat = torch.cat((F.interpolate(q(a_, dt), scale_factor=s, mode="nearest"), q(b_, dt)), 1)
+    close(from_act(y), F.silu(F.conv2d(cat, q(wt, dt), bias)), dt, f"nearest pre term {case}")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("tile", [0, 2, 22])
 def test_conv2d_pre_activation_bilinear_term(dt, tile):
     """y = act(conv(x) + bias + F.interpolate(pre, bilinear, align_corners=False)): the epilogue term behind DMFF's

@@ -274,6 +274,26 @@ def test_chained_bottlenecks_plan_is_bit_identical(name):
     assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_folded_upsample_matches_materialised_concat(dtype):
+    """Head rows Upsample -> Concat -> C3 with the up-sampled half of the C3's 1x1 computed at low resolution
+    (Model.fold_upsample) vs the materialised concat: fp32 agrees to summation-order noise, bf16 to rounding noise."""
+    cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", 29, dtype)
+    rgb, ir = synth_images(2, 320, 384, seed=29)
+    outs = []
+    for on in (True, False):
+        m.fold_upsample = on
+        m.invalidate()
+        names = [l.name for l in m.plan_for(2, 320, 384).launches]
+        assert ("c3_up_term" in names) == on and ("upsample_nearest" in names) != on
+        outs.append(m(rgb.cuda(), ir.cuda())[0].float())
+    m.fold_upsample = True
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    scale = outs[1][..., :4].abs().max().item()
+    assert (outs[0][..., :4] - outs[1][..., :4]).abs().max().item() <= tol * scale
+    assert (outs[0][..., 4:] - outs[1][..., 4:]).abs().max().item() <= tol
+
+
 def test_graph_replay_equals_eager():
     cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", seed=1, dtype=torch.bfloat16)
     rgb, ir = synth_images(2, 320, 320, seed=1)

@@ -1,0 +1,70 @@
+"""Check every configuration of the pre-term conv launches of a plan against a torch evaluation of the same launch."""
+import os, sys
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, R)
+import torch, yaml
+import torch.nn.functional as F
+from icafusion_amd import ops, _lib
+if os.environ.get("ICAF_OLD"):              # a library built from an older revision (tools/build_variant.py): no stem2 etc.
+    _lib.SIGNATURES.pop("icaf_stem2")
+from icafusion_amd.models.yolo import Model
+from icafusion_amd.models import common as _c
+if os.environ.get("ICAF_OLD"):
+    _c.Conv.fuse_stem2 = False; _c.C3.fuse_cv3 = False; _c.C3.chain_bottlenecks = False
+from icafusion_amd.synth import synth_images, synth_state_dict
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+cfg = yaml.safe_load(open(f"{R}/models/transformer/yolov5s_Transfusion_kaist.yaml"))
+m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 3)); m = m.to("cuda:0"); m.compute_dtype = torch.bfloat16
+m.autotune = False; m.use_graph = False
+if os.environ.get("ICAF_OLD"):
+    m.fold_upsample = False
+plan = m.plan_for(B, 640, 640, "cuda:0")
+rgb, ir = synth_images(B, 640, 640, seed=3)
+plan.inputs[0].copy_(rgb.cuda()); plan.inputs[1].copy_(ir.cuda())
+sp = ops.current_stream_ptr()
+for i, l in enumerate(plan.launches):
+    l(sp); torch.cuda.synchronize()
+    if l.fn is not ops.lib().icaf_conv2d or not l.keep[0].pre:
+        continue
+    a, x, wp, bias, y, res, pre, chain = l.keep
+    N, K = a.Cout, a.Cin
+    W = wp[:N, :K].float()
+    ref = x.float().reshape(-1, x.shape[-1])[:, :K] @ W.t() + bias[:N]
+    Bp, hp, wq, cp = pre.shape
+    mode = "nearest" if a.pre_mode == 1 else "bilinear"
+    up = F.interpolate(pre.permute(0, 3, 1, 2), size=(a.Ho, a.Wo), mode=mode, **({} if a.pre_mode == 1 else {"align_corners": False}))
+    ref = F.silu(ref + up.permute(0, 2, 3, 1).reshape(-1, cp)[:, :N]).reshape(y.shape)
+    for c in ops.conv_candidates(a):
+        a.tile = c
+        if l.fn(*l.args, sp) != 0:
+            continue
+        torch.cuda.synchronize()
+        d = (y.float() - ref).abs()
+        bad = (d > 0.05 * ref.abs().max()).nonzero()
+        print(f"launch {i} {l.name} mode={mode} N={N} K={K} M={a.B * a.Ho * a.Wo} tile {c}: max |d| = {d.max().item():.3e} bad={len(bad)}" + (f" first bad (b,h,w,c)={bad[0].tolist()} last={bad[-1].tolist()}" if len(bad) else ""))
+    a.tile = 0
+    l(sp); torch.cuda.synchronize()
+
+# determinism / error pattern of the suspicious configuration
+for i, l in enumerate(plan.launches):
+    if l.fn is not ops.lib().icaf_conv2d or not l.keep[0].pre or l.keep[0].pre_mode == 1:
+        continue
+    a, x, wp, bias, y, res, pre, chain = l.keep
+    outs = []
+    for c in (2, 2, 22):
+        a.tile = c
+        l.fn(*l.args, sp); torch.cuda.synchronize()
+        outs.append(y.clone())
+    a.tile = 0
+    d = (outs[0].float() - outs[2].float()).abs()
+    bad = (d > 0).nonzero()
+    print(f"launch {i}: tile2 run-to-run equal={torch.equal(outs[0], outs[1])}; tile 2 vs 22: {len(bad)} differing elements")
+    if len(bad):
+        import collections
+        print("  by batch:", collections.Counter(bad[:, 0].tolist()).most_common(6))
+        print("  by channel mod 64:", collections.Counter((bad[:, 3] % 64).tolist()).most_common(8))
+        print("  by w:", collections.Counter(bad[:, 2].tolist()).most_common(8))
+        print("  by h:", collections.Counter(bad[:, 1].tolist()).most_common(8))
+        print("  linear pixel index mod 128:", collections.Counter((((bad[:, 0] * a.Ho + bad[:, 1]) * a.Wo + bad[:, 2]) % 128).tolist()).most_common(8))
+        for k in bad[:5].tolist():
+            print("   ", k, outs[0][tuple(k)].item(), outs[2][tuple(k)].item())
+    break
