@@ -190,7 +190,10 @@ class Model(HipModule):
         self.use_graph = False       # replay each plan as one hipGraph launch
         self.pair_streams = True     # run structurally identical RGB / IR backbone rows as one groups=2 launch
         self.branch_dmff = True      # capture the shallow DMFF blocks as parallel branches of the hipGraph
-        self.fold_upsample = True    # Upsample -> Concat -> C3: run the up-sampled half of the C3's 1x1 at low resolution
+        # Upsample -> Concat -> C3: run the up-sampled half of the C3's 1x1 at low resolution (C3.emit, VirtualCat).  Built and
+        # tested, OFF by default: the pre-term GEMMs only exist on the 4-wavefront tiles and the forward got 1.1 % slower
+        # (2.573 vs 2.544 ms, same-box A/B) although two up-sampling launches and 40 % of those GEMMs' FLOPs disappear.
+        self.fold_upsample = False
         self.static_outputs = False  # return views of plan-owned buffers instead of clones
 
     # -- reference API ----------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ ops.load_tune_cache(f"{R}/profiles/tune_cache.json")
 st = torch.cuda.Stream(); sp = st.cuda_stream
 for rnd in range(2):
     for v in values:
-        setattr(getattr(common, cls), attr, v)
+        setattr(m if cls == "Model" else getattr(common, cls), attr, v)      # (Model.x: an attribute of the model instance)
         m.invalidate()
         plan = m.plan_for(32, 640, 640, "cuda:0")
         for _ in range(3):
