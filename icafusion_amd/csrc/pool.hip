@@ -124,12 +124,52 @@ __global__ __launch_bounds__(256) void sppf_kernel(const typename Elem<DT>::type
 // LDS version (used whenever a whole H x W plane of VPB channel-vectors fits): the chained pools are done exactly as
 // the reference chains them — three rounds of a separable (horizontal, then vertical) k-max over the plane held in
 // LDS — so each output costs 2k LDS reads instead of (3k-2)^2 global reads.
+// 16-bit types never leave their packed form: a bf16 / f16 bit pattern b maps to the unsigned key
+// b ^ (b & 0x8000 ? 0xffff : 0x8000), which orders like the value (-inf < ... < -0 < +0 < ... < +inf), so the max of
+// eight channels is four `v_pk_max_u16` instead of eight conversions and eight fp32 max per neighbour; the plane is
+// keyed once on the way in and un-keyed on the way out (max only ever selects one of its inputs: bit-exact).
+__device__ __forceinline__ unsigned int key16x2(unsigned int b) {
+    const unsigned int sign = b & 0x80008000u;
+    return b ^ ((sign >> 15) * 0x7fffu | 0x80008000u);          // negative halves: ^0xffff, positive: ^0x8000
+}
+__device__ __forceinline__ u32x4 key_vec(u32x4 v) { return u32x4{key16x2(v[0]), key16x2(v[1]), key16x2(v[2]), key16x2(v[3])}; }
+__device__ __forceinline__ unsigned int unkey16x2(unsigned int k) {
+    const unsigned int pos = k & 0x80008000u;                     // keys of non-negative values have the top bit set
+    return k ^ (((pos ^ 0x80008000u) >> 15) * 0x7fffu | 0x80008000u);
+}
+__device__ __forceinline__ u32x4 unkey_vec(u32x4 v) { return u32x4{unkey16x2(v[0]), unkey16x2(v[1]), unkey16x2(v[2]), unkey16x2(v[3])}; }
+__device__ __forceinline__ unsigned int max_u16x2(unsigned int a, unsigned int b) {
+    using u16x2 = __attribute__((ext_vector_type(2))) unsigned short;
+    const u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    const u16x2 m = __builtin_elementwise_max(x, y);
+    return __builtin_bit_cast(unsigned int, m);
+}
+
+template <int DT> struct PlaneMax {        // element-wise max of two 16-byte vectors in the representation held in LDS
+    static __device__ __forceinline__ u32x4 in(u32x4 v) { return key_vec(v); }
+    static __device__ __forceinline__ u32x4 out(u32x4 v) { return unkey_vec(v); }
+    static __device__ __forceinline__ u32x4 mx(u32x4 a, u32x4 b) {
+        return u32x4{max_u16x2(a[0], b[0]), max_u16x2(a[1], b[1]), max_u16x2(a[2], b[2]), max_u16x2(a[3], b[3])};
+    }
+};
+template <> struct PlaneMax<ICAF_F32> {
+    static __device__ __forceinline__ u32x4 in(u32x4 v) { return v; }
+    static __device__ __forceinline__ u32x4 out(u32x4 v) { return v; }
+    static __device__ __forceinline__ u32x4 mx(u32x4 a, u32x4 b) {
+        u32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = __float_as_uint(fmaxf(__uint_as_float(a[j]), __uint_as_float(b[j])));
+        return r;
+    }
+};
+
 template <int DT>
 __global__ __launch_bounds__(256) void sppf_lds_kernel(const typename Elem<DT>::type* __restrict__ x, int ldx,
                                                        typename Elem<DT>::type* __restrict__ y1, typename Elem<DT>::type* __restrict__ y2,
                                                        typename Elem<DT>::type* __restrict__ y3, int ldy, int H, int W, int C, int k,
                                                        int vpb) {
     using E = Elem<DT>;
+    using PM = PlaneMax<DT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* cur = (u32x4*)smem;
     u32x4* tmp = cur + (size_t)H * W * vpb;
@@ -139,7 +179,7 @@ __global__ __launch_bounds__(256) void sppf_lds_kernel(const typename Elem<DT>::
     const long long pix0 = (long long)b * H * W;
     for (int i = threadIdx.x; i < n; i += 256) {
         const int v = i % vpb, p = i / vpb;
-        cur[i] = *(const u32x4*)(x + (pix0 + p) * ldx + (vg * vpb + v) * E::VEC);
+        cur[i] = PM::in(*(const u32x4*)(x + (pix0 + p) * ldx + (vg * vpb + v) * E::VEC));
     }
     __syncthreads();
     typename E::type* outs[3] = {y1, y2, y3};
@@ -147,32 +187,23 @@ __global__ __launch_bounds__(256) void sppf_lds_kernel(const typename Elem<DT>::
     for (int stage = 0; stage < 3; ++stage) {
         for (int i = threadIdx.x; i < n; i += 256) {
             const int v = i % vpb, p = i / vpb, xx = p % W, yy = p / W;
-            float m[E::VEC];
-            unpack16<DT>(cur[i], m);
+            u32x4 m = cur[i];
             for (int d = -r; d <= r; ++d) {
                 if (d == 0 || (unsigned)(xx + d) >= (unsigned)W) continue;
-                float f[E::VEC];
-                unpack16<DT>(cur[(yy * W + xx + d) * vpb + v], f);
-#pragma unroll
-                for (int j = 0; j < E::VEC; ++j) m[j] = fmaxf(m[j], f[j]);
+                m = PM::mx(m, cur[(yy * W + xx + d) * vpb + v]);
             }
-            tmp[i] = pack16<DT>(m);
+            tmp[i] = m;
         }
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += 256) {
             const int v = i % vpb, p = i / vpb, xx = p % W, yy = p / W;
-            float m[E::VEC];
-            unpack16<DT>(tmp[i], m);
+            u32x4 m = tmp[i];
             for (int d = -r; d <= r; ++d) {
                 if (d == 0 || (unsigned)(yy + d) >= (unsigned)H) continue;
-                float f[E::VEC];
-                unpack16<DT>(tmp[((yy + d) * W + xx) * vpb + v], f);
-#pragma unroll
-                for (int j = 0; j < E::VEC; ++j) m[j] = fmaxf(m[j], f[j]);
+                m = PM::mx(m, tmp[((yy + d) * W + xx) * vpb + v]);
             }
-            const u32x4 o = pack16<DT>(m);
-            cur[i] = o;
-            *(u32x4*)(outs[stage] + (pix0 + p) * ldy + (vg * vpb + v) * E::VEC) = o;
+            cur[i] = m;
+            *(u32x4*)(outs[stage] + (pix0 + p) * ldy + (vg * vpb + v) * E::VEC) = PM::out(m);
         }
         __syncthreads();
     }
