@@ -184,6 +184,9 @@ def metrics_case(general, metrics, name):
 def main():
     torch.set_num_threads(os.cpu_count())
     yt, common, general, metrics = import_reference()
+    if "--m-only" in sys.argv:                        # yolov5m widths (48 / 96 / 192 / 384 / 768: no powers of two), added later
+        model_case(yt, "model_m_kaist_320_b1", "yolov5m_Transfusion_kaist.yaml", 1, 320, 320, seed=13)
+        return
     if "--fusion-variants-only" in sys.argv:          # the NiNfusion / Add fixtures, added later
         model_case(yt, "model_s_add_kaist_320_b1", "yolov5s_Add_kaist.yaml", 1, 320, 320, seed=11)
         model_case(yt, "model_n_ninfusion_flir_320_b2", "yolov5n_NiNfusion_FLIR.yaml", 2, 320, 320, seed=12)
@@ -205,6 +208,7 @@ def main():
     metrics_case(general, metrics, "metrics_ap")
     model_case(yt, "model_s_add_kaist_320_b1", "yolov5s_Add_kaist.yaml", 1, 320, 320, seed=11)
     model_case(yt, "model_n_ninfusion_flir_320_b2", "yolov5n_NiNfusion_FLIR.yaml", 2, 320, 320, seed=12)
+    model_case(yt, "model_m_kaist_320_b1", "yolov5m_Transfusion_kaist.yaml", 1, 320, 320, seed=13)
 
 
 if __name__ == "__main__":
