@@ -151,3 +151,28 @@ def test_every_launch_configuration_is_bit_identical_at_full_grid():
             y.copy_(snap)
         l(sp); torch.cuda.synchronize()
     assert checked > 150
+
+
+def test_bench_configuration_equals_plain_plan():
+    """What bench.py measures — batch 32, hipGraph replay, the committed tile choices of profiles/tune_cache.json — gives
+    the same bits as the plain plan (default tiles, launch by launch, no graph), twice in a row."""
+    import os
+    from icafusion_amd import ops
+    cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", torch.bfloat16, seed=4)
+    rgb, ir = synth_images(32, 640, 640, seed=4)
+    rgb, ir = rgb.to(DEV), ir.to(DEV)
+    m.autotune, m.use_graph = False, False
+    plain = m(rgb, ir)[0].clone()
+    saved = dict(ops._TUNE_CACHE)
+    try:
+        ops.load_tune_cache(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tune_cache.json"))
+        m.autotune, m.use_graph = True, True
+        m.invalidate()
+        a = m(rgb, ir)[0].clone()
+        b = m(rgb, ir)[0].clone()
+    finally:
+        ops._TUNE_CACHE.clear()
+        ops._TUNE_CACHE.update(saved)
+    assert torch.equal(a, b), "graph replay must be deterministic"
+    assert torch.equal(a, plain), "tuned + graph-replayed forward must equal the plain plan bit for bit"
+    assert torch.isfinite(plain.float()).all()
