@@ -219,6 +219,72 @@ static int nms_layout(int B, long long rows, int nc, int multi, void* base, NmsW
     return ICAF_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Validation statistics (reference test.py:196-230): TP flags of every detection at every IoU threshold
+// ---------------------------------------------------------------------------------------------------------------
+// One workgroup per image.  Detections arrive as the NMS output block (letterboxed pixel space) and are first mapped to
+// the native image (scale_coords + clip_coords, utils/general.py:386-407: subtract the pad, divide by the gain, clip).
+// Phase 1, one thread per detection: best IoU over the labels of its class and the FIRST label reaching it (box_iou +
+// torch max).  Phase 2, one thread: detections in index order claim their best label if nobody has and the IoU exceeds
+// iouv[0]; a claim marks correct[i][t] = best > iouv[t].  (The reference walks class by class; claims of different
+// classes never touch the same label, so index order gives the same flags.)  fp32, no contraction: the IoU values are
+// bit-identical to the numpy statement of the same formula (icafusion_amd/utils/metrics.py, the test oracle).
+constexpr int MATCH_MAX_DET = 1024, MATCH_MAX_LABELS = 2048;
+
+__global__ __launch_bounds__(256) void match_predictions_kernel(const float* __restrict__ det, const int* __restrict__ count, int max_det,
+                                                                const float* __restrict__ labels, const int* __restrict__ label_off,
+                                                                const float* __restrict__ scale, const float* __restrict__ iouv, int T,
+                                                                unsigned char* __restrict__ correct, float* __restrict__ predn) {
+    __shared__ float best[MATCH_MAX_DET];
+    __shared__ int arg[MATCH_MAX_DET];
+    __shared__ unsigned char claimed[MATCH_MAX_LABELS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(count[b], max_det), l0 = label_off[b], nl = label_off[b + 1] - l0;
+    const float* db = det + (long long)b * max_det * 6;
+    float gain = 1.0f, padx = 0.0f, pady = 0.0f, w0 = 3.0e38f, h0 = 3.0e38f;
+    if (scale) { gain = scale[b * 5]; padx = scale[b * 5 + 1]; pady = scale[b * 5 + 2]; w0 = scale[b * 5 + 3]; h0 = scale[b * 5 + 4]; }
+    for (int i = tid; i < nl; i += 256) claimed[i] = 0;
+    for (int i = tid; i < n; i += 256) {
+        float x1 = db[i * 6], y1 = db[i * 6 + 1], x2 = db[i * 6 + 2], y2 = db[i * 6 + 3];
+        const float cls = db[i * 6 + 5];
+        if (scale) {
+            x1 = (x1 - padx) / gain; x2 = (x2 - padx) / gain; y1 = (y1 - pady) / gain; y2 = (y2 - pady) / gain;
+            x1 = fminf(fmaxf(x1, 0.0f), w0); x2 = fminf(fmaxf(x2, 0.0f), w0);
+            y1 = fminf(fmaxf(y1, 0.0f), h0); y2 = fminf(fmaxf(y2, 0.0f), h0);
+        }
+        if (predn) {
+            float* o = predn + ((long long)b * max_det + i) * 4;
+            o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
+        }
+        const float area_a = (x2 - x1) * (y2 - y1);
+        float bst = -1.0f;
+        int ba = -1;
+        for (int j = 0; j < nl; ++j) {
+            const float* lb = labels + (long long)(l0 + j) * 5;
+            if (lb[0] != cls) continue;
+            const float iw = fmaxf(fminf(x2, lb[3]) - fmaxf(x1, lb[1]), 0.0f), ih = fmaxf(fminf(y2, lb[4]) - fmaxf(y1, lb[2]), 0.0f);
+            const float inter = iw * ih, area_b = (lb[3] - lb[1]) * (lb[4] - lb[2]);
+            const float iou = inter / (area_a + area_b - inter);
+            if (iou > bst) { bst = iou; ba = j; }
+        }
+        best[i] = bst;
+        arg[i] = ba;
+        for (int t = 0; t < T; ++t) correct[((long long)b * max_det + i) * T + t] = 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float thr0 = iouv[0];
+        int found = 0;
+        for (int i = 0; i < n && found < nl; ++i) {
+            if (arg[i] < 0 || !(best[i] > thr0) || claimed[arg[i]]) continue;
+            claimed[arg[i]] = 1;
+            ++found;
+            for (int t = 0; t < T; ++t) correct[((long long)b * max_det + i) * T + t] = best[i] > iouv[t] ? 1 : 0;
+        }
+    }
+}
+
 }  // namespace icaf
 
 using namespace icaf;
@@ -260,6 +326,18 @@ extern "C" int icaf_nms(const float* pred, int B, long long rows, int nc, float 
                                                      (unsigned int)B, ws.seg_begin, ws.seg_end, 0, 64, hs));
     nms_greedy_kernel<<<dim3((unsigned)B), dim3(256), 0, hs>>>(ws.keys_out, ws.cdet, ws.ncand, cap, iou_thres, agnostic ? 0.0f : max_wh,
                                                                 max_det, max_nms, det, count, keep_idx);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+extern "C" int icaf_match_predictions(const float* det, const int* count, int B, int max_det, const float* labels, const int* label_off,
+                                      int max_labels_per_image, const float* scale, const float* iouv, int T, unsigned char* correct,
+                                      float* predn, icaf_stream_t s) {
+    if (!det || !count || !label_off || !iouv || !correct) return fail(ICAF_ERR_ARG, "icaf_match_predictions: null pointer");
+    if (B < 1 || T < 1 || max_det < 1 || max_det > MATCH_MAX_DET) return fail(ICAF_ERR_ARG, "icaf_match_predictions: max_det must be in [1, %d]", MATCH_MAX_DET);
+    if (max_labels_per_image > MATCH_MAX_LABELS) return fail(ICAF_ERR_UNSUPPORTED, "icaf_match_predictions: at most %d labels per image", MATCH_MAX_LABELS);
+    if (max_labels_per_image > 0 && !labels) return fail(ICAF_ERR_ARG, "icaf_match_predictions: labels missing");
+    match_predictions_kernel<<<dim3((unsigned)B), dim3(256), 0, S(s)>>>(det, count, max_det, labels, label_off, scale, iouv, T, correct, predn);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }

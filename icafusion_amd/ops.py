@@ -516,6 +516,27 @@ class NmsRunner:
 # ------------------------------------------------------------------------------------------------------------
 # graph capture + events
 # ------------------------------------------------------------------------------------------------------------
+def match_predictions(det, count, labels, label_off, iouv, scale=None, predn=None, stream_ptr=None):
+    """TP flags of every detection at every IoU threshold on the device (icaf_match_predictions; reference
+    test.py:196-230).  det (B, max_det, 6) / count (B,) int32: the NMS output block; labels (L, 5) fp32 [cls, x1, y1,
+    x2, y2] in native image space sorted by image, label_off (B + 1,) int32; scale (B, 5) fp32 [gain, pad_x, pad_y, w0,
+    h0] or None; iouv (T,) fp32.  Returns uint8 (B, max_det, T); rows >= count[b] are unspecified."""
+    B, max_det, six = det.shape
+    assert six == 6 and det.dtype == torch.float32 and det.is_contiguous() and count.dtype == torch.int32
+    assert label_off.dtype == torch.int32 and label_off.numel() == B + 1 and iouv.dtype == torch.float32
+    assert labels.dtype == torch.float32 and labels.is_contiguous() and (labels.numel() == 0 or labels.shape[1] == 5)
+    T = iouv.numel()
+    correct = torch.empty((B, max_det, T), dtype=torch.uint8, device=det.device)
+    off = label_off.cpu()
+    max_l = int((off[1:] - off[:-1]).max()) if B else 0
+    st = lib().icaf_match_predictions(det.data_ptr(), count.data_ptr(), B, max_det, labels.data_ptr() if labels.numel() else None,
+                                      label_off.data_ptr(), max_l, scale.data_ptr() if scale is not None else None, iouv.data_ptr(), T,
+                                      correct.data_ptr(), predn.data_ptr() if predn is not None else None,
+                                      stream_ptr if stream_ptr is not None else current_stream_ptr())
+    check(st, "icaf_match_predictions")
+    return correct
+
+
 class Graph:
     def __init__(self):
         self.exec = C.c_void_p(None)

@@ -224,6 +224,15 @@ int icaf_detect_decode(const float* p, int ldp, float* z, float* logits, float* 
  * det: [B][max_det][6] (x1,y1,x2,y2,conf,cls), count: [B], keep_idx: [B][max_det] = indices into the image's
  * candidate list exactly as torchvision.ops.nms would return them (may be NULL).
  */
+/* Validation statistics of test.py:196-230 on the device, one workgroup per image: the NMS output block det
+ * [B][max_det][6] / count[B] (letterboxed pixel space) is mapped to native image space with scale[b] = {gain, pad_x,
+ * pad_y, w0, h0} (scale_coords + clip_coords, utils/general.py:386-407; NULL = already native), every detection is paired
+ * with the best-IoU label of its class (labels [L][5] = cls, x1, y1, x2, y2 in native space, image b owning rows
+ * [label_off[b], label_off[b+1])), and claims it in index order if its IoU exceeds iouv[0]:
+ * correct[b][i][t] = claimed && iou > iouv[t] (uint8).  predn (optional) receives the native-space boxes [B][max_det][4]. */
+int icaf_match_predictions(const float* det, const int* count, int B, int max_det, const float* labels, const int* label_off,
+                           int max_labels_per_image, const float* scale, const float* iouv, int T, unsigned char* correct,
+                           float* predn, icaf_stream_t s);
 int icaf_nms_workspace_bytes(int B, long long rows, int nc, int multi_label, size_t* bytes);
 int icaf_nms(const float* pred, int B, long long rows, int nc, float conf_thres, float iou_thres, int multi_label,
              int agnostic, const int* classes_host, int n_classes, int max_det, int max_nms, float max_wh,

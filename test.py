@@ -18,8 +18,9 @@ import yaml
 from icafusion_amd.models.experimental import attempt_load
 from icafusion_amd.models.yolo import Model
 from icafusion_amd.utils.datasets import create_dataloader_rgb_ir
-from icafusion_amd.utils.general import non_max_suppression, scale_coords, xywh2xyxy
-from icafusion_amd.utils.metrics import ap_per_class, match_predictions
+from icafusion_amd import ops
+from icafusion_amd.utils.general import nms_device, scale_coords, xywh2xyxy
+from icafusion_amd.utils.metrics import ap_per_class
 from icafusion_amd.utils.torch_utils import select_device, time_synchronized
 
 
@@ -57,27 +58,34 @@ def test(data, weights=None, batch_size=32, imgsz=640, conf_thres=0.001, iou_thr
         targets = targets.clone()
         targets[:, 2:] *= torch.tensor([width, height, width, height])
         t = time_synchronized()
-        out = non_max_suppression(out, conf_thres, iou_thres, multi_label=True, agnostic=single_cls)
+        det, count, _ = nms_device(out, conf_thres, iou_thres, multi_label=True, agnostic=single_cls)
         t_nms += time_synchronized() - t
-        for si, pred in enumerate(out):
+        # statistics per image (reference test.py:144-230) on the device: labels go up in native image space, one kernel
+        # maps the detections there (scale_coords + clip_coords) and matches them; only flags / conf / cls come back
+        if single_cls:
+            det[..., 5] = 0
+        lab_rows, off, scale, tcls_all = [], [0], [], []
+        for si in range(nb):
             labels = targets[targets[:, 0] == si, 1:]
-            nl, tcls = len(labels), labels[:, 0].tolist()
+            tcls_all.append(labels[:, 0].tolist())
+            tbox = xywh2xyxy(labels[:, 1:5])
+            scale_coords(img[si].shape[1:], tbox, shapes[si][0], shapes[si][1])               # native-space labels
+            lab_rows.append(torch.cat((labels[:, :1], tbox), 1))
+            off.append(off[-1] + len(labels))
+            (h0, w0), ((gain, _), (padw, padh)) = shapes[si][0], shapes[si][1]
+            scale.append([gain, padw, padh, w0, h0])
+        correct = ops.match_predictions(det, count, torch.cat(lab_rows).float().contiguous().to(dev),
+                                        torch.tensor(off, dtype=torch.int32, device=dev), torch.from_numpy(iouv.astype(np.float32)).to(dev),
+                                        scale=torch.tensor(scale, dtype=torch.float32, device=dev))
+        correct, cc, count = correct.cpu().numpy().astype(bool), det[..., 4:6].cpu().numpy(), count.cpu().numpy()
+        for si in range(nb):
+            n, tcls = int(count[si]), tcls_all[si]
             seen += 1
-            if len(pred) == 0:
-                if nl:
+            if n == 0:
+                if tcls:
                     stats.append((np.zeros((0, 10), bool), np.zeros(0), np.zeros(0), tcls))
                 continue
-            pred = pred.cpu()
-            if single_cls:
-                pred[:, 5] = 0
-            predn = pred.clone()
-            scale_coords(img[si].shape[1:], predn[:, :4], shapes[si][0], shapes[si][1])       # native-space predictions
-            correct = np.zeros((len(pred), 10), bool)
-            if nl:
-                tbox = xywh2xyxy(labels[:, 1:5])
-                scale_coords(img[si].shape[1:], tbox, shapes[si][0], shapes[si][1])           # native-space labels
-                correct = match_predictions(predn.numpy(), torch.cat((labels[:, :1], tbox), 1).numpy(), iouv)
-            stats.append((correct, pred[:, 4].numpy(), pred[:, 5].numpy(), tcls))
+            stats.append((correct[si, :n] if tcls else np.zeros((n, 10), bool), cc[si, :n, 0], cc[si, :n, 1], tcls))
     mp = mr = map50 = map_ = 0.0
     ap, ap_class, nt = np.zeros((0, 10)), np.zeros(0, int), np.zeros(nc, int)
     if stats:

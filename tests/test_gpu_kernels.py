@@ -772,3 +772,52 @@ def test_graph_capture_replays_conv():
         plan.run(s.cuda_stream)
     s.synchronize()
     assert torch.equal(y, eager)
+
+
+@pytest.mark.parametrize("seed,with_scale", [(1, False), (2, True), (3, True)])
+def test_match_predictions_equals_host_statement(seed, with_scale):
+    """icaf_match_predictions (scale_coords + clip + per-class best-IoU matching of test.py:196-230 on the device) vs the
+    numpy statement in icafusion_amd/utils/metrics.py: identical TP flags, identical native-space boxes."""
+    from icafusion_amd.utils.metrics import match_predictions as host_match
+    g = np.random.default_rng(seed)
+    B, max_det, nc = 5, 300, 4
+    det = np.zeros((B, max_det, 6), np.float32)
+    count = g.integers(0, max_det + 1, B).astype(np.int32)
+    count[0] = 0
+    labels, off, scales = [], [0], []
+    for b in range(B):
+        n = count[b]
+        xy = g.uniform(0, 600, (n, 2)); wh = g.uniform(5, 120, (n, 2))
+        det[b, :n, :2], det[b, :n, 2:4] = xy, xy + wh
+        det[b, :n, 4], det[b, :n, 5] = np.sort(g.uniform(0.1, 1, n))[::-1], g.integers(0, nc, n)
+        nl = 0 if b == 1 else int(g.integers(1, 40))
+        gain, px, py = (float(g.uniform(0.4, 1.6)), float(g.uniform(0, 40)), float(g.uniform(0, 40))) if with_scale else (1.0, 0.0, 0.0)
+        w0, h0 = (500.0, 420.0) if with_scale else (3.0e38, 3.0e38)
+        scales.append([gain, px, py, w0, h0])
+        lab = np.zeros((nl, 5), np.float32)
+        for k in range(nl):                       # labels near detections (so that matches exist), in native space
+            if n and g.random() < 0.7:
+                src = det[b, g.integers(0, n)]
+                box = (src[:4] - np.array([px, py, px, py], np.float32)) / np.float32(gain) + g.normal(0, 4, 4)
+                lab[k] = [src[5], *box]
+            else:
+                x, y = g.uniform(0, 400, 2); lab[k] = [g.integers(0, nc), x, y, x + g.uniform(5, 90), y + g.uniform(5, 90)]
+        labels.append(lab); off.append(off[-1] + nl)
+    lab_all = np.concatenate(labels, 0).astype(np.float32)
+    iouv = np.linspace(0.5, 0.95, 10).astype(np.float32)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    scale_t = dev(np.array(scales, np.float32)) if with_scale else None
+    predn = torch.zeros((B, max_det, 4), dtype=torch.float32, device=DEV)
+    correct = ops.match_predictions(dev(det), dev(count), dev(lab_all), dev(np.array(off, np.int32)), dev(iouv), scale=scale_t, predn=predn)
+    torch.cuda.synchronize()
+    correct, predn = correct.cpu().numpy().astype(bool), predn.cpu().numpy()
+    for b in range(B):
+        n = count[b]
+        pn = det[b, :n].copy()
+        if with_scale:
+            gain, px, py, w0, h0 = (np.float32(v) for v in scales[b])
+            pn[:, [0, 2]] = np.clip((pn[:, [0, 2]] - px) / gain, 0, w0)
+            pn[:, [1, 3]] = np.clip((pn[:, [1, 3]] - py) / gain, 0, h0)
+        np.testing.assert_array_equal(predn[b, :n], pn[:, :4])
+        ref = host_match(pn, labels[b], iouv)
+        np.testing.assert_array_equal(correct[b, :n], ref, err_msg=f"image {b}")
