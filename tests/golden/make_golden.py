@@ -187,6 +187,9 @@ def main():
     if "--m-only" in sys.argv:                        # yolov5m widths (48 / 96 / 192 / 384 / 768: no powers of two), added later
         model_case(yt, "model_m_kaist_320_b1", "yolov5m_Transfusion_kaist.yaml", 1, 320, 320, seed=13)
         return
+    if "--n-only" in sys.argv:                        # yolov5n + DMFF (16-channel stem, C = 64 / 128 / 256 fusion blocks), added later
+        model_case(yt, "model_n_flir_352x320_b2", "yolov5n_Transfusion_FLIR.yaml", 2, 352, 320, seed=14)
+        return
     if "--fusion-variants-only" in sys.argv:          # the NiNfusion / Add fixtures, added later
         model_case(yt, "model_s_add_kaist_320_b1", "yolov5s_Add_kaist.yaml", 1, 320, 320, seed=11)
         model_case(yt, "model_n_ninfusion_flir_320_b2", "yolov5n_NiNfusion_FLIR.yaml", 2, 320, 320, seed=12)
@@ -209,6 +212,7 @@ def main():
     model_case(yt, "model_s_add_kaist_320_b1", "yolov5s_Add_kaist.yaml", 1, 320, 320, seed=11)
     model_case(yt, "model_n_ninfusion_flir_320_b2", "yolov5n_NiNfusion_FLIR.yaml", 2, 320, 320, seed=12)
     model_case(yt, "model_m_kaist_320_b1", "yolov5m_Transfusion_kaist.yaml", 1, 320, 320, seed=13)
+    model_case(yt, "model_n_flir_352x320_b2", "yolov5n_Transfusion_FLIR.yaml", 2, 352, 320, seed=14)
 
 
 if __name__ == "__main__":

@@ -31,7 +31,8 @@ def build(yaml_name, seed, dtype=torch.float32, loops=None):
 
 GOLDEN = ["model_s_kaist_320_b2", "model_s_kaist_384x320_loops3", "model_l_vedai_320_b1", "model_s_kaist_640_b1",
           "model_s_add_kaist_320_b1", "model_n_ninfusion_flir_320_b2",      # Add / NiNfusion variants
-          "model_m_kaist_320_b1"]                                           # yolov5m widths: 48 / 96 / 192 / 384 / 768 channels
+          "model_m_kaist_320_b1",                                           # yolov5m widths: 48 / 96 / 192 / 384 / 768 channels
+          "model_n_flir_352x320_b2"]                                        # yolov5n + DMFF, rectangular input, FLIR classes
 
 
 @pytest.mark.parametrize("name", GOLDEN)
