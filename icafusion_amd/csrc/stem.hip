@@ -528,8 +528,8 @@ static int launch_stem(const StemP& q, hipStream_t s) {
     constexpr int EB = Elem<DT>::BYTES;
     const int lds = 2 * ST_PATCH_BYTES + 3 * BN * 128 + ST_TH * ST_TW * (BN * EB + 16);
     int dev = 0, cus = 256;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    ICAF_HIP(hipGetDevice(&dev));
+    ICAF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int per_cu = (160 * 1024) / lds < 4 ? (160 * 1024) / lds : 4;
     int grid = cus * (per_cu < 1 ? 1 : per_cu);
     if (grid > q.npatch) grid = q.npatch;
@@ -579,8 +579,8 @@ extern "C" int icaf_stem(const void* img, int img_u8, int ctot, const void* w, c
 template <int DT, bool U8>
 static int launch_stem2(const Stem2P& q, hipStream_t s) {
     int dev = 0, cus = 256;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    ICAF_HIP(hipGetDevice(&dev));
+    ICAF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     int grid = cus < q.npatch ? cus : q.npatch;     // 122 KiB of LDS: one workgroup per CU
     grid = (grid + 7) & ~7;                         // the tile walk is per XCD (8 of them)
     static bool attr = false;
