@@ -110,3 +110,30 @@ def test_host_metrics_match_reference_fixture():
     np.testing.assert_allclose(r[4], g["r"], rtol=1e-9)
     np.testing.assert_allclose(box_iou(torch.from_numpy(g["box1"]), torch.from_numpy(g["box2"])).numpy(), g["iou"], rtol=1e-6)
     np.testing.assert_allclose(scale_coords((512, 640), torch.from_numpy(g["coords"]).clone(), (480, 720)).numpy(), g["scaled"], rtol=1e-6)
+
+
+def test_pmc_summary_kernel_names_match_bench_names():
+    """tools/pmc_summary.py maps rocprofv3 kernel names to the names bench.py reports (roofline.traffic is looked up by
+    name: a template argument added to a kernel must not silently turn the traffic into null)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                               "tools", "pmc_summary.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cases = {
+        "void icaf::igemm_dma_kernel<1, 1, 128, 128, 64, 32, 1, 128, 2, 1, false, false>(icaf::ConvP)": "igemm_dma128x2_bf16_bf16_128x128w8",
+        "void icaf::igemm_dma_kernel<1, 1, 128, 128, 64, 64, 1, 64, 3, 2, false, true>(icaf::ConvP)": "igemm_dma64x3_bf16_bf16_128x128",
+        "void icaf::igemm_dma_kernel<1, 0, 64, 64, 32, 32, 0, 64, 3, 1, false, false>(icaf::ConvP)": "igemm_dma64x3_bf16_f32_64x64",
+        "void icaf::igemm_kernel<1, 1, 128, 64, 64, 32, 1>(icaf::ConvP)": "igemm_reg_bf16_bf16_128x64",
+        "void icaf::ctile_kernel<1, 8, 32, 64, 1, 1>(icaf::ConvP, int, int, int, int, int)": "ctile_bf16_8x32n64",
+        "void icaf::bneck_kernel<1, 8, 32, 32, 1, true>(icaf::ConvP, int, int, int, int, int)": "bottleneck+cv3",
+        "void icaf::bneck_kernel<1, 8, 32, 32, 1, false>(icaf::ConvP, int, int, int, int, int)": "bottleneck",
+        "void icaf::stem2_kernel<1, false>(icaf::Stem2P)": "stem+conv3x3s2+1x1",
+        "void icaf::stem_kernel<1, 32, false>(icaf::StemP)": "stem",
+        "void icaf::pool_tokens_rows_kernel<1>(icaf::Elem<1>::type const*, int)": "dmff_pool_tokens",
+        "void icaf::pool_tokens_kernel<1>(icaf::Elem<1>::type const*, int)": "dmff_pool_tokens",
+        "void icaf::sppf_lds_kernel<1>(icaf::Elem<1>::type const*, int)": "sppf_pool",
+    }
+    for raw, want in cases.items():
+        assert mod.short(raw) == want, raw
