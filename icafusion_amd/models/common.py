@@ -756,9 +756,12 @@ class CrossTransformerBlock(HipModule):
 class TransformerFusionBlock(HipModule):
     """DMFF: Dual-Modality Feature Fusion (reference models/common.py:762-865).
 
-    Optional `loops_num` (5th positional after h/block_exp/n_layer in the reference's signature order is kept;
-    the yaml passes it as the 4th list element, see models/yolo.py) exposes the iterative parameter-shared loop
-    the reference wires but never surfaces (models/common.py:691,744)."""
+    The reference's positional signature is kept; the extra keyword `loops_num` (yaml: a trailing `{loops_num: n}` mapping,
+    see models/yolo.py) exposes the iterative parameter-shared loop the reference wires but never surfaces
+    (models/common.py:691,744)."""
+
+    # class-level (not set in __init__): instances un-pickled from reference checkpoints never ran this __init__
+    fuse_tail = True         # run interpolate + residual + cat + conv1x1_out as one GEMM when the layout allows
 
     def __init__(self, d_model, vert_anchors=16, horz_anchors=16, h=8, block_exp=4, n_layer=1, embd_pdrop=0.1,
                  attn_pdrop=0.1, resid_pdrop=0.1, loops_num=1):
@@ -775,7 +778,6 @@ class TransformerFusionBlock(HipModule):
             for _ in range(n_layer)])
         self.concat = Concat(dimension=1)
         self.conv1x1_out = Conv(c1=d_model * 2, c2=d_model, k=1, s=1, p=0, g=1, act=True)
-        self.fuse_tail = True        # run interpolate + residual + cat + conv1x1_out as one GEMM when the layout allows
 
     def emit(self, plan, xs, out=None):
         rgb, ir = xs

@@ -97,8 +97,13 @@ def parse_model(d, ch):
             args = [c2]
         elif m is TransformerFusionBlock:
             c2 = ch[f[0]]
-            extra = {"loops_num": args[3]} if len(args) > 3 else {}
-            args = [c2, *args[1:3]]
+            # positional arguments exactly as the reference passes them (models/yolo_test.py:284-286: args = [c2, *args[1:]],
+            # i.e. vert_anchors, horz_anchors, h, block_exp, ...); the parameter-shared iteration count, which the reference
+            # wires but never surfaces (models/common.py:691,744), is an optional trailing mapping: [1024, 10, 10, {loops_num: 3}]
+            extra = dict(args.pop()) if args and isinstance(args[-1], dict) else {}
+            if set(extra) - {"loops_num"}:
+                raise ValueError(f"TransformerFusionBlock: unknown yaml keyword(s) {sorted(set(extra) - {'loops_num'})}")
+            args = [c2, *args[1:]]
             m_ = m(*args, **extra)
         else:
             c2 = ch[f]
@@ -157,6 +162,22 @@ def _same_structure(a, b):
 
 
 class Model(HipModule):
+    # Execution switches of the MI355X implementation.  They are CLASS-level defaults on purpose: reference checkpoints are
+    # whole pickled Model objects (train.py:424-435) whose __dict__ is restored without running this __init__, so every
+    # attribute the reference does not know must resolve through the class (set it on an instance to override).
+    compute_dtype = None     # None: the parameters' dtype (.half() / .bfloat16() as in the reference);
+    #                          set to torch.bfloat16 / float16 to keep fp32 masters and only pack in 16 bit
+    autotune = False         # device-time every igemm configuration once per plan and keep the fastest
+    use_graph = False        # replay each plan as one hipGraph launch
+    pair_streams = True      # run structurally identical RGB / IR backbone rows as one groups=2 launch
+    branch_dmff = True       # capture the shallow DMFF blocks as parallel branches of the hipGraph
+    # Upsample -> Concat -> C3: run the up-sampled half of the C3's 1x1 at low resolution (C3.emit, VirtualCat).  Built and
+    # tested, OFF by default: the pre-term GEMMs only exist on the 4-wavefront tiles and the forward got 1.1 % slower
+    # (2.573 vs 2.544 ms, same-box A/B) although two up-sampling launches and 40 % of those GEMMs' FLOPs disappear.
+    fold_upsample = False
+    static_outputs = False   # return views of plan-owned buffers instead of clones
+    plan_cache_bytes = 64 << 30     # LRU cap on the plan-owned buffers of all cached (B, H, W, dtype) plans; None = unbounded
+
     def __init__(self, cfg="yolov5s.yaml", ch=3, nc=None, anchors=None):
         super().__init__()
         if isinstance(cfg, dict):
@@ -184,17 +205,6 @@ class Model(HipModule):
         for mod in self.modules():                      # utils/torch_utils.py:144-154 (initialize_weights)
             if type(mod) is nn.BatchNorm2d:
                 mod.eps, mod.momentum = 1e-3, 0.03
-        self.compute_dtype = None    # None: the parameters' dtype (.half() / .bfloat16() as in the reference);
-        #                              set to torch.bfloat16 / float16 to keep fp32 masters and only pack in 16 bit
-        self.autotune = False        # device-time every igemm configuration once per plan and keep the fastest
-        self.use_graph = False       # replay each plan as one hipGraph launch
-        self.pair_streams = True     # run structurally identical RGB / IR backbone rows as one groups=2 launch
-        self.branch_dmff = True      # capture the shallow DMFF blocks as parallel branches of the hipGraph
-        # Upsample -> Concat -> C3: run the up-sampled half of the C3's 1x1 at low resolution (C3.emit, VirtualCat).  Built and
-        # tested, OFF by default: the pre-term GEMMs only exist on the 4-wavefront tiles and the forward got 1.1 % slower
-        # (2.573 vs 2.544 ms, same-box A/B) although two up-sampling launches and 40 % of those GEMMs' FLOPs disappear.
-        self.fold_upsample = False
-        self.static_outputs = False  # return views of plan-owned buffers instead of clones
 
     # -- reference API ----------------------------------------------------------------------------------------
     def forward(self, x, x2, augment=False, profile=False):
@@ -457,16 +467,7 @@ class Model(HipModule):
         B, _, H, W = x.shape
         if H % 32 or W % 32:
             raise ValueError(f"input size {H}x{W} must be a multiple of the max stride 32")
-        key = (B, H, W, dt, x.device)
-        plans = self.__dict__.setdefault("_plans", {})
-        if key not in plans:
-            plan = self.build_plan(B, H, W, x.device, dt)
-            if self.autotune:
-                plan.autotune()
-            if self.use_graph:
-                plan.capture()
-            plans[key] = plan
-        plan = plans[key]
+        plan = self.plan_for(B, H, W, x.device, dt)
         if x.data_ptr() != plan.inputs[0].data_ptr():
             plan.inputs[0].copy_(x)
         if x2.data_ptr() != plan.inputs[1].data_ptr():
@@ -503,18 +504,35 @@ class Model(HipModule):
 
     def plan_for(self, B, H, W, device="cuda", dtype=None, u8=False):
         """Pre-build (and return) the execution plan; its .inputs are the static RGB / IR staging buffers (u8: the one
-        uint8 6-channel staging buffer)."""
+        uint8 6-channel staging buffer).  Plans live in a least-recently-used cache capped at `plan_cache_bytes` of plan-owned
+        buffers: a validation run with rectangular batches and a ragged last batch (test.py) meets a new (B, H, W) every few
+        batches, and each plan pins all of its intermediates (yolov5l 1280x1280 b16: ~40 GB).  Evicted plans are freed as
+        soon as nobody else (a DetectionPipeline, a caller) holds them; the newest plan is always kept."""
         dt = dtype or self.compute_dtype or next(self.parameters()).dtype
         device = torch.device(device)
-        if device.index is None:
+        if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         key = (B, H, W, dt, device, "u8") if u8 else (B, H, W, dt, device)
         plans = self.__dict__.setdefault("_plans", {})
-        if key not in plans:
+        plan = plans.pop(key, None)
+        if plan is None:
+            cap = self.plan_cache_bytes
+            if cap is not None:                     # make room BEFORE allocating the new plan's buffers
+                while plans and sum(p.nbytes for p in plans.values()) > max(cap - self._plan_bytes_hint(plans), 0):
+                    plans.pop(next(iter(plans)))
             plan = self.build_plan(B, H, W, device, dt, u8=u8)
-            if self.autotune:
-                plan.autotune()
-            if self.use_graph:
-                plan.capture()
-            plans[key] = plan
-        return plans[key]
+            if device.type == "cuda":
+                if self.autotune:
+                    plan.autotune()
+                if self.use_graph:
+                    plan.capture()
+            if cap is not None:
+                while plans and sum(p.nbytes for p in plans.values()) + plan.nbytes > cap:
+                    plans.pop(next(iter(plans)))
+        plans[key] = plan                           # (re-)insert as most recently used
+        return plan
+
+    @staticmethod
+    def _plan_bytes_hint(plans):
+        """Expected size of the next plan: that of the largest cached one (shapes of one run are of one scale)."""
+        return max((p.nbytes for p in plans.values()), default=0)

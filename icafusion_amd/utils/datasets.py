@@ -2,13 +2,18 @@
 
 Same entry points and return conventions as the reference's utils/datasets.py for the inference / validation paths:
 `letterbox` (:1404-1444 — note the reference's `auto` / `scaleFill` branches are commented out, so every image is padded
-to the full `new_shape`), `LoadImages` (:172-241, image files only) and a paired RGB+IR validation set that yields the
-6-channel uint8 batches `test.py:115-123` consumes (a compact stand-in for LoadMultiModalImagesAndLabels :690-1024:
-square letterbox, no augmentation, no rectangular batching, no label cache).
+to the full `new_shape`), `LoadImages` (:172-241, image files only) and the paired RGB+IR validation set that yields the
+6-channel uint8 batches `test.py:115-123` consumes, following LoadMultiModalImagesAndLabels' evaluation protocol
+(:690-1024): longest side resized to `img_size` (:1116-1122), RECTANGULAR batches — images sorted by aspect ratio, one
+letterbox shape per batch, `ceil(shape * img_size / stride + pad) * stride` (:826-849; test.py:100 passes rect=True,
+pad=0.5, which makes KAIST's 512x640 frames 544x672 batches) — `scaleup=False`, labels re-normalised to the letterboxed
+image (:961-986), label files found by replacing the `visible` / `infrared` path component with `labels` (:391-401).
+Not carried over: augmentation / mosaic (training), the label cache file, image caching.
 
-Decoding goes through PIL, resizing is a half-pixel-centre bilinear filter evaluated in float32 and rounded to nearest:
-the same sampling geometry as cv2.INTER_LINEAR, which however evaluates it in 11-bit fixed point — results can differ
-from OpenCV's by one grey level.  Arrays are BGR HWC uint8 like cv2.imread's, so downstream code is unchanged."""
+Decoding goes through PIL.  Up-sampling is a half-pixel-centre bilinear filter evaluated in float32 and rounded to nearest
+(cv2.INTER_LINEAR's geometry; OpenCV evaluates it in 11-bit fixed point, so results can differ by one grey level);
+down-sampling is the exact pixel-area average (cv2.INTER_AREA's definition, float32).  Arrays are BGR HWC uint8 like
+cv2.imread's, so downstream code is unchanged."""
 import glob
 import os
 from pathlib import Path
@@ -48,6 +53,29 @@ def resize_bilinear(img, new_wh):
     top = f[y0][:, x0] * (1 - fx)[None, :, None] + f[y0][:, x1] * fx[None, :, None]
     bot = f[y1][:, x0] * (1 - fx)[None, :, None] + f[y1][:, x1] * fx[None, :, None]
     out = top * (1 - fy)[:, None, None] + bot * fy[:, None, None]
+    return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
+
+
+def resize_area(img, new_wh):
+    """(H, W, C) uint8 -> (new_h, new_w, C) uint8 by pixel-area averaging (the definition of cv2.INTER_AREA for
+    down-scaling, which load_image_rgb_ir uses when r < 1: utils/datasets.py:1119-1122): output pixel j covers the input
+    interval [j * s, (j + 1) * s), s = n_in / n_out, and averages the input pixels weighted by their overlap with it."""
+    h, w = img.shape[:2]
+    nw, nh = new_wh
+    if (nw, nh) == (w, h):
+        return img
+
+    def weights(n_in, n_out):
+        s = n_in / n_out
+        lo = np.arange(n_out, dtype=np.float64) * s
+        hi = lo + s
+        px = np.arange(n_in, dtype=np.float64)
+        ov = np.clip(np.minimum(hi[:, None], px[None] + 1.0) - np.maximum(lo[:, None], px[None]), 0.0, None)
+        return (ov / s).astype(np.float32)                       # (n_out, n_in), rows sum to 1
+    wy, wx = weights(h, nh), weights(w, nw)
+    f = img.astype(np.float32)
+    out = np.einsum("oh,hwc->owc", wy, f, optimize=True)
+    out = np.einsum("pw,owc->opc", wx, out, optimize=True)
     return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
 
 
@@ -116,47 +144,127 @@ class LoadImages:
 
 
 def img2label_paths(img_paths):
-    """.../images/x.jpg -> .../labels/x.txt (reference utils/datasets.py:84-87)."""
-    sa, sb = os.sep + "images" + os.sep, os.sep + "labels" + os.sep
-    return [sb.join(p.rsplit(sa, 1)).rsplit(".", 1)[0] + ".txt" for p in img_paths]
+    """.../visible/<split>/x.jpg or .../infrared/<split>/x.jpg -> .../labels/<split>/x.txt: the first `visible` (else
+    `infrared`) in the path becomes `labels`, the extension `txt` (reference utils/datasets.py:391-401).  The shipped
+    data/multispectral/*.yaml files use exactly this layout."""
+    out = []
+    for x in img_paths:
+        parts = x.split("/")
+        if "visible" in parts:
+            sa = "visible"
+        elif "infrared" in parts:
+            sa = "infrared"
+        else:
+            raise ValueError(f"{x}: paired datasets keep images under a 'visible' or 'infrared' directory and labels under "
+                             "'labels' (reference utils/datasets.py:391-401)")
+        out.append("txt".join(x.replace(sa, "labels", 1).rsplit(x.split(".")[-1], 1)))
+    return out
+
+
+def _image_files(path):
+    """Directory (recursive), glob, or a text file listing image paths ('./' = relative to the list) — :709-722."""
+    if isinstance(path, (list, tuple)):
+        return sorted(f for p in path for f in _image_files(p))
+    p = Path(path)
+    if p.is_dir():
+        files = glob.glob(str(p / "**" / "*.*"), recursive=True)
+    elif p.is_file() and p.suffix.lower()[1:] not in IMG_FORMATS:
+        parent = str(p.parent) + os.sep
+        with open(p) as f:
+            files = [ln.replace("./", parent) if ln.startswith("./") else ln for ln in f.read().strip().splitlines()]
+    else:
+        return _list_images(path)
+    return sorted(f for f in files if f.rsplit(".", 1)[-1].lower() in IMG_FORMATS)
+
+
+def _read_labels(path):
+    if not os.path.isfile(path):
+        return None
+    with open(path) as f:
+        rows = [ln.split() for ln in f.read().strip().splitlines() if ln.strip()]
+    lab = np.array(rows, np.float32).reshape(-1, 5) if rows else np.zeros((0, 5), np.float32)
+    if len(lab) and ((lab < 0).any() or (lab[:, 1:] > 1).any()):
+        raise ValueError(f"{path}: labels must be non-negative, normalised [cls cx cy w h] rows (reference :1049-1052)")
+    return lab
 
 
 class PairedValSet:
     """RGB + IR validation pairs with YOLO txt labels.  `__getitem__` -> (6xHxW uint8 tensor = cat(rgb, ir) as
     utils/datasets.py:1022-1024, labels (n, 6) [0, cls, cx, cy, w, h] normalised to the letterboxed image, rgb path,
-    ((h0, w0), ((ratio, ratio), (pad_w, pad_h))) for scale_coords)."""
+    ((h0, w0), ((h / h0, w / w0), (pad_w, pad_h))) for scale_coords)."""
 
-    def __init__(self, path_rgb, path_ir, img_size=640, label_paths=None):
-        self.rgb, self.ir = _list_images(path_rgb), _list_images(path_ir)
-        assert len(self.rgb) == len(self.ir) and self.rgb, f"{len(self.rgb)} RGB vs {len(self.ir)} IR images"
-        self.img_size = img_size
-        self.label_files = label_paths or img2label_paths(self.rgb)
+    def __init__(self, path_rgb, path_ir, img_size=640, batch_size=16, rect=False, pad=0.0, stride=32, single_cls=False,
+                 label_paths=None):
+        self.rgb, self.ir = _image_files(path_rgb), _image_files(path_ir)
+        if not self.rgb or len(self.rgb) != len(self.ir):
+            raise FileNotFoundError(f"{len(self.rgb)} RGB images under {path_rgb} vs {len(self.ir)} IR images under {path_ir}")
+        self.img_size, self.rect, self.stride = img_size, bool(rect), stride
+        self.label_files = list(label_paths) if label_paths is not None else img2label_paths(self.rgb)
+        labels = [_read_labels(f) for f in self.label_files]
+        self.n_missing = sum(l is None for l in labels)
+        if self.n_missing == len(labels):
+            # the reference prints "No labels found" and asserts (:781) unless augmenting: validation without a single label
+            # file means the paths are wrong, and every metric would silently come out as zero
+            raise FileNotFoundError(f"no label file found for any of {len(labels)} images, e.g. {self.label_files[0]}")
+        self.labels = [np.zeros((0, 5), np.float32) if l is None else l for l in labels]
+        if single_cls:
+            for l in self.labels:
+                l[:, 0] = 0
+        n = len(self.rgb)
+        self.batch = np.floor(np.arange(n) / batch_size).astype(np.int64)      # batch index of each image (:800-803)
+        self.batch_shapes = None
+        if self.rect:
+            from PIL import Image
+            shapes = []
+            for f in self.rgb:
+                with Image.open(f) as im:
+                    shapes.append(im.size)                                    # (w, h), header only
+            s = np.array(shapes, dtype=np.float64)
+            ar = s[:, 1] / s[:, 0]                                            # aspect ratio h / w
+            order = ar.argsort()
+            self.rgb = [self.rgb[i] for i in order]
+            self.ir = [self.ir[i] for i in order]                             # pairs share their shape (:851-859 sorts IR by its own)
+            self.label_files = [self.label_files[i] for i in order]
+            self.labels = [self.labels[i] for i in order]
+            ar = ar[order]
+            nb = int(self.batch[-1]) + 1
+            bshapes = [[1.0, 1.0]] * nb
+            for i in range(nb):
+                ari = ar[self.batch == i]
+                mini, maxi = ari.min(), ari.max()
+                if maxi < 1:
+                    bshapes[i] = [maxi, 1.0]
+                elif mini > 1:
+                    bshapes[i] = [1.0, 1.0 / mini]
+            self.batch_shapes = np.ceil(np.array(bshapes) * img_size / stride + pad).astype(np.int64) * stride     # (h, w)
 
     def __len__(self):
         return len(self.rgb)
 
     def __getitem__(self, i):
-        a0, b0 = imread_bgr(self.rgb[i]), imread_bgr(self.ir[i])
-        a, ratio, pad = letterbox(a0, self.img_size)
-        b = letterbox(b0, self.img_size)[0]
-        h0, w0 = a0.shape[:2]
-        lab = np.zeros((0, 5), np.float32)
-        if os.path.isfile(self.label_files[i]):
-            with open(self.label_files[i]) as f:
-                rows = [ln.split() for ln in f.read().strip().splitlines() if ln.strip()]
-            if rows:
-                lab = np.array(rows, np.float32).reshape(-1, 5)
+        a, b = imread_bgr(self.rgb[i]), imread_bgr(self.ir[i])
+        h0, w0 = a.shape[:2]
+        r = self.img_size / max(h0, w0)                 # longest side -> img_size (load_image_rgb_ir, :1116-1122)
+        if r != 1:
+            resize = resize_area if r < 1 else resize_bilinear
+            a, b = resize(a, (int(w0 * r), int(h0 * r))), resize(b, (int(w0 * r), int(h0 * r)))
+        h, w = a.shape[:2]
+        shape = tuple(int(v) for v in self.batch_shapes[self.batch[i]]) if self.rect else self.img_size
+        a, ratio, pad = letterbox(a, shape, auto=False, scaleup=False)
+        b = letterbox(b, shape, auto=False, scaleup=False)[0]
+        lab = self.labels[i]
         out = np.zeros((len(lab), 6), np.float32)
-        if len(lab):                    # normalised xywh of the original image -> normalised xywh of the letterboxed one
+        if len(lab):        # normalised xywh of the file -> pixel xyxy of the letterboxed image -> normalised xywh of it (:961-986)
             H, W = a.shape[:2]
+            gw, gh = ratio[0] * w, ratio[1] * h
+            x1, y1 = gw * (lab[:, 1] - lab[:, 3] / 2) + pad[0], gh * (lab[:, 2] - lab[:, 4] / 2) + pad[1]
+            x2, y2 = gw * (lab[:, 1] + lab[:, 3] / 2) + pad[0], gh * (lab[:, 2] + lab[:, 4] / 2) + pad[1]
             out[:, 1] = lab[:, 0]
-            out[:, 2] = (lab[:, 1] * w0 * ratio[0] + pad[0]) / W
-            out[:, 3] = (lab[:, 2] * h0 * ratio[1] + pad[1]) / H
-            out[:, 4] = lab[:, 3] * w0 * ratio[0] / W
-            out[:, 5] = lab[:, 4] * h0 * ratio[1] / H
+            out[:, 2], out[:, 3] = (x1 + x2) / 2 / W, (y1 + y2) / 2 / H
+            out[:, 4], out[:, 5] = (x2 - x1) / W, (y2 - y1) / H
         chw = lambda x: np.ascontiguousarray(x[:, :, ::-1].transpose(2, 0, 1))      # noqa: E731
         img6 = torch.from_numpy(np.concatenate((chw(a), chw(b)), 0))
-        return img6, torch.from_numpy(out), self.rgb[i], ((h0, w0), (ratio, pad))
+        return img6, torch.from_numpy(out), self.rgb[i], ((h0, w0), ((h / h0, w / w0), pad))
 
     @staticmethod
     def collate_fn(batch):
@@ -166,9 +274,15 @@ class PairedValSet:
         return torch.stack(img, 0), torch.cat(label, 0), path, shapes
 
 
-def create_dataloader_rgb_ir(path_rgb, path_ir, imgsz, batch_size, *_, **kw):
-    """Reference signature (utils/datasets.py:102-129) reduced to what validation needs: -> (loader, dataset)."""
-    ds = PairedValSet(path_rgb, path_ir, imgsz)
-    loader = torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=False, num_workers=int(kw.get("workers", 0)),
+def create_dataloader_rgb_ir(path1, path2, imgsz, batch_size, stride=32, opt=None, hyp=None, augment=False, cache=False, pad=0.0,
+                             rect=False, rank=-1, world_size=1, workers=0, image_weights=False, quad=False, prefix="", sampler=None):
+    """Reference signature (utils/datasets.py:102-129) -> (loader, dataset); test.py:100 calls it with rect=True, pad=0.5.
+    augment / hyp / image_weights / quad belong to training and must be off."""
+    if augment or image_weights or quad:
+        raise NotImplementedError("training-time loading (augment / image_weights / quad) is outside the inference hot path")
+    ds = PairedValSet(path1, path2, imgsz, batch_size, rect=rect, pad=pad, stride=int(stride),
+                      single_cls=bool(getattr(opt, "single_cls", False)))
+    batch_size = min(batch_size, len(ds))
+    loader = torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=False, num_workers=int(workers),
                                          collate_fn=PairedValSet.collate_fn)
     return loader, ds

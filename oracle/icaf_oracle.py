@@ -68,7 +68,9 @@ def build_layers(cfg):
             c2, p = sum(ch[x] for x in f), dict(dim=args[0])
         elif kind == "TransformerFusionBlock":
             c2 = ch[f[0]]                                                # yaml's first arg is ignored (:284-286)
-            p = dict(c=c2, va=args[1], ha=args[2], heads=8, loops=args[3] if len(args) > 3 else 1)
+            kw = args[-1] if isinstance(args[-1], dict) else {}         # this repo's optional {loops_num: n} (not in the reference)
+            pos = [a for a in args if not isinstance(a, dict)]
+            p = dict(c=c2, va=pos[1], ha=pos[2], heads=pos[3] if len(pos) > 3 else 8, loops=kw.get("loops_num", 1))
         elif kind == "NiNfusion":                                       # models/yolo_test.py:280-283
             c1 = sum(ch[x] for x in f)
             c2, p = c1 // 2, dict(k=args[0], s=args[1])

@@ -6,8 +6,11 @@ ap_per_class.  `test(...)` keeps the reference's return value ((mp, mr, map50, m
     python test.py --data data/multispectral/kaist.yaml --weights best.pt --batch-size 32 --img-size 640
     python test.py --data ... --cfg models/transformer/yolov5s_Transfusion_kaist.yaml      (synthetic weights: plumbing)
 
-Differences (all outside the metric): square letterbox instead of rectangular batches, no plots / wandb / json / MR
-evaluator (the reference's MR call site is disabled and returns zeros, test.py:260-285)."""
+Protocol as the reference's: rectangular batches with pad 0.5 (test.py:100 — KAIST's 512x640 frames become 544x672
+batches), conf 0.001 / IoU 0.5 multi-label NMS, boxes mapped back to native image space before matching.  Every distinct
+batch shape compiles its own execution plan (hipGraph); Model keeps them in a byte-capped LRU (Model.plan_cache_bytes).
+Not carried over (all outside the metric): plots / wandb / json / the MR evaluator (the reference's MR call site is disabled
+and returns zeros, test.py:260-285)."""
 import argparse
 import time
 
@@ -45,7 +48,8 @@ def test(data, weights=None, batch_size=32, imgsz=640, conf_thres=0.001, iou_thr
         model.use_graph = True
     dev = next(model.parameters()).device
     if dataloader is None:
-        dataloader = create_dataloader_rgb_ir(data["val_rgb"], data["val_ir"], imgsz, batch_size)[0]
+        gs = int(max(float(model.stride.max()), 32))                      # grid size = max stride (test.py:68)
+        dataloader = create_dataloader_rgb_ir(data["val_rgb"], data["val_ir"], imgsz, batch_size, gs, None, pad=0.5, rect=True)[0]
     iouv = np.linspace(0.5, 0.95, 10)
     names = data.get("names", [str(i) for i in range(nc)])
     stats, seen, t_inf, t_nms = [], 0, 0.0, 0.0

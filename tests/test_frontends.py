@@ -15,20 +15,72 @@ from oracle import icaf_oracle as oracle
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def make_dataset(root, n=4, size=(96, 128), nc=1, seed=0):
-    """root/visible/images/*.png, root/infrared/images/*.png, root/visible/labels/*.txt (YOLO: cls cx cy w h)."""
+def make_dataset(root, n=4, size=(96, 128), nc=1, seed=0, mixed=True):
+    """The layout of the shipped data/multispectral/*.yaml files: root/visible/test/*.png, root/infrared/test/*.png and
+    root/labels/test/*.txt (YOLO: cls cx cy w h) — labels are found by the reference's visible -> labels rule."""
     g = np.random.default_rng(seed)
-    for mod in ("visible", "infrared"):
-        os.makedirs(os.path.join(root, mod, "images"), exist_ok=True)
-    os.makedirs(os.path.join(root, "visible", "labels"), exist_ok=True)
+    for mod in ("visible", "infrared", "labels"):
+        os.makedirs(os.path.join(root, mod, "test"), exist_ok=True)
     for i in range(n):
-        h, w = size if i % 2 == 0 else (size[1], size[0])
+        h, w = size if (i % 2 == 0 or not mixed) else (size[1], size[0])
         for mod in ("visible", "infrared"):
-            D.imwrite_bgr(os.path.join(root, mod, "images", f"im{i:03d}.png"), g.integers(0, 256, (h, w, 3), dtype=np.uint8))
+            D.imwrite_bgr(os.path.join(root, mod, "test", f"im{i:03d}.png"), g.integers(0, 256, (h, w, 3), dtype=np.uint8))
         k = int(g.integers(1, 5))
         lab = np.concatenate((g.integers(0, nc, (k, 1)).astype(np.float32), g.uniform(0.2, 0.8, (k, 2)), g.uniform(0.1, 0.3, (k, 2))), 1)
-        np.savetxt(os.path.join(root, "visible", "labels", f"im{i:03d}.txt"), lab, fmt="%g")
-    return os.path.join(root, "visible", "images"), os.path.join(root, "infrared", "images")
+        np.savetxt(os.path.join(root, "labels", "test", f"im{i:03d}.txt"), lab, fmt="%g")
+    return os.path.join(root, "visible", "test"), os.path.join(root, "infrared", "test")
+
+
+def test_img2label_paths_follow_the_reference_rule():
+    """utils/datasets.py:391-401: the first 'visible' (else 'infrared') becomes 'labels', the extension 'txt'."""
+    got = D.img2label_paths(["/data/kaist/visible/test/set06_V000_I00019.jpg", "/data/kaist/infrared/train/a.b.png",
+                             "/d/visible/x/visible/y.jpeg"])
+    assert got == ["/data/kaist/labels/test/set06_V000_I00019.txt", "/data/kaist/labels/train/a.b.txt", "/d/labels/x/visible/y.txt"]
+    with pytest.raises(ValueError, match="visible"):
+        D.img2label_paths(["/data/kaist/images/test/x.jpg"])
+
+
+def test_missing_labels_fail_loudly(tmp_path):
+    rgb_dir, ir_dir = make_dataset(str(tmp_path), n=2)
+    os.rename(os.path.join(str(tmp_path), "labels"), os.path.join(str(tmp_path), "annotations"))
+    with pytest.raises(FileNotFoundError, match="no label file"):
+        D.create_dataloader_rgb_ir(rgb_dir, ir_dir, 128, 2)
+
+
+def test_rectangular_batches_follow_the_reference_protocol(tmp_path):
+    """test.py:100 -> rect=True, pad=0.5: images sorted by h / w, one shape per batch = ceil(shape * img_size / stride + pad)
+    * stride (utils/datasets.py:826-849); KAIST's 512x640 frames at img_size 640 become 544x672 batches."""
+    rgb_dir, ir_dir = make_dataset(str(tmp_path / "kaist"), n=3, size=(512, 640), mixed=False)
+    loader, ds = D.create_dataloader_rgb_ir(rgb_dir, ir_dir, 640, 2, 32, None, pad=0.5, rect=True)
+    assert ds.batch_shapes.tolist() == [[544, 672], [544, 672]]
+    shapes_seen = []
+    for img6, targets, paths, shapes in loader:
+        shapes_seen.append(tuple(img6.shape))
+        (h0, w0), ((rh, rw), (pw, ph)) = shapes[0]
+        assert (h0, w0, rh, rw, pw, ph) == (512, 640, 1.0, 1.0, 16.0, 16.0)
+        assert (img6[0, :, :16] == 114).all() and (img6[0, :, :, :16] == 114).all() and (img6[0, :, -16:] == 114).all()
+    assert shapes_seen == [(2, 6, 544, 672), (1, 6, 544, 672)]          # ragged last batch
+    # mixed orientations: portrait images sort behind landscape ones and each batch takes the shape of its own members
+    rgb_dir, ir_dir = make_dataset(str(tmp_path / "mixed"), n=4, size=(96, 128), mixed=True)
+    loader, ds = D.create_dataloader_rgb_ir(rgb_dir, ir_dir, 128, 2, 32, None, pad=0.5, rect=True)
+    assert [os.path.basename(f) for f in ds.rgb] == ["im000.png", "im002.png", "im001.png", "im003.png"]
+    assert ds.batch_shapes.tolist() == [[128, 160], [160, 128]]             # ceil([0.75, 1] * 128 / 32 + 0.5) * 32
+    for (img6, targets, paths, shapes), want in zip(loader, [(2, 6, 128, 160), (2, 6, 160, 128)]):
+        assert tuple(img6.shape) == want
+    # a down-scaled set: longest side -> img_size by area averaging, no up-scaling afterwards (scaleup=False)
+    loader, ds = D.create_dataloader_rgb_ir(rgb_dir, ir_dir, 64, 4, 32, None, pad=0.0, rect=False)
+    img6, targets, paths, shapes = next(iter(loader))
+    assert tuple(img6.shape) == (4, 6, 64, 64) and shapes[0][1][0] == (0.5, 0.5)
+
+
+def test_resize_area_is_the_exact_box_average():
+    a = np.random.default_rng(4).integers(0, 256, (8, 12, 3), dtype=np.uint8)
+    half = D.resize_area(a, (6, 4))
+    ref = a.reshape(4, 2, 6, 2, 3).astype(np.float32).mean((1, 3))
+    assert np.abs(half.astype(np.float32) - np.floor(ref + 0.5)).max() == 0
+    assert (D.resize_area(np.full((9, 7, 3), 77, np.uint8), (3, 4)) == 77).all()
+    frac = D.resize_area(np.arange(5, dtype=np.uint8).reshape(1, 5, 1) * 50, (2, 1))      # 5 -> 2 columns: 2.5 pixels each
+    assert frac.reshape(-1).tolist() == [int(np.floor((0 + 50 + 100 * 0.5) / 2.5 + 0.5)), int(np.floor((100 * 0.5 + 150 + 200) / 2.5 + 0.5))]
 
 
 @pytest.mark.parametrize("shape,new", [((512, 640), 640), ((480, 640), (544, 672)), ((100, 50), 64), ((30, 300), 128)])
@@ -76,7 +128,7 @@ def test_load_images_and_paired_set(tmp_path):
         box = xywh2xyxy(lab[:, 1:5] * torch.tensor([128, 128, 128, 128.0]))
         (h0, w0), pad = shapes[si]
         scale_coords((128, 128), box, (h0, w0), pad)
-        raw = np.loadtxt(os.path.join(str(tmp_path), "visible", "labels", os.path.basename(paths[si])[:-4] + ".txt"), ndmin=2)
+        raw = np.loadtxt(os.path.join(str(tmp_path), "labels", "test", os.path.basename(paths[si])[:-4] + ".txt"), ndmin=2)
         want = xywh2xyxy(torch.from_numpy(raw[:, 1:5]).float() * torch.tensor([w0, h0, w0, h0.__float__()]))
         want[:, [0, 2]] = want[:, [0, 2]].clamp(0, w0)
         want[:, [1, 3]] = want[:, [1, 3]].clamp(0, h0)
@@ -123,7 +175,7 @@ def test_detect_twostream_and_test_py_end_to_end(tmp_path):
     model.load_state_dict(sd)
     (mp, mr, map50, map_, *_), maps, _ = val.test(data, batch_size=2, imgsz=320, model=model.to("cuda:0"))
     # oracle detections on the same batches through the same statistics
-    loader, _ = D.create_dataloader_rgb_ir(rgb_dir, ir_dir, 320, 2)
+    loader, _ = D.create_dataloader_rgb_ir(rgb_dir, ir_dir, 320, 2, 32, None, pad=0.5, rect=True)      # test.py:100
     om = oracle.OracleModel(cfg, sd)
     iouv = np.linspace(0.5, 0.95, 10)
     tp, conf, pcls, tcls = [], [], [], []
@@ -131,11 +183,12 @@ def test_detect_twostream_and_test_py_end_to_end(tmp_path):
         f = img6.float() / 255.0
         z = om.forward(f[:, :3].contiguous(), f[:, 3:].contiguous())[0].numpy()
         dets = oracle.non_max_suppression(z, 0.001, 0.5, multi_label=True)
-        targets[:, 2:] *= 320
+        H, W = img6.shape[2:]                                       # rectangular batch shape
+        targets[:, 2:] *= torch.tensor([W, H, W, H])
         for si, d in enumerate(dets):
             lab = targets[targets[:, 0] == si, 1:]
-            dn = torch.from_numpy(d.copy()); scale_coords((320, 320), dn[:, :4], shapes[si][0], shapes[si][1])
-            tb = xywh2xyxy(lab[:, 1:5]); scale_coords((320, 320), tb, shapes[si][0], shapes[si][1])
+            dn = torch.from_numpy(d.copy()); scale_coords((H, W), dn[:, :4], shapes[si][0], shapes[si][1])
+            tb = xywh2xyxy(lab[:, 1:5]); scale_coords((H, W), tb, shapes[si][0], shapes[si][1])
             tp.append(oracle.match_predictions(dn.numpy(), torch.cat((lab[:, :1], tb), 1).numpy(), iouv))
             conf.append(d[:, 4]); pcls.append(d[:, 5]); tcls.append(lab[:, 0].numpy())
     ap, _ = oracle.ap_per_class(np.concatenate(tp), np.concatenate(conf), np.concatenate(pcls), np.concatenate(tcls))

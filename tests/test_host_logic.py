@@ -70,6 +70,20 @@ def test_loops_argument_and_unsupported_modules():
     cfg = load_cfg("yolov5s_Transfusion_kaist_loops3.yaml")
     m = Model(cfg)
     assert all(m.model[i].crosstransformer[0].loops == 3 for i in (20, 21, 22))
+    assert all(m.model[i].crosstransformer[0].crossatt.h == 8 for i in (20, 21, 22))
+    # positional arguments keep the reference's meaning (models/yolo_test.py:284-286: args = [c2, *args[1:]]): a 4th positional is
+    # `h`, the number of heads — NOT the iteration count
+    cfg4 = load_cfg("yolov5s_Transfusion_kaist.yaml")
+    cfg4["backbone"][20][3] = [256, 20, 20, 4]
+    cfg4["backbone"][21][3] = [512, 16, 16, 4, 2, {"loops_num": 2}]
+    m4 = Model(cfg4)
+    assert m4.model[20].crosstransformer[0].crossatt.h == 4 and m4.model[20].crosstransformer[0].loops == 1
+    assert m4.model[21].crosstransformer[0].crossatt.h == 4 and m4.model[21].crosstransformer[0].loops == 2
+    assert m4.model[21].crosstransformer[0].mlp_vis[0].out_features == 2 * 256            # block_exp = 2
+    with pytest.raises(ValueError, match="unknown yaml keyword"):
+        bad_kw = load_cfg("yolov5s_Transfusion_kaist.yaml")
+        bad_kw["backbone"][20][3] = [256, 20, 20, {"loops": 3}]
+        Model(bad_kw)
     bad = load_cfg("yolov5s_Transfusion_kaist.yaml")
     bad["backbone"][1] = [-1, 1, "GhostConv", [128, 3, 2]]
     with pytest.raises(NotImplementedError):
@@ -137,3 +151,24 @@ def test_pmc_summary_kernel_names_match_bench_names():
     }
     for raw, want in cases.items():
         assert mod.short(raw) == want, raw
+
+
+def test_plan_cache_is_a_byte_capped_lru():
+    """Model.plan_for keeps plans in least-recently-used order under `plan_cache_bytes` (a rectangular-batch validation run
+    meets many (B, H, W); each plan pins all of its intermediates).  CPU: plans build without a GPU."""
+    m = Model(load_cfg("yolov5n_Transfusion_kaist.yaml")).eval()
+    shapes = [(1, 320, 320), (1, 320, 352), (1, 352, 320), (2, 320, 320), (1, 384, 320), (1, 320, 384)]
+    one = m.plan_for(*shapes[0], device="cpu", dtype=torch.bfloat16)
+    assert one.nbytes > 0 and m.plan_for(*shapes[0], device="cpu", dtype=torch.bfloat16) is one           # cache hit
+    m.plan_cache_bytes = int(3.5 * one.nbytes)
+    for s in shapes:
+        m.plan_for(*s, device="cpu", dtype=torch.bfloat16)
+        total = sum(p.nbytes for p in m._plans.values())
+        assert total <= m.plan_cache_bytes and len(m._plans) <= 3
+    keys = [k[:3] for k in m._plans]
+    assert keys[-1] == shapes[-1] and shapes[0] not in keys                                                # oldest evicted, newest kept
+    m.plan_for(*keys[0], device="cpu", dtype=torch.bfloat16)                                               # touch the oldest survivor ...
+    m.plan_for(1, 416, 320, device="cpu", dtype=torch.bfloat16)
+    assert keys[0] in [k[:3] for k in m._plans] and keys[1] not in [k[:3] for k in m._plans]               # ... so the next one goes
+    m.plan_cache_bytes = 1                                                                                 # the newest plan always stays
+    assert m.plan_for(1, 448, 320, device="cpu", dtype=torch.bfloat16) is not None and len(m._plans) == 1
