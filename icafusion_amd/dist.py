@@ -47,10 +47,16 @@ def unpack_detections(block, max_det):
     return det, count
 
 
-def gather_detections(det, count, out=None):
+def gather_detections(det, count, out=None, force_collective=False):
     """All-gather every rank's detections (equal B_local on all ranks).  Returns (det_all, count_all) on every rank,
-    ordered by rank, i.e. in global batch order for a contiguous shard."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    ordered by rank, i.e. in global batch order for a contiguous shard.  With one rank nothing needs exchanging and the
+    inputs are returned — unless force_collective is set, which sends the block through the collective anyway (a
+    1-GPU box can then exercise the RCCL call, its stream ordering and the gathered buffer: tests/test_gpu_model.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if force_collective:
+            raise RuntimeError("gather_detections(force_collective=True) needs an initialised process group")
+        return det, count
+    if dist.get_world_size() == 1 and not force_collective:
         return det, count
     world = dist.get_world_size()
     block = pack_detections(det, count)

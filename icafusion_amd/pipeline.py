@@ -8,19 +8,23 @@ image (32 of 256 CUs at batch 32), so here batch i's NMS runs concurrently with 
     nms stream     :              wait snapshot(i) -> candidates / sort / greedy (i) [-> all_gather(i)] -> ...
 
 `z` is snapshotted into one of two staging buffers because the plan's output buffer is overwritten by the next
-replay; events order snapshot -> NMS -> reuse.  Results of step i are valid after `wait(i)` / `synchronize()`.
+replay; events order snapshot -> NMS -> reuse.  Each of the two slots also owns its NMS runner (workspace + det / count /
+keep output buffers) and its gathered block, so the tensors step n returned stay untouched until step n + 2 reuses the
+slot — and two pipelines of the same shape never share buffers.  Results of step i are valid after `synchronize()`.
 PyTorch streams / events are used as plumbing only; every kernel on both streams is ours (plus RCCL).
 """
 import torch
 
 from . import dist as D
+from . import ops
 from .utils.general import nms_device
 
 
 class DetectionPipeline:
     def __init__(self, model, batch, height, width, device, conf_thres=0.25, iou_thres=0.45, classes=None,
-                 agnostic=False, multi_label=False, max_det=300, world=1, overlap=True):
+                 agnostic=False, multi_label=False, max_det=300, world=1, overlap=True, force_gather=False):
         self.model, self.device, self.world = model, torch.device(device), world
+        self.gather = world > 1 or bool(force_gather)       # force_gather: run the all-gather even with one rank (hardware test of the RCCL path)
         self.nms_args = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic,
                              multi_label=multi_label, max_det=max_det)
         model.static_outputs = True
@@ -32,8 +36,12 @@ class DetectionPipeline:
         self.zbuf = [torch.empty_like(self.z) for _ in range(2)] if overlap else [self.z]
         self.snap_done = [torch.cuda.Event() for _ in range(2)]
         self.nms_done = [torch.cuda.Event() for _ in range(2)]
-        self.gathered = (torch.empty((world * batch, max_det * 6 + 1), dtype=torch.float32, device=self.device)
-                         if world > 1 else None)
+        nslots = 2 if overlap else 1
+        rows, no = self.z.shape[1], self.z.shape[2]
+        ml = bool(multi_label) and no - 5 > 1
+        self.runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det) for _ in range(nslots)]
+        self.gathered = [torch.empty((world * batch, max_det * 6 + 1), dtype=torch.float32, device=self.device)
+                         for _ in range(nslots)] if self.gather else None
         self.n = 0
         self.last = None
 
@@ -55,11 +63,11 @@ class DetectionPipeline:
                 self.zbuf[i].copy_(self.z, non_blocking=True)
             self.snap_done[i].record(fs)
             ns.wait_event(self.snap_done[i])
-        det, count, keep = nms_device(self.zbuf[i], stream_ptr=ns.cuda_stream, **self.nms_args)
+        det, count, keep = nms_device(self.zbuf[i], stream_ptr=ns.cuda_stream, runner=self.runners[i], **self.nms_args)
         out = (det, count)
-        if self.world > 1:
+        if self.gather:
             with torch.cuda.stream(ns):
-                out = D.gather_detections(det, count, out=self.gathered)
+                out = D.gather_detections(det, count, out=self.gathered[i], force_collective=True)
         if self.overlap:
             self.nms_done[i].record(ns)
         self.n += 1

@@ -8,7 +8,8 @@ import torch
 
 from .. import ops
 
-_RUNNERS = {}
+_RUNNERS = {}          # small LRU of NmsRunners for the stand-alone entry points (pipelines own theirs)
+_MAX_RUNNERS = 4
 
 
 def make_divisible(x, divisor):
@@ -66,8 +67,11 @@ def box_iou(box1, box2):
 
 
 def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-               max_det=300, max_nms=30000, max_wh=4096.0, stream_ptr=None):
-    """Device-resident NMS: returns (det (B,max_det,6), count (B,), keep_idx (B,max_det)) without any host sync."""
+               max_det=300, max_nms=30000, max_wh=4096.0, stream_ptr=None, runner=None):
+    """Device-resident NMS: returns (det (B,max_det,6), count (B,), keep_idx (B,max_det)) without any host sync.
+    The three tensors are the runner's STATIC output buffers: with the default (shared, per-shape) runner they are
+    overwritten by the next call of the same shape — consume or clone them first, or pass an own `runner`
+    (ops.NmsRunner) as DetectionPipeline does for each of its two in-flight slots."""
     if not prediction.is_cuda:
         raise RuntimeError("non_max_suppression runs on the MI355X only (no CPU fallback; see oracle/ for the "
                            "CPU reference used by the tests)")
@@ -75,10 +79,17 @@ def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     B, rows, no = pred.shape
     nc = no - 5
     ml = bool(multi_label) and nc > 1
-    key = (B, rows, nc, ml, max_det, pred.device)
-    if key not in _RUNNERS:
-        _RUNNERS[key] = ops.NmsRunner(B, rows, nc, pred.device, ml, max_det)
-    return _RUNNERS[key].launch(pred, conf_thres, iou_thres, agnostic, classes, max_nms, max_wh, stream_ptr)
+    if runner is None:
+        key = (B, rows, nc, ml, max_det, pred.device)
+        runner = _RUNNERS.pop(key, None)
+        if runner is None:
+            while len(_RUNNERS) >= _MAX_RUNNERS:          # rectangular validation batches meet many (B, rows): bound the workspaces
+                _RUNNERS.pop(next(iter(_RUNNERS)))
+            runner = ops.NmsRunner(B, rows, nc, pred.device, ml, max_det)
+        _RUNNERS[key] = runner
+    elif (runner.B, runner.rows, runner.nc, runner.multi_label, runner.max_det) != (B, rows, nc, ml, max_det):
+        raise ValueError("nms_device: the runner was built for another (B, rows, nc, multi_label, max_det)")
+    return runner.launch(pred, conf_thres, iou_thres, agnostic, classes, max_nms, max_wh, stream_ptr)
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,

@@ -92,15 +92,15 @@ def build_layers(cfg):
 # --------------------------------------------------------------------------------------------------------------
 def conv_bn_silu(x, sd, pre, k, s, p, act=True):
     """models/common.py:48-60 (Conv = SiLU(BN(Conv2d no-bias))), BN in eval mode."""
+    if pre + ".bn.weight" not in sd:          # fused checkpoint (utils/torch_utils.py:182-202): Conv.fuseforward = act(conv(x)), one op
+        y = F.conv2d(x, sd[pre + ".conv.weight"], sd[pre + ".conv.bias"], s, p)
+        return F.silu(y) if act else y
     y = F.conv2d(x, sd[pre + ".conv.weight"], None, s, p)
-    if pre + ".bn.weight" in sd:
-        g, b = sd[pre + ".bn.weight"], sd[pre + ".bn.bias"]
-        mu, var = sd[pre + ".bn.running_mean"], sd[pre + ".bn.running_var"]
-        scale = g / torch.sqrt(var + BN_EPS)
-        y = (y - mu[None, :, None, None]) * scale[None, :, None, None] + b[None, :, None, None]
-    else:                                     # already-fused checkpoint (utils/torch_utils.py:182-202)
-        y = y + sd[pre + ".conv.bias"][None, :, None, None]
-    return y * torch.sigmoid(y) if act else y
+    g, b = sd[pre + ".bn.weight"], sd[pre + ".bn.bias"]
+    mu, var = sd[pre + ".bn.running_mean"], sd[pre + ".bn.running_var"]
+    scale = g / torch.sqrt(var + BN_EPS)
+    y = (y - mu[None, :, None, None]) * scale[None, :, None, None] + b[None, :, None, None]
+    return F.silu(y) if act else y
 
 
 def c3(x, sd, pre, n, shortcut):
@@ -147,6 +147,8 @@ def pooled_tokens(x, va, ha, w1, w2, pos):
 
 
 def layer_norm(x, w, b):
+    if x.dtype != torch.float32:              # 16-bit mode (OracleModel dtype=): what nn.LayerNorm itself does for a .half() model
+        return F.layer_norm(x, (x.shape[-1],), w, b, LN_EPS)
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
     return (x - mu) / torch.sqrt(var + LN_EPS) * w + b
@@ -157,6 +159,8 @@ def linear(x, sd, pre):
 
 
 def gelu_erf(x):
+    if x.dtype != torch.float32:
+        return F.gelu(x)
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
@@ -200,6 +204,8 @@ def bilinear_resize(t, out_h, out_w):
     """F.interpolate(mode='bilinear', align_corners=False) written out (models/common.py:831,837).
     src = (dst + 0.5) * in/out - 0.5 clamped at 0; neighbours clamped at the border."""
     _, _, h, w = t.shape
+    if t.dtype != torch.float32:
+        return F.interpolate(t, size=(out_h, out_w), mode="bilinear", align_corners=False)
 
     def axis(n_in, n_out):
         d = torch.arange(n_out, dtype=torch.float32)
@@ -243,8 +249,10 @@ def detect(feats, sd, pre, nc, anchors):
         gy, gx = torch.meshgrid(torch.arange(ny, dtype=torch.float32), torch.arange(nx, dtype=torch.float32),
                                 indexing="ij")
         grid = torch.stack((gx, gy), -1)[None, None]
-        anc = torch.tensor(anchors[l], dtype=torch.float32).reshape(1, na, 1, 1, 2)
-        xy = (s[..., 0:2] * 2.0 - 0.5 + grid) * STRIDES[l]
+        # 16-bit mode: `model.half()` casts the anchor_grid buffer too, the grid stays fp32 (models/yolo_test.py:69-70), and the
+        # decoded values are assigned back INTO the 16-bit tensor y (:57-60), i.e. rounded to the storage type
+        anc = torch.tensor(anchors[l], dtype=torch.float32).to(y.dtype).reshape(1, na, 1, 1, 2)
+        xy = ((s[..., 0:2] * 2.0 - 0.5 + grid) * STRIDES[l]).to(y.dtype)
         wh = (s[..., 2:4] * 2.0) ** 2 * anc
         z.append(torch.cat((xy, wh, s[..., 4:]), -1).reshape(b, -1, no))
         logits.append(y[..., 5:].reshape(b, -1, nc))
@@ -254,15 +262,21 @@ def detect(feats, sd, pre, nc, anchors):
 class OracleModel:
     """Functional interpreter of a *_Transfusion_* yaml (models/yolo_test.py:136-163 graph walk)."""
 
-    def __init__(self, cfg, state_dict, loops=None):
+    def __init__(self, cfg, state_dict, loops=None, dtype=torch.float32):
+        """dtype = torch.float16 / bfloat16 restates what the reference does with `model.half()` (detect_twostream.py:40,
+        test.py:73-75): every parameter AND buffer in the 16-bit type, every op evaluated by torch in that type (its CPU
+        kernels accumulate in fp32 and round each op's output).  Used to measure the reference's own 16-bit deviation from
+        its fp32 result on given weights / inputs — the yardstick for the HIP path's 16-bit tolerances."""
         self.cfg = cfg
-        self.sd = {k: v.detach().float() for k, v in state_dict.items()}
+        self.dtype = dtype
+        self.sd = {k: (v.detach().float().to(dtype) if v.is_floating_point() else v.detach()) for k, v in state_dict.items()}
         self.layers, self.ch = build_layers(cfg)
         self.loops = loops
 
     @torch.no_grad()
     def forward(self, rgb, ir, keep_layers=False):
         sd, outs = self.sd, []
+        rgb, ir = rgb.to(self.dtype), ir.to(self.dtype)
         x = rgb
         for (i, f, kind, p) in self.layers:
             pre = f"model.{i}"

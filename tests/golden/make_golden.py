@@ -181,9 +181,71 @@ def metrics_case(general, metrics, name):
     print(name, "ap50", r[5][:, 0])
 
 
+def match_case(general, name):
+    """Pin the TP-matching statement: the reference has it INLINE in its validation loop (test.py:196-230), so those source
+    lines are read from the reference tree at generation time, dedented and exec'ed on synthetic detections / labels with
+    the reference's own scale_coords / xywh2xyxy / box_iou in scope.  Nothing of the block is stored — only its outputs."""
+    import textwrap
+    with open(os.path.join(REF, "test.py")) as f:
+        lines = f.read().splitlines()
+    i0 = next(i for i, l in enumerate(lines) if "# Assign all predictions as incorrect" in l)
+    i1 = next(i for i, l in enumerate(lines) if i > i0 and "# Append statistics (correct, conf, pcls, tcls)" in l)
+    assert (i0 + 1, i1 + 1) == (196, 229), (i0, i1)                         # the block SURVEY.md / DESIGN.md cite as test.py:196-230
+    block = textwrap.dedent("\n".join(lines[i0:i1])).rstrip()
+    assert block.lstrip().startswith("# Assign all predictions as incorrect") and block.rstrip().endswith("break"), block
+    code = compile(block, "reference test.py:196-230", "exec")
+    g = np.random.default_rng(77)
+    iouv = torch.linspace(0.5, 0.95, 10)
+    rec, T = {}, 24
+    for t in range(T):
+        H, W = [(320, 320), (544, 672), (160, 128)][t % 3]                  # letterboxed batch shape
+        h0, w0 = [(300, 320), (512, 640), (150, 100)][t % 3]                # native image
+        gain = min(H / h0, W / w0)
+        shapes = [((h0, w0), ((gain, gain), ((W - w0 * gain) / 2, (H - h0 * gain) / 2)))]
+        m, n = int(g.integers(0, 7)), int(g.integers(0, 60))
+        if t == 0:
+            m, n = 0, 5
+        if t == 1:
+            m, n = 3, 0
+        cls = g.integers(0, 3, (m, 1)).astype(np.float32)
+        cxy = g.uniform(0.25, 0.75, (m, 2)) * [W, H]
+        wh = g.uniform(0.05, 0.3, (m, 2)) * [W, H]
+        labels = torch.from_numpy(np.concatenate((cls, cxy, wh), 1).astype(np.float32))          # [cls, x, y, w, h] letterboxed pixels
+        if m and n:
+            src = labels[g.integers(0, m, n)]
+            xyxy = general.xywh2xyxy(src[:, 1:5]) + torch.from_numpy(g.normal(0, 0.04, (n, 4)).astype(np.float32)) * src[:, [3, 4, 3, 4]]
+            pcls = torch.where(torch.from_numpy(g.random(n) < 0.8), src[:, 0], torch.from_numpy(g.integers(0, 3, n).astype(np.float32)))
+        else:
+            a = torch.from_numpy(g.uniform(0, 100, (n, 2)).astype(np.float32))
+            xyxy = torch.cat((a, a + 40), 1)
+            pcls = torch.from_numpy(g.integers(0, 3, n).astype(np.float32))
+        conf = torch.from_numpy(np.sort(g.random(n).astype(np.float32))[::-1].copy())              # NMS output order: descending conf
+        pred = torch.cat((xyxy, conf[:, None], pcls[:, None]), 1)
+        if n > 4:
+            pred[3, :4] = pred[2, :4]                                           # two detections with identical IoU to a label
+        img = torch.zeros(1, 6, H, W)
+        predn = pred.clone()
+        general.scale_coords(img[0].shape[1:], predn[:, :4], shapes[0][0], shapes[0][1])          # test.py:160-161
+        ns = dict(torch=torch, pred=pred, predn=predn, labels=labels, nl=len(labels), niou=10, iouv=iouv, device="cpu", img=img,
+                  si=0, shapes=shapes, plots=False, scale_coords=general.scale_coords, xywh2xyxy=general.xywh2xyxy,
+                  box_iou=general.box_iou, confusion_matrix=None)
+        exec(code, ns)
+        tbox = general.xywh2xyxy(labels[:, 1:5])
+        general.scale_coords(img[0].shape[1:], tbox, shapes[0][0], shapes[0][1])
+        rec[f"pred{t}"], rec[f"predn{t}"], rec[f"labels{t}"] = pred.numpy(), predn.numpy(), labels.numpy()
+        rec[f"tbox{t}"], rec[f"correct{t}"] = tbox.numpy(), ns["correct"].numpy()
+        rec[f"geom{t}"] = np.asarray([H, W, h0, w0, gain, shapes[0][1][1][0], shapes[0][1][1][1]], np.float64)
+    rec["n"], rec["iouv"] = np.asarray(T), iouv.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print(name, "TP flags per trial:", [int(rec[f"correct{t}"][:, 0].sum()) for t in range(T)])
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     yt, common, general, metrics = import_reference()
+    if "--match-only" in sys.argv:                    # TP matching of the validation loop (test.py:196-230), added in round 2
+        match_case(general, "match_predictions")
+        return
     if "--m-only" in sys.argv:                        # yolov5m widths (48 / 96 / 192 / 384 / 768: no powers of two), added later
         model_case(yt, "model_m_kaist_320_b1", "yolov5m_Transfusion_kaist.yaml", 1, 320, 320, seed=13)
         return
@@ -213,6 +275,7 @@ def main():
     model_case(yt, "model_n_ninfusion_flir_320_b2", "yolov5n_NiNfusion_FLIR.yaml", 2, 320, 320, seed=12)
     model_case(yt, "model_m_kaist_320_b1", "yolov5m_Transfusion_kaist.yaml", 1, 320, 320, seed=13)
     model_case(yt, "model_n_flir_352x320_b2", "yolov5n_Transfusion_FLIR.yaml", 2, 352, 320, seed=14)
+    match_case(general, "match_predictions")
 
 
 if __name__ == "__main__":

@@ -821,3 +821,34 @@ def test_match_predictions_equals_host_statement(seed, with_scale):
         np.testing.assert_array_equal(predn[b, :n], pn[:, :4])
         ref = host_match(pn, labels[b], iouv)
         np.testing.assert_array_equal(correct[b, :n], ref, err_msg=f"image {b}")
+
+
+def test_match_predictions_kernel_reproduces_the_reference_block():
+    """icaf_match_predictions fed the letterboxed NMS rows + scale parameters vs tests/golden/match_predictions.npz (the
+    reference's inline block test.py:196-230 exec'ed by make_golden.py): same native-space boxes, same TP flags."""
+    from helpers import load_golden
+    g = load_golden("match_predictions")
+    T, max_det = int(g["n"]), 300
+    iouv = g["iouv"].astype(np.float32)
+    det = np.zeros((T, max_det, 6), np.float32)
+    count = np.zeros(T, np.int32)
+    labs, off, scales = [], [0], []
+    for t in range(T):
+        pred, tbox, labels = g[f"pred{t}"], g[f"tbox{t}"], g[f"labels{t}"]
+        H, W, h0, w0, gain, pw, ph = g[f"geom{t}"]
+        count[t] = len(pred)
+        det[t, :len(pred)] = pred
+        labs.append(np.concatenate((labels[:, :1], tbox), 1).astype(np.float32) if len(labels) else np.zeros((0, 5), np.float32))
+        off.append(off[-1] + len(labels))
+        scales.append([gain, pw, ph, w0, h0])
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    predn = torch.zeros((T, max_det, 4), dtype=torch.float32, device=DEV)
+    correct = ops.match_predictions(dev(det), dev(count), dev(np.concatenate(labs, 0)), dev(np.array(off, np.int32)), dev(iouv),
+                                    scale=dev(np.array(scales, np.float32)), predn=predn)
+    torch.cuda.synchronize()
+    correct, predn = correct.cpu().numpy().astype(bool), predn.cpu().numpy()
+    for t in range(T):
+        n = count[t]
+        np.testing.assert_array_equal(predn[t, :n], g[f"predn{t}"][:, :4], err_msg=f"boxes, trial {t}")
+        if len(labs[t]):
+            np.testing.assert_array_equal(correct[t, :n], g[f"correct{t}"], err_msg=f"flags, trial {t}")

@@ -84,18 +84,21 @@ def test_fused_model_same_output():
     assert float((a - b).abs().max()) <= 1e-3
 
 
-@pytest.mark.parametrize("dtype,box_tol,conf_tol", [(torch.bfloat16, 12.0, 4e-2), (torch.float16, 1.5, 5e-3)])
-def test_low_precision_forward_tolerance(dtype, box_tol, conf_tol):
-    """bf16 / f16 throughput builds: stated tolerance vs the fp32 oracle (the reference itself moves by 2.3 px /
-    1.9e-3 in bf16 and 0.25 px / 2.3e-4 in fp16 on its own CPU path — BASELINE.md); mean error must be small."""
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_low_precision_forward_tolerance(dtype):
+    """bf16 / f16 throughput builds vs the reference's fp32 output (golden), bounded by the reference's OWN deviation in the same
+    16-bit type on the same weights and inputs (the oracle evaluated by torch in that type = `model.half()`): at most 1.5x its
+    maximum and mean errors — see tests/test_gpu_parity16.py for the full-size configurations and the rationale."""
     cfg, sd, m = build("yolov5s_Transfusion_kaist.yaml", seed=1, dtype=dtype)
     rgb, ir = synth_images(2, 320, 320, seed=1)
     ref = load_golden("model_s_kaist_320_b2")["z"]
+    ref16 = oracle.OracleModel(cfg, sd, dtype=dtype).forward(rgb, ir)[0].float().numpy()
     z = m(rgb.to(DEV), ir.to(DEV))[0].float().cpu().numpy()
     assert np.isfinite(z).all()
-    assert np.abs(z[..., :4] - ref[..., :4]).max() <= box_tol
-    assert np.abs(z[..., 4:] - ref[..., 4:]).max() <= conf_tol
-    assert np.abs(z[..., 4:] - ref[..., 4:]).mean() <= conf_tol / 8
+    for name, sl in (("box px", np.s_[..., :4]), ("score", np.s_[..., 4:])):
+        e_hip, e_ref = np.abs(z[sl] - ref[sl]), np.abs(ref16[sl] - ref[sl])
+        print(f"{dtype} {name}: HIP max {e_hip.max():.4g} mean {e_hip.mean():.4g} | reference-in-{dtype} max {e_ref.max():.4g} mean {e_ref.mean():.4g}")
+        assert e_hip.max() <= 1.5 * e_ref.max() and e_hip.mean() <= 1.5 * e_ref.mean()
 
 
 def test_forward_u8_equals_float_forward():

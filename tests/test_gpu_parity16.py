@@ -1,0 +1,57 @@
+"""16-bit parity on the configurations that are benchmarked (BASELINE.json configs 2-5 at their per-GPU shard sizes): a slice
+of every full-size bf16 / fp16 batch against the fp32 CPU oracle, with the tolerance DERIVED from the reference's own 16-bit
+deviation on the same weights and inputs (tools/parity16.py: the oracle evaluated by torch in the same 16-bit type, which is
+what `model.half()` does in detect_twostream.py:40 / test.py:73-75), plus the bf16 / fp16 mAP@50 delta through the same
+ap_per_class on 16 images at 640x640 (north_star: within 0.1).  Every measured number is printed and appended to
+gpurun_out/parity_16bit_tests.jsonl; profiles/parity_16bit.json is the committed copy of a full tools/parity16.py run.
+
+Why a multiple of the reference's deviation, and why 1.5: both pipelines keep activations in the 16-bit type between layers
+and accumulate in fp32, so both carry rounding noise of the same magnitude through ~40 layers; they differ in WHERE they round
+(fused launches keep some intermediates in fp32 / LDS; the reference rounds after every torch op and also decodes boxes in the
+16-bit type, where pixel coordinates near 640 have a 4 px (bf16) / 0.5 px (fp16) grid).  The HIP path is therefore expected
+BELOW the reference's own deviation; 1.5x leaves room for a different noise realisation in the maximum over 10^5-10^6 values.
+"""
+import json
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+import parity16                                     # noqa: E402
+
+FACTOR = 1.5
+
+
+def _record(rec):
+    print(json.dumps(rec))
+    try:
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(REPO, "gpurun_out", "parity_16bit_tests.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("name", list(parity16.CONFIGS))
+def test_full_size_16bit_slice_vs_fp32_oracle(name):
+    rec = parity16.measure(name)
+    _record(rec)
+    hip, ref = rec["hip16_vs_oracle_fp32"], rec["reference16_vs_oracle_fp32"]
+    for k in ("box_px_max", "box_px_mean", "score_max", "score_mean"):
+        assert hip[k] <= FACTOR * ref[k], f"{name}: {k} = {hip[k]:.4g} exceeds {FACTOR} x the reference's own 16-bit deviation {ref[k]:.4g}"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_16bit_map50_delta_vs_fp32_oracle(dtype):
+    """mAP@50 (percent) of the 16-bit HIP detections vs the fp32 oracle's, 16 images 640x640, conf 0.001 / IoU 0.5 multi-label NMS
+    as test.py: on random synthetic labels and on pseudo ground truth cut from the oracle's own strongest detections."""
+    rec = parity16.measure_map(dtype)
+    _record(rec)
+    assert rec["images"] >= 16 and rec["labels_pseudo_gt"] >= 16
+    assert rec["pseudo_gt"]["map50_oracle_fp32"] > 50.0, "pseudo ground truth must give a non-trivial mAP"
+    for tag in ("random_labels", "pseudo_gt"):
+        assert abs(rec[tag]["map50_delta"]) <= 0.1, f"{dtype} {tag}: mAP@50 {rec[tag]['map50_hip16']} vs {rec[tag]['map50_oracle_fp32']}"

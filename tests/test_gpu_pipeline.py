@@ -1,0 +1,127 @@
+"""The serving loop on the MI355X: DetectionPipeline (forward on one stream, NMS [+ detections all-gather] of the previous batch
+on a second one), the RCCL collective exercised with a one-rank process group, and the byte-capped LRU of execution plans."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import REPO, load_cfg                               # noqa: E402
+from icafusion_amd.models.yolo import Model                      # noqa: E402
+from icafusion_amd.pipeline import DetectionPipeline             # noqa: E402
+from icafusion_amd.synth import synth_images, synth_state_dict   # noqa: E402
+from icafusion_amd.utils.general import non_max_suppression      # noqa: E402
+
+DEV = "cuda:0"
+
+
+def build(yaml_name, dtype, seed=0):
+    m = Model(load_cfg(yaml_name)).eval()
+    m.load_state_dict(synth_state_dict(m, seed))
+    m = m.to(DEV)
+    m.compute_dtype = dtype
+    return m
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_pipeline_steps_equal_sequential_forward_plus_nms(overlap):
+    """Five different batches through the overlapped pipeline: every step's detections equal forward -> NMS run back to back,
+    and the tensors a step returned are still intact after the NEXT step was enqueued (each in-flight slot owns its buffers)."""
+    m = build("yolov5s_Transfusion_FLIR.yaml", torch.bfloat16)
+    m.use_graph = True
+    B, H, W = 4, 320, 384
+    pipe = DetectionPipeline(m, B, H, W, DEV, conf_thres=0.25, iou_thres=0.45, overlap=overlap)
+    batches = [synth_images(B, H, W, seed=40 + k) for k in range(5)]
+    got = []
+    for rgb, ir in batches:
+        pipe.inputs[0].copy_(rgb.to(DEV)); pipe.inputs[1].copy_(ir.to(DEV))
+        torch.cuda.current_stream().synchronize()
+        got.append(pipe.step()[:2])
+        if len(got) >= 2 and overlap:                        # step n-1's tensors must survive step n being enqueued
+            pipe.synchronize()
+            det, count = got[-2]
+            prev = [det[k, :n].clone() for k, n in enumerate(count.tolist())]
+            rgb0, ir0 = batches[len(got) - 2]
+            m.static_outputs = False
+            want = non_max_suppression(m(rgb0.to(DEV), ir0.to(DEV))[0], 0.25, 0.45)
+            m.static_outputs = True
+            assert all(torch.equal(a, b) for a, b in zip(prev, want))
+        if not overlap:
+            pipe.synchronize()
+            got[-1] = tuple(t.clone() for t in got[-1])
+    pipe.synchronize()
+    m.static_outputs = False
+    rgb, ir = batches[-1]
+    want = non_max_suppression(m(rgb.to(DEV), ir.to(DEV))[0], 0.25, 0.45)
+    det, count = got[-1]
+    assert sum(count.tolist()) > 0
+    assert all(torch.equal(det[k, :n], w) for (k, n), w in zip(enumerate(count.tolist()), want))
+
+
+_RCCL_SCRIPT = r'''
+import os, sys, torch, numpy as np
+sys.path.insert(0, {repo!r})
+import torch.distributed as dist
+from icafusion_amd import dist as D
+from icafusion_amd.models.yolo import Model
+from icafusion_amd.pipeline import DetectionPipeline
+from icafusion_amd.synth import synth_images, synth_state_dict
+import yaml
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="2" if False else "1", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)          # "nccl" IS RCCL on ROCm
+assert dist.get_backend() == "nccl"
+cfg = yaml.safe_load(open(os.path.join({repo!r}, "models", "transformer", "yolov5s_Transfusion_kaist.yaml")))
+m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 0)); m = m.to("cuda:0"); m.compute_dtype = torch.bfloat16; m.use_graph = True
+B, H, W = 4, 320, 320
+pipe = DetectionPipeline(m, B, H, W, "cuda:0", conf_thres=0.1, iou_thres=0.5, world=1, overlap=True, force_gather=True)
+outs = []
+for k in range(4):
+    rgb, ir = synth_images(B, H, W, seed=70 + k)
+    pipe.inputs[0].copy_(rgb.cuda()); pipe.inputs[1].copy_(ir.cuda()); torch.cuda.current_stream().synchronize()
+    outs.append(pipe.step())
+    pipe.synchronize()
+    det_all, count_all = outs[-1]
+    det, count, _ = pipe.runners[k & 1].det, pipe.runners[k & 1].count, None
+    assert det_all.shape == (B, 300, 6) and count_all.dtype == torch.int32
+    assert torch.equal(det_all, det) and torch.equal(count_all, count), "all-gather of one rank must return that rank's block"
+    assert int(count.sum()) > 0
+    assert det_all.data_ptr() == pipe.gathered[k & 1].data_ptr()            # the collective wrote the pipeline's gathered buffer
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_WORLD1_OK", [int(c.sum()) for _, c in outs])
+'''
+
+
+def test_rccl_all_gather_runs_on_the_nms_stream_with_one_rank():
+    """`nccl` (= RCCL) process group of world size 1: DetectionPipeline(force_gather=True) sends every step's detection block
+    through dist.all_gather_into_tensor on the NMS stream — the collective, its stream ordering against the NMS kernels and
+    the gathered buffers run on hardware although no second GPU exists (a subprocess: it owns the process group)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT.format(repo=REPO)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_plan_cache_does_not_grow_over_many_shapes():
+    """A rectangular-batch validation run of yolov5l meets a new (B, H, W) every few batches; with the LRU cap the device memory
+    held by plans stays bounded (one never-freed plan per shape, ~40 GB each at 1280x1280 b16)."""
+    m = build("yolov5l_Transfusion_kaist.yaml", torch.bfloat16)
+    shapes = [(4, 544, 672), (4, 512, 640), (4, 640, 640), (4, 640, 512), (3, 544, 672), (4, 576, 640), (4, 608, 672), (2, 640, 640)]
+    first = m.plan_for(*shapes[0], device=DEV)
+    one = first.nbytes
+    del first
+    m.plan_cache_bytes = int(2.6 * one)
+    peak = []
+    for s in shapes * 2:
+        rgb, ir = synth_images(s[0], s[1], s[2], seed=1)
+        z = m(rgb.to(DEV), ir.to(DEV))[0]
+        assert torch.isfinite(z).all()
+        held = sum(p.nbytes for p in m._plans.values())
+        assert held <= m.plan_cache_bytes and len(m._plans) <= 3
+        torch.cuda.synchronize()
+        peak.append(torch.cuda.memory_allocated())
+    assert max(peak[8:]) <= max(peak[:8]) * 1.05, "second pass over the same shapes must not allocate more than the first"
+    assert max(peak) < 6 * one + 2 * 2 ** 30

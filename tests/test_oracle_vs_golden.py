@@ -124,3 +124,25 @@ def test_metrics_match_reference():
     np.testing.assert_allclose(ap, g["ap"], rtol=1e-9, atol=1e-12)
     np.testing.assert_array_equal(classes, g["classes"])
     np.testing.assert_allclose(oracle.box_iou(g["box1"], g["box2"]), g["iou"], rtol=1e-5, atol=1e-6)
+
+
+def test_match_predictions_pinned_by_the_reference_block():
+    """tests/golden/match_predictions.npz = outputs of the reference's own inline TP-matching block (test.py:196-230, exec'ed
+    from the reference tree by make_golden.py): the oracle's statement and the host statement the device kernel is tested
+    against must reproduce its flags exactly, from the same native-space boxes."""
+    from icafusion_amd.utils.metrics import match_predictions as host_match
+    from icafusion_amd.utils.general import scale_coords
+    g = load_golden("match_predictions")
+    iouv = g["iouv"]
+    hits = 0
+    for t in range(int(g["n"])):
+        pred, predn, tbox, labels, want = g[f"pred{t}"], g[f"predn{t}"], g[f"tbox{t}"], g[f"labels{t}"], g[f"correct{t}"]
+        H, W, h0, w0, gain, pw, ph = g[f"geom{t}"]
+        mine = torch.from_numpy(pred.copy())
+        scale_coords((int(H), int(W)), mine[:, :4], (int(h0), int(w0)), ((gain, gain), (pw, ph)))       # our scale_coords == the reference's
+        np.testing.assert_array_equal(mine.numpy(), predn)
+        gt = np.concatenate((labels[:, :1], tbox), 1) if len(labels) else np.zeros((0, 5), np.float32)
+        np.testing.assert_array_equal(oracle.match_predictions(predn, gt, iouv), want, err_msg=f"oracle, trial {t}")
+        np.testing.assert_array_equal(host_match(predn, gt, iouv), want, err_msg=f"host statement, trial {t}")
+        hits += int(want.sum())
+    assert hits > 100
