@@ -5,10 +5,18 @@
 One object per .hip file (parallel), then one shared library exporting the C ABI of include/icaf.h.
 detect.hip / nms.hip are built with fp contraction off: their arithmetic must round like the reference's
 separate fp32 torch ops so that NMS keep-indices are bit-exact.
+
+Every compile also asks the backend for its per-kernel resource usage (-Rpass-analysis=kernel-resource-usage); the
+summary lands in lib/kernel_resources.json, and the build FAILS if a kernel that synchronises its LDS-DMA ring with
+counted `s_waitcnt vmcnt(N)` waits (igemm_dma / ctile / bneck / stem / stem2 / dmff_* kernels) uses scratch memory: a register
+spill is a VMEM operation too, it bumps the same counter, and the counted wait would then let a wave read a slice of
+the ring that has not landed yet — silently, and only at large grids.
 """
 import concurrent.futures as cf
 import hashlib
+import json
 import os
+import re
 import subprocess
 import sys
 
@@ -18,7 +26,34 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "_obj")
 LIB = os.path.join(LIBDIR, "libicaf.so")
 ARCH = "gfx950"
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-comment"]
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-comment",
+          "-Rpass-analysis=kernel-resource-usage"]
+RESOURCES = os.path.join(LIBDIR, "kernel_resources.json")
+# kernels whose K loops use counted vmcnt waits: any scratch use (spill) would race with them
+NO_SCRATCH = re.compile(r"igemm_dma_kernel|ctile_kernel|bneck_kernel|stem_kernel|stem2_kernel|dmff_\w*kernel")
+_REMARK = re.compile(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|"
+                     r"LDS Size \[bytes/block\]|VGPRs Spill|SGPRs Spill):\s+(\S+)")
+
+
+def parse_resources(stderr):
+    """-Rpass-analysis=kernel-resource-usage remarks -> {mangled kernel name: {vgpr, agpr, sgpr, scratch, occupancy, lds, ...}}"""
+    out, cur = {}, None
+    keys = {"TotalSGPRs": "sgpr", "VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy",
+            "LDS Size [bytes/block]": "lds", "VGPRs Spill": "vgpr_spill", "SGPRs Spill": "sgpr_spill"}
+    for k, v in _REMARK.findall(stderr):
+        if k == "Function Name":
+            cur = out.setdefault(v, {})
+        elif cur is not None:
+            cur[keys[k]] = int(v)
+    return out
+
+
+def demangle(names):
+    try:
+        r = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, check=True)
+        return dict(zip(names, r.stdout.splitlines()))
+    except Exception:
+        return {n: n for n in names}
 PER_FILE = {"detect.hip": ["-ffp-contract=off"], "nms.hip": ["-ffp-contract=off"]}
 EXPORT = "-fvisibility=default"
 
@@ -63,19 +98,34 @@ def build(force=False, verbose=True):
               ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-        return obj
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr[-6000:]}")
+        return obj, parse_resources(r.stderr)
 
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(compile_one, srcs))
+        results = list(ex.map(compile_one, srcs))
+    objs = [o for o, _ in results]
+    res = {}
+    for src, (_, r) in zip(srcs, results):
+        for k, v in r.items():
+            res[k] = dict(v, file=src)
+    pretty = demangle(sorted(res))
+    report = {pretty[k][:400]: v for k, v in sorted(res.items())}
+    bad = {k: v for k, v in report.items() if NO_SCRATCH.search(k) and (v.get("scratch", 0) or v.get("vgpr_spill", 0))}
+    if bad:
+        raise RuntimeError("kernels with counted vmcnt waits must not use scratch memory (a spill is a VMEM op and races with the "
+                           "LDS-DMA ring):\n" + "\n".join(f"  {k}: {v}" for k, v in bad.items()))
     cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    with open(RESOURCES, "w") as f:
+        json.dump(report, f, indent=0, sort_keys=True)
     with open(stamp, "w") as f:
         f.write(want)
     if verbose:
-        print(f"[icafusion_amd.build] built {LIB} from {len(srcs)} HIP sources for {ARCH}")
+        spills = sum(1 for v in report.values() if v.get("scratch", 0))
+        print(f"[icafusion_amd.build] built {LIB} from {len(srcs)} HIP sources for {ARCH}: {len(report)} kernels, "
+              f"{spills} with scratch (none among the counted-vmcnt kernels)")
     return LIB
 
 

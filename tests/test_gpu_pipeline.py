@@ -71,7 +71,7 @@ from icafusion_amd.models.yolo import Model
 from icafusion_amd.pipeline import DetectionPipeline
 from icafusion_amd.synth import synth_images, synth_state_dict
 import yaml
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="2" if False else "1", LOCAL_RANK="0")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1)          # "nccl" IS RCCL on ROCm
 assert dist.get_backend() == "nccl"

@@ -172,3 +172,18 @@ def test_plan_cache_is_a_byte_capped_lru():
     assert keys[0] in [k[:3] for k in m._plans] and keys[1] not in [k[:3] for k in m._plans]               # ... so the next one goes
     m.plan_cache_bytes = 1                                                                                 # the newest plan always stays
     assert m.plan_for(1, 448, 320, device="cpu", dtype=torch.bfloat16) is not None and len(m._plans) == 1
+
+
+def test_no_counted_vmcnt_kernel_uses_scratch():
+    """icafusion_amd/build.py records every kernel's resource usage; kernels that order their LDS-DMA ring with counted
+    `s_waitcnt vmcnt(N)` must have zero scratch (a spill is a VMEM op on the same counter — ADVICE r1), and the build refuses
+    to link otherwise.  Here: the report of the library that is actually loaded says so."""
+    import json
+    import os
+    from icafusion_amd import build
+    assert os.path.exists(build.RESOURCES), "run `python -m icafusion_amd.build`"
+    rep = json.load(open(build.RESOURCES))
+    guarded = {k: v for k, v in rep.items() if build.NO_SCRATCH.search(k)}
+    assert len(guarded) > 100 and len(rep) > len(guarded)
+    assert all(v.get("scratch", 0) == 0 and v.get("vgpr_spill", 0) == 0 for v in guarded.values())
+    assert all(v["vgpr"] + v.get("agpr", 0) <= 512 for v in rep.values())
