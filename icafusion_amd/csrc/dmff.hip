@@ -463,10 +463,12 @@ static int launch_attn(const void* qkv, void* out, int B, int N, int C, int DK, 
     const int NP = (N + 31) & ~31;
     const size_t lds = (size_t)NP * (DKP * EB + 16) + (size_t)DKP * ((size_t)NP * EB + 16);
     if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "icaf_cross_attention: %zu bytes of LDS needed (N=%d, dk=%d) exceed 160 KiB", lds, N, DK);
-    static bool attr_set = false;          // per instantiation
-    if (lds > 64 * 1024 && !attr_set) {
+    static bool attr_set[ICAF_MAX_DEVICES] = {};          // per instantiation and per device
+    int dev = 0;
+    ICAF_HIP(hipGetDevice(&dev));
+    if (lds > 64 * 1024 && dev >= 0 && dev < ICAF_MAX_DEVICES && !attr_set[dev]) {
         ICAF_HIP(hipFuncSetAttribute((const void*)cross_attn_kernel<DT, DKP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const int nqt = NP / 32;
     int qsplit = (nqt + 3) / 4;
@@ -502,10 +504,12 @@ int run_pool_tokens(const void* f0, int ld0, const void* f1, int ld1, const floa
     using T = typename Elem<DT>::type;
     const size_t rows_lds = (size_t)W * C * 2 * sizeof(float);        // fp32 column sums + maxima of one token row
     if ((kh > sh || kw > sw) && rows_lds <= 160 * 1024) {             // overlapping windows: separable, one token row per workgroup
-        static size_t attr_bytes = 0;
-        if (rows_lds > 64 * 1024 && rows_lds > attr_bytes) {
+        static size_t attr_bytes[ICAF_MAX_DEVICES] = {};      // per device
+        int dev = 0;
+        ICAF_HIP(hipGetDevice(&dev));
+        if (rows_lds > 64 * 1024 && dev >= 0 && dev < ICAF_MAX_DEVICES && rows_lds > attr_bytes[dev]) {
             ICAF_HIP(hipFuncSetAttribute((const void*)pool_tokens_rows_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
-            attr_bytes = rows_lds;
+            attr_bytes[dev] = rows_lds;
         }
         pool_tokens_rows_kernel<DT><<<dim3((unsigned)(2 * B * th)), dim3(256), rows_lds, s>>>((const T*)f0, ld0, (const T*)f1, ld1, p0, p1, (T*)tok,
                                                                                              B, H, W, C, th, tw, kh, kw, sh, sw, a0, b0, a1, b1);

@@ -147,4 +147,6 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf
 
 inline hipStream_t S(icaf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+constexpr int ICAF_MAX_DEVICES = 64;      // per-device one-time kernel attribute flags (hipFuncSetAttribute is per device)
+
 }  // namespace icaf

@@ -1,21 +1,36 @@
 // Non-maximum suppression for gfx950 — replaces utils/general.py:518-607 + torchvision.ops.nms (greedy, IoU > thr).
 //
-// Three launches per batch, all images in parallel, nothing returns to the host:
-//   1. nms_candidates_kernel  one 1024-thread workgroup per image walks the prediction rows in order and compacts the
-//                             candidates (obj > conf, conf = obj*cls > conf, class filter) with a workgroup prefix
-//                             scan, so the candidate list has exactly the reference's order; emits a 64-bit sort
-//                             key (score bits << 32 | ~index) per candidate.
-//   2. rocPRIM segmented radix sort (descending) of the keys — unique keys make the order total: descending score,
-//      ties by ascending candidate index, i.e. a stable descending sort like torchvision's.
-//   3. nms_greedy_kernel      one workgroup per image visits candidates in sorted order, 64 at a time: four wavefronts
-//                             test the chunk against the (<= max_det) kept boxes held in LDS, wave 0 resolves the chunk
-//                             internally, and the walk stops as soon as max_det boxes are kept — the reference computes
-//                             the full keep list and truncates it, which yields the same first max_det boxes.
+// The reference filters candidates, sorts ALL of them by score and walks the sorted list greedily; only the first max_det
+// (300) survivors are returned.  The walk therefore reaches at most a few hundred to a few thousand of the (up to 25 200 x nc)
+// candidates, so nothing here sorts more than it walks:
+//   0. hipMemsetAsync          clears the per-image score histograms and candidate counters.
+//   1. nms_keys_kernel         every prediction row in parallel (B x rows / 1024 workgroups — the whole chip, not one
+//                              workgroup per image): obj > conf, conf = obj * cls > conf, class filter; writes ONE 32-bit word
+//                              per candidate slot (order-preserving score bits, 0 = not a candidate), the class of
+//                              single-label rows, a 2178-bin histogram of the score's upper 16 bits per image (LDS
+//                              atomics, flushed once per workgroup) and the candidate count of every 1024-row chunk.
+//   2. nms_walk_kernel         one 1024-thread workgroup per image, rounds of
+//                                select   the highest-score histogram bins that are still unvisited and hold <= 1024 (first
+//                                         round) / 4096 keys — one LDS prefix scan over the histogram;
+//                                gather   those candidates into LDS as unique 64-bit keys (score bits << 32 | ~slot);
+//                                sort     rank sort in LDS (every thread counts the keys greater than its own, broadcast
+//                                         16-byte LDS reads; unique keys -> unique ranks);
+//                                walk     greedy suppression, 64 candidates per step: 16 wavefronts test the step against
+//                                         the kept boxes (<= max_det, in LDS), wave 0 resolves the step internally;
+//                              until max_det boxes are kept or the candidates (capped at max_nms, by score) are exhausted.
+//                              Rounds visit disjoint, descending score ranges, each sorted by the full key, so the visiting
+//                              order equals a stable descending sort of all candidates — ties fall back to the slot index,
+//                              which increases with the reference's candidate index.  A histogram bin holding more than 4096
+//                              keys (thousands of near-identical scores) is split by an 8-digit radix refinement of the
+//                              64-bit key range — slow, exact, and never taken by real score distributions.
+//                              Boxes are decoded from the prediction rows on demand; no candidate list is materialised.
+//   3. nms_rank_kernel         (only when keep_idx is requested) converts the kept slots into torchvision's indices: the
+//                              rank of the slot among the image's candidates = chunk counts before it + candidates before
+//                              it inside its chunk.
 // All box arithmetic is fp32 with contraction disabled, in the reference's operation order, so kept indices are
 // bit-identical to the CPU algorithm on the same prediction tensor.
 #pragma clang fp contract(off)
 #include <cstring>
-#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include "icaf_common.h"
 
 namespace icaf {
@@ -26,92 +41,88 @@ __device__ __forceinline__ bool class_ok(const ClassMask& cm, int use, int c) {
     return !use || (c < 256 && ((cm.w[c >> 5] >> (c & 31)) & 1u));
 }
 
-__device__ __forceinline__ int block_excl_scan_1024(int v, int* wsum, int& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int base = 0, tot = 0;
-    for (int w = 0; w < 16; ++w) {
-        const int s = wsum[w];
-        if (w < wave) base += s;
-        tot += s;
-    }
-    __syncthreads();
-    total = tot;
-    return base + inc - v;
+constexpr int NMS_NB = 2178;                 // histogram bins over the upper 16 bits of the ordered score word
+constexpr unsigned NMS_BIN_LO = 0xB700u;     // bin 0 = everything below 2^-17 (and negative scores), bin NB-1 = [1.0, inf)
+constexpr int NMS_CAP = 4096;                // keys gathered / sorted per round
+constexpr int NMS_FIRST = 1024;              // target of the first round (the walk usually ends inside it)
+constexpr int NMS_CHUNK_ROWS = 1024;         // prediction rows per nms_keys workgroup
+constexpr int MAX_KEEP = 1024;
+constexpr int WALK_THREADS = 1024;
+
+// float -> unsigned with the same ordering (negative floats below positive ones); never 0 for a candidate (c > conf, not NaN)
+__device__ __forceinline__ unsigned int ordered_bits(float c) {
+    const unsigned int b = __float_as_uint(c);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ int bin_of(unsigned int u) {
+    const int v = (int)(u >> 16) - (int)NMS_BIN_LO;
+    return v < 0 ? 0 : (v > NMS_NB - 1 ? NMS_NB - 1 : v);
+}
+// smallest 64-bit key of histogram bin t
+__device__ __forceinline__ unsigned long long bin_floor_key(int t) {
+    return t <= 0 ? 0ull : ((unsigned long long)((unsigned)(t + (int)NMS_BIN_LO) << 16)) << 32;
 }
 
-__global__ __launch_bounds__(1024) void nms_candidates_kernel(const float* __restrict__ pred, long long rows, int nc, float conf, int multi,
-                                                              ClassMask cm, int use_cm, long long cap,
-                                                              unsigned long long* __restrict__ keys, float* __restrict__ cdet,
-                                                              int* __restrict__ ncand, unsigned int* __restrict__ seg_begin,
-                                                              unsigned int* __restrict__ seg_end) {
-    __shared__ int wsum[16];
-    const int b = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__ pred, long long rows, int nc, float conf, int multi,
+                                                       ClassMask cm, int use_cm, long long cap, int nchunks,
+                                                       unsigned int* __restrict__ key32, unsigned short* __restrict__ cls16,
+                                                       unsigned int* __restrict__ ghist, unsigned int* __restrict__ ncand,
+                                                       unsigned int* __restrict__ chunk_cnt) {
+    __shared__ unsigned int hist[NMS_NB];
+    __shared__ int wsum[4];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int no = 5 + nc;
+    for (int i = tid; i < NMS_NB; i += 256) hist[i] = 0;
+    __syncthreads();
     const float* pb = pred + (long long)b * rows * no;
-    unsigned long long* kb = keys + (long long)b * cap;
-    float* db = cdet + (long long)b * cap * 6;
-    int base = 0;
-    for (long long r0 = 0; r0 < rows; r0 += 1024) {
-        const long long r = r0 + tid;
-        int cnt = 0, best_j = 0;
-        float obj = 0.0f, best = -INFINITY;
+    unsigned int* kb = key32 + (long long)b * cap;
+    int cnt = 0;
+#pragma unroll
+    for (int it = 0; it < NMS_CHUNK_ROWS / 256; ++it) {
+        const long long r = (long long)chunk * NMS_CHUNK_ROWS + it * 256 + tid;
+        if (r >= rows) break;
         const float* p = pb + r * no;
-        if (r < rows) {
-            obj = p[4];
-            if (obj > conf) {
-                if (multi) {
-                    for (int j = 0; j < nc; ++j) {
-                        const float c = p[5 + j] * obj;
-                        if (c > conf && class_ok(cm, use_cm, j)) ++cnt;
-                    }
-                } else {
-                    for (int j = 0; j < nc; ++j) {
-                        const float c = p[5 + j] * obj;
-                        if (c > best) { best = c; best_j = j; }
-                    }
-                    if (best > conf && class_ok(cm, use_cm, best_j)) cnt = 1;
+        const float obj = p[4];
+        if (multi) {
+            for (int j = 0; j < nc; ++j) {
+                unsigned int k = 0;
+                if (obj > conf) {
+                    const float c = p[5 + j] * obj;
+                    if (c > conf && class_ok(cm, use_cm, j)) k = ordered_bits(c);
                 }
+                kb[r * nc + j] = k;
+                if (k) { atomicAdd(&hist[bin_of(k)], 1u); ++cnt; }
             }
-        }
-        int total;
-        int pos = base + block_excl_scan_1024(cnt, wsum, total);
-        if (cnt) {
-            const float hw = p[2] / 2.0f, hh = p[3] / 2.0f;
-            const float x1 = p[0] - hw, y1 = p[1] - hh, x2 = p[0] + hw, y2 = p[1] + hh;
-            if (multi) {
+        } else {
+            unsigned int k = 0;
+            int best_j = 0;
+            if (obj > conf) {
+                float best = -INFINITY;
                 for (int j = 0; j < nc; ++j) {
                     const float c = p[5 + j] * obj;
-                    if (c > conf && class_ok(cm, use_cm, j)) {
-                        float* d = db + (long long)pos * 6;
-                        d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = c; d[5] = (float)j;
-                        kb[pos] = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pos);
-                        ++pos;
-                    }
+                    if (c > best) { best = c; best_j = j; }
                 }
-            } else {
-                float* d = db + (long long)pos * 6;
-                d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = best; d[5] = (float)best_j;
-                kb[pos] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pos);
+                if (best > conf && class_ok(cm, use_cm, best_j)) k = ordered_bits(best);
             }
+            kb[r] = k;
+            cls16[(long long)b * rows + r] = (unsigned short)best_j;
+            if (k) { atomicAdd(&hist[bin_of(k)], 1u); ++cnt; }
         }
-        base += total;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((tid & 63) == 0) wsum[tid >> 6] = cnt;
+    __syncthreads();
     if (tid == 0) {
-        ncand[b] = base;
-        seg_begin[b] = (unsigned int)((long long)b * cap);
-        seg_end[b] = (unsigned int)((long long)b * cap + base);
+        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        chunk_cnt[(long long)b * nchunks + chunk] = (unsigned)total;
+        if (total) atomicAdd(&ncand[b], (unsigned)total);
+    }
+    for (int i = tid; i < NMS_NB; i += 256) {
+        const unsigned int v = hist[i];
+        if (v) atomicAdd(&ghist[(long long)b * NMS_NB + i], v);
     }
 }
-
-constexpr int MAX_KEEP = 1024;
 
 __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1, float bx2,
                                        float by2, float barea, float thr) {
@@ -123,98 +134,334 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
     return ovr > thr;
 }
 
-__global__ __launch_bounds__(256) void nms_greedy_kernel(const unsigned long long* __restrict__ keys_sorted, const float* __restrict__ cdet,
-                                                         const int* __restrict__ ncand, long long cap, float iou_thr, float cls_off,
-                                                         int max_det, int max_nms, float* __restrict__ det, int* __restrict__ count,
-                                                         int* __restrict__ keep_idx) {
-    __shared__ float kx1[MAX_KEEP], ky1[MAX_KEEP], kx2[MAX_KEEP], ky2[MAX_KEEP], kar[MAX_KEEP];
-    __shared__ float cx1[64], cy1[64], cx2[64], cy2[64], car[64];
-    __shared__ int sup[4][64];
-    __shared__ int nkept_s;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_all = ncand[b];
-    const bool reordered = n_all > max_nms;          // reference re-indexes x by score rank in that case (:586)
-    const int n = reordered ? max_nms : n_all;
-    const unsigned long long* kb = keys_sorted + (long long)b * cap;
-    const float* db = cdet + (long long)b * cap * 6;
-    float* ob = det + (long long)b * max_det * 6;
-    int* ib = keep_idx ? keep_idx + (long long)b * max_det : nullptr;
-    if (tid == 0) nkept_s = 0;
-    __syncthreads();
-    int nkept = 0;
-    for (int c0 = 0; c0 < n && nkept < max_det; c0 += 64) {
-        const int pos = c0 + lane;
-        const bool valid = pos < n;
-        int ci = 0;
-        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, area = 0.f, sc = 0.f, cl = 0.f, ux1 = 0.f, uy1 = 0.f, ux2 = 0.f, uy2 = 0.f;
-        if (valid) {
-            ci = (int)(0xffffffffu - (unsigned)(kb[pos] & 0xffffffffull));
-            const float* d = db + (long long)ci * 6;
-            ux1 = d[0]; uy1 = d[1]; ux2 = d[2]; uy2 = d[3]; sc = d[4]; cl = d[5];
-            const float off = cl * cls_off;                     // boxes + cls * max_wh (reference :589-590)
-            x1 = ux1 + off; y1 = uy1 + off; x2 = ux2 + off; y2 = uy2 + off;
-            area = (x2 - x1) * (y2 - y1);
-        }
-        // phase A: every wave tests the chunk against a quarter of the kept list
-        bool dead = !valid;
-        for (int k = wave; k < nkept && !__all(dead); k += 4)
-            dead = dead || iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], kar[k], x1, y1, x2, y2, area, iou_thr);
-        sup[wave][lane] = dead ? 1 : 0;
-        if (wave == 0) { cx1[lane] = x1; cy1[lane] = y1; cx2[lane] = x2; cy2[lane] = y2; car[lane] = area; }
-        __syncthreads();
-        if (wave == 0) {
-            dead = (sup[0][lane] | sup[1][lane] | sup[2][lane] | sup[3][lane]) != 0;
-            unsigned long long alive = __ballot(!dead);
-            // phase B: resolve the chunk in order; each surviving candidate is kept and suppresses later lanes
-            while (alive && nkept < max_det) {
-                const int j = __ffsll((long long)alive) - 1;
-                alive &= ~(1ull << j);
-                const float jx1 = cx1[j], jy1 = cy1[j], jx2 = cx2[j], jy2 = cy2[j], jar = car[j];
-                if (lane == j) {
-                    kx1[nkept] = x1; ky1[nkept] = y1; kx2[nkept] = x2; ky2[nkept] = y2; kar[nkept] = area;
-                    float* o = ob + (long long)nkept * 6;
-                    o[0] = ux1; o[1] = uy1; o[2] = ux2; o[3] = uy2; o[4] = sc; o[5] = cl;
-                    if (ib) ib[nkept] = reordered ? pos : ci;
-                }
-                ++nkept;
-                const bool hit = lane > j && iou_gt(jx1, jy1, jx2, jy2, jar, x1, y1, x2, y2, area, iou_thr);
-                alive &= ~__ballot(hit);
-            }
-            if (lane == 0) nkept_s = nkept;
-        }
-        __syncthreads();
-        nkept = nkept_s;
+// inclusive prefix sum over the 1024 threads of the walk kernel (v per thread); total returned through `total`
+__device__ __forceinline__ unsigned int block_incl_scan_1024(unsigned int v, unsigned int* wsum, unsigned int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
     }
-    if (tid == 0) count[b] = nkept;
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const unsigned int s = wsum[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc;
+}
+
+struct WalkSmem {
+    unsigned long long keys[NMS_CAP];                                     // gathered / sorted keys of the round
+    float kx1[MAX_KEEP], ky1[MAX_KEEP], kx2[MAX_KEEP], ky2[MAX_KEEP], kar[MAX_KEEP];      // kept boxes (class-offset), areas
+    float cx1[WALK_THREADS], cy1[WALK_THREADS], cx2[WALK_THREADS], cy2[WALK_THREADS], car[WALK_THREADS];   // decoded candidates
+    unsigned int kslot[MAX_KEEP];                                         // candidate slot of every kept box
+    unsigned int kpos[MAX_KEEP];                                          // its position in the sorted order
+    unsigned int hist[NMS_NB];
+    unsigned int dh[256];
+    unsigned int wsum[16];
+    unsigned long long deadmask;
+    unsigned long long lo, hi;
+    unsigned int batch_n, sel_cnt, sel_val, nkept;
+    int mode_b_bin;
+};
+
+// decode the box of candidate slot `slot`: xywh -> xyxy exactly as the reference (utils/general.py:332-339)
+__device__ __forceinline__ void decode_slot(const float* __restrict__ pb, const unsigned short* __restrict__ cb, int nc, int multi,
+                                            unsigned int slot, float& x1, float& y1, float& x2, float& y2, float& sc, int& cl) {
+    const unsigned int row = multi ? slot / (unsigned)nc : slot;
+    cl = multi ? (int)(slot - row * (unsigned)nc) : (int)cb[row];
+    const float* p = pb + (long long)row * (5 + nc);
+    const float hw = p[2] / 2.0f, hh = p[3] / 2.0f;
+    x1 = p[0] - hw; y1 = p[1] - hh; x2 = p[0] + hw; y2 = p[1] + hh;
+    sc = p[5 + cl] * p[4];
+}
+
+__global__ __launch_bounds__(WALK_THREADS) void nms_walk_kernel(const float* __restrict__ pred, long long rows, int nc, int multi,
+                                                                long long cap, const unsigned int* __restrict__ key32,
+                                                                const unsigned short* __restrict__ cls16,
+                                                                const unsigned int* __restrict__ ghist,
+                                                                const unsigned int* __restrict__ ncand, float iou_thr, float cls_off,
+                                                                int max_det, int max_nms, float* __restrict__ det,
+                                                                int* __restrict__ count, int* __restrict__ keep_idx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char walk_smem_raw[];
+    WalkSmem& sm = *reinterpret_cast<WalkSmem*>(walk_smem_raw);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* pb = pred + (long long)b * rows * (5 + nc);
+    const unsigned int* kb = key32 + (long long)b * cap;
+    const unsigned short* cb = cls16 + (long long)b * rows;
+    const unsigned int n_all = ncand[b];
+    const bool reordered = n_all > (unsigned)max_nms;             // reference re-indexes x by score rank in that case (:586)
+    const unsigned int n = reordered ? (unsigned)max_nms : n_all;
+    for (int i = tid; i < NMS_NB; i += WALK_THREADS) sm.hist[i] = ghist[(long long)b * NMS_NB + i];
+    if (tid == 0) { sm.nkept = 0; sm.deadmask = 0ull; sm.mode_b_bin = -1; }
+    __syncthreads();
+    int hib = NMS_NB;                              // histogram bins [0, hib) are entirely unvisited
+    unsigned long long hi = ~0ull;                 // keys >= hi have been visited
+    unsigned int processed = 0, nkept = 0;
+    unsigned int in_bin_left = 0;                  // refinement mode: unvisited keys left in bin hib (which is then partially visited)
+    int round = 0;
+    while (nkept < (unsigned)max_det && processed < n) {
+        // ------------------------------------------------------------------ select [lo, hi)
+        unsigned long long lo = 0ull;
+        unsigned int expect = 0;
+        int mode_b = -1;
+        if (in_bin_left == 0) {
+            // P(d) = keys in bins (hib-1-d .. hib-1]; largest d with P(d) <= target
+            unsigned int target = round == 0 ? NMS_FIRST : NMS_CAP;
+            for (;;) {
+                unsigned int loc[3], s = 0;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const int d = tid * 3 + e;
+                    loc[e] = d < hib ? sm.hist[hib - 1 - d] : 0u;
+                    s += loc[e];
+                }
+                unsigned int total;
+                const unsigned int incl = block_incl_scan_1024(s, sm.wsum, total);
+                if (tid == 0) { sm.sel_cnt = 0; sm.sel_val = 0; }
+                __syncthreads();
+                unsigned int run = incl - s, nle = 0, last = 0;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    run += loc[e];
+                    if (tid * 3 + e < hib && run <= target) { ++nle; last = run; }
+                }
+                if (nle) { atomicAdd(&sm.sel_cnt, nle); atomicMax(&sm.sel_val, last); }
+                __syncthreads();
+                const unsigned int dcnt = sm.sel_cnt, val = sm.sel_val;     // dcnt bins from the top hold `val` keys in total
+                __syncthreads();
+                if (total == 0) { expect = 0; hib = 0; break; }             // nothing left anywhere
+                if (val > 0) { expect = val; hib -= (int)dcnt; lo = bin_floor_key(hib); break; }
+                // the next non-empty bin alone exceeds the target
+                hib -= (int)dcnt;                                            // skip the empty bins above it
+                if (target < NMS_CAP) { target = NMS_CAP; continue; }
+                mode_b = hib - 1;                                            // > NMS_CAP keys in one bin: refine inside it
+                break;
+            }
+            if (expect == 0 && mode_b < 0) break;
+            if (mode_b >= 0) { in_bin_left = sm.hist[mode_b]; hib = mode_b; }      // (bins between it and `hi` are empty: hi stays a valid bound)
+        }
+        if (in_bin_left != 0) {
+            // radix refinement inside bin `hib` over the keys in [bin_floor_key(hib), hi): find lo with 1 <= #[lo, hi) <= NMS_CAP
+            const unsigned long long blo = bin_floor_key(hib);
+            if (in_bin_left <= NMS_CAP) {
+                lo = blo; expect = in_bin_left;
+            } else {
+                unsigned long long prefix = 0ull;      // the digits chosen so far (upper bits of lo)
+                unsigned int acc = 0;                  // keys above the current prefix range that the batch already includes
+                for (int level = 0; level < 8; ++level) {
+                    const int shift = 56 - 8 * level;
+                    for (int i = tid; i < 256; i += WALK_THREADS) sm.dh[i] = 0;
+                    __syncthreads();
+                    for (long long i = tid; i < cap; i += WALK_THREADS) {
+                        const unsigned int k32 = kb[i];
+                        if (!k32) continue;
+                        const unsigned long long k = ((unsigned long long)k32 << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+                        if (k < blo || k >= hi) continue;
+                        if (level > 0 && (k >> (shift + 8)) != (prefix >> (shift + 8))) continue;
+                        atomicAdd(&sm.dh[(unsigned)(k >> shift) & 255u], 1u);
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        int dmax = 255;
+                        while (dmax > 0 && sm.dh[dmax] == 0) --dmax;
+                        if (acc + sm.dh[dmax] > NMS_CAP) {                   // descend into the top digit
+                            sm.lo = prefix | ((unsigned long long)dmax << shift);
+                            sm.sel_val = 0;
+                        } else {
+                            unsigned int suf = 0;
+                            int d = dmax;
+                            while (d >= 0 && acc + suf + sm.dh[d] <= NMS_CAP) { suf += sm.dh[d]; --d; }
+                            sm.lo = prefix | ((unsigned long long)(d + 1) << shift);
+                            sm.sel_val = acc + suf;                          // >= 1
+                        }
+                    }
+                    __syncthreads();
+                    prefix = sm.lo;
+                    const unsigned int got = sm.sel_val;
+                    __syncthreads();
+                    if (got) { lo = prefix; expect = got; break; }
+                }
+                if (lo < blo) lo = blo;
+            }
+        }
+        // ------------------------------------------------------------------ gather the keys of [lo, hi) into LDS (any order)
+        if (tid == 0) sm.batch_n = 0;
+        __syncthreads();
+        for (long long i0 = 0; i0 < cap; i0 += WALK_THREADS) {
+            const long long i = i0 + tid;
+            unsigned long long k = 0ull;
+            bool take = false;
+            if (i < cap) {
+                const unsigned int k32 = kb[i];
+                if (k32) {
+                    k = ((unsigned long long)k32 << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+                    take = k >= lo && k < hi;
+                }
+            }
+            const unsigned long long m = __ballot(take);
+            if (m) {
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(&sm.batch_n, (unsigned)__popcll(m));
+                base = __shfl(base, 0);
+                if (take) {
+                    const unsigned int slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                    if (slot < NMS_CAP) sm.keys[slot] = k;
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned int bn = sm.batch_n < NMS_CAP ? sm.batch_n : NMS_CAP;       // (== expect by construction)
+        // ------------------------------------------------------------------ rank sort, descending (unique keys -> unique ranks)
+        {
+            const unsigned int bn2 = (bn + 1u) & ~1u;
+            if (tid == 0 && (bn & 1u)) sm.keys[bn] = 0ull;                            // pad to an even count with the smallest key
+            __syncthreads();
+            unsigned long long mine[NMS_CAP / WALK_THREADS];
+            unsigned int rank[NMS_CAP / WALK_THREADS];
+#pragma unroll
+            for (int e = 0; e < NMS_CAP / WALK_THREADS; ++e) {
+                const unsigned int i = tid + e * WALK_THREADS;
+                mine[e] = i < bn ? sm.keys[i] : 0ull;
+                rank[e] = 0;
+            }
+            const unsigned int nmine = (bn + WALK_THREADS - 1 - tid) / WALK_THREADS;   // how many of mine[] are real
+            if (nmine) {
+                for (unsigned int j = 0; j < bn2; j += 2) {
+                    const unsigned long long a = sm.keys[j], c = sm.keys[j + 1];      // one 16-byte broadcast read
+#pragma unroll
+                    for (int e = 0; e < NMS_CAP / WALK_THREADS; ++e) rank[e] += (a > mine[e]) + (c > mine[e]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < NMS_CAP / WALK_THREADS; ++e)
+                if ((unsigned)e < nmine) sm.keys[rank[e]] = mine[e];
+            __syncthreads();
+        }
+        // ------------------------------------------------------------------ greedy walk over the sorted round
+        const unsigned int limit = (n - processed) < bn ? (n - processed) : bn;     // max_nms cap (by score rank)
+        for (unsigned int base = 0; base < limit && nkept < (unsigned)max_det; base += WALK_THREADS) {
+            {
+                const unsigned int pos = base + tid;
+                if (pos < limit) {
+                    const unsigned int slot = 0xffffffffu - (unsigned)(sm.keys[pos] & 0xffffffffull);
+                    float x1, y1, x2, y2, sc;
+                    int cl;
+                    decode_slot(pb, cb, nc, multi, slot, x1, y1, x2, y2, sc, cl);
+                    const float off = (float)cl * cls_off;                 // boxes + cls * max_wh (reference :589-590)
+                    x1 = x1 + off; y1 = y1 + off; x2 = x2 + off; y2 = y2 + off;
+                    sm.cx1[tid] = x1; sm.cy1[tid] = y1; sm.cx2[tid] = x2; sm.cy2[tid] = y2;
+                    sm.car[tid] = (x2 - x1) * (y2 - y1);
+                }
+            }
+            __syncthreads();
+            const unsigned int span = (limit - base) < WALK_THREADS ? (limit - base) : WALK_THREADS;
+            for (unsigned int c0 = 0; c0 < span && nkept < (unsigned)max_det; c0 += 64) {
+                const unsigned int ci = c0 + lane;
+                const bool valid = ci < span;
+                float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, area = 0.f;
+                if (valid) { x1 = sm.cx1[ci]; y1 = sm.cy1[ci]; x2 = sm.cx2[ci]; y2 = sm.cy2[ci]; area = sm.car[ci]; }
+                // phase A: the 16 wavefronts test the step against interleaved sixteenths of the kept list
+                bool dead = !valid;
+                for (unsigned int k = wave; k < nkept && !__all(dead); k += 16)
+                    dead = dead || iou_gt(sm.kx1[k], sm.ky1[k], sm.kx2[k], sm.ky2[k], sm.kar[k], x1, y1, x2, y2, area, iou_thr);
+                const unsigned long long dm = __ballot(dead);
+                if (lane == 0 && dm) atomicOr(&sm.deadmask, dm);
+                __syncthreads();
+                if (wave == 0) {
+                    // phase B: resolve the step in order; each surviving candidate is kept and suppresses later lanes
+                    unsigned long long alive = ~sm.deadmask;
+                    while (alive && nkept < (unsigned)max_det) {
+                        const int j = __ffsll((long long)alive) - 1;
+                        alive &= ~(1ull << j);
+                        const unsigned int cj = c0 + (unsigned)j;
+                        const float jx1 = sm.cx1[cj], jy1 = sm.cy1[cj], jx2 = sm.cx2[cj], jy2 = sm.cy2[cj], jar = sm.car[cj];
+                        if (lane == j) {
+                            sm.kx1[nkept] = x1; sm.ky1[nkept] = y1; sm.kx2[nkept] = x2; sm.ky2[nkept] = y2; sm.kar[nkept] = area;
+                            sm.kslot[nkept] = 0xffffffffu - (unsigned)(sm.keys[base + cj] & 0xffffffffull);
+                            sm.kpos[nkept] = processed + base + cj;
+                        }
+                        ++nkept;
+                        const bool hit = lane > j && iou_gt(jx1, jy1, jx2, jy2, jar, x1, y1, x2, y2, area, iou_thr);
+                        alive &= ~__ballot(hit);
+                    }
+                    if (lane == 0) { sm.nkept = nkept; sm.deadmask = 0ull; }
+                }
+                __syncthreads();
+                nkept = sm.nkept;
+            }
+        }
+        processed += bn;
+        hi = lo;
+        if (in_bin_left != 0) {
+            in_bin_left = in_bin_left > bn ? in_bin_left - bn : 0u;       // bin `hib` done once nothing is left in it
+        }
+        ++round;
+        if (bn == 0) break;                                                // defensive: no progress is impossible by construction
+    }
+    // ---------------------------------------------------------------------- outputs, all kept boxes in parallel
+    if (tid == 0) count[b] = (int)nkept;
+    for (unsigned int k = tid; k < nkept; k += WALK_THREADS) {
+        float x1, y1, x2, y2, sc;
+        int cl;
+        decode_slot(pb, cb, nc, multi, sm.kslot[k], x1, y1, x2, y2, sc, cl);
+        float* o = det + ((long long)b * max_det + k) * 6;
+        o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = sc; o[5] = (float)cl;
+        if (keep_idx) keep_idx[(long long)b * max_det + k] = (int)(reordered ? sm.kpos[k] : sm.kslot[k]);
+    }
+}
+
+// keep_idx holds candidate SLOTS (row * nc + class) after the walk; torchvision returns indices into the candidate list,
+// i.e. the rank of the slot among the image's candidates (slots are visited in candidate order).  One wavefront per kept box.
+__global__ __launch_bounds__(256) void nms_rank_kernel(const unsigned int* __restrict__ key32, long long cap, int ncm, int nchunks,
+                                                       const unsigned int* __restrict__ chunk_cnt,
+                                                       const unsigned int* __restrict__ ncand, const int* __restrict__ count,
+                                                       int max_det, int max_nms, int* __restrict__ keep_idx) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= count[b] || ncand[b] > (unsigned)max_nms) return;           // re-ordered images already hold sorted positions
+    const unsigned int slot = (unsigned)keep_idx[(long long)b * max_det + k];
+    const unsigned int per_chunk = (unsigned)NMS_CHUNK_ROWS * (unsigned)ncm;
+    const unsigned int chunk = slot / per_chunk;
+    unsigned int r = 0;
+    for (unsigned int c = lane; c < chunk; c += 64) r += chunk_cnt[(long long)b * nchunks + c];
+    const unsigned int* kb = key32 + (long long)b * cap;
+    for (unsigned int i = chunk * per_chunk + lane; i < slot; i += 64) r += kb[i] != 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+    if (lane == 0) keep_idx[(long long)b * max_det + k] = (int)r;
 }
 
 struct NmsWs {
-    unsigned long long* keys_in; unsigned long long* keys_out; float* cdet; int* ncand; unsigned int* seg_begin; unsigned int* seg_end;
-    void* sort_tmp; size_t sort_tmp_bytes; size_t total;
+    unsigned int* key32; unsigned short* cls16; unsigned int* ghist; unsigned int* ncand; unsigned int* chunk_cnt;
+    size_t zero_bytes; int nchunks; size_t total;
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int nms_layout(int B, long long rows, int nc, int multi, void* base, NmsWs& ws) {
     if (B < 1 || rows < 1 || nc < 1) return fail(ICAF_ERR_ARG, "icaf_nms: bad B/rows/nc");
+    if (nc > 65535) return fail(ICAF_ERR_UNSUPPORTED, "icaf_nms: at most 65535 classes");
     const long long cap = rows * ((multi && nc > 1) ? nc : 1);
-    if ((long long)B * cap > 0xffffffffLL) return fail(ICAF_ERR_UNSUPPORTED, "icaf_nms: B*rows*nc exceeds 2^32 candidates");
-    size_t tmp = 0;
-    hipError_t e = rocprim::segmented_radix_sort_keys_desc(nullptr, tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                                           (unsigned int)((long long)B * cap), (unsigned int)B, (unsigned int*)nullptr,
-                                                           (unsigned int*)nullptr, 0, 64, (hipStream_t) nullptr);
-    if (e != hipSuccess) return fail(ICAF_ERR_HIP, "rocprim temp-size query -> %s", hipGetErrorString(e));
+    if (cap > 0xfffffff0LL || (long long)B > 65535) return fail(ICAF_ERR_UNSUPPORTED, "icaf_nms: rows*nc exceeds 2^32 candidate slots per image");
     size_t off = 0;
     unsigned char* p = (unsigned char*)base;
     auto take = [&](size_t bytes) { unsigned char* r = p ? p + off : nullptr; off = align_up(off + bytes, 256); return r; };
-    ws.keys_in = (unsigned long long*)take((size_t)B * cap * 8);
-    ws.keys_out = (unsigned long long*)take((size_t)B * cap * 8);
-    ws.cdet = (float*)take((size_t)B * cap * 6 * 4);
-    ws.ncand = (int*)take((size_t)B * 4);
-    ws.seg_begin = (unsigned int*)take((size_t)B * 4);
-    ws.seg_end = (unsigned int*)take((size_t)B * 4);
-    ws.sort_tmp = take(tmp);
-    ws.sort_tmp_bytes = tmp;
+    ws.nchunks = (int)((rows + NMS_CHUNK_ROWS - 1) / NMS_CHUNK_ROWS);
+    ws.ghist = (unsigned int*)take((size_t)B * NMS_NB * 4 + (size_t)B * 4);       // histograms + candidate counters: cleared per call
+    ws.ncand = ws.ghist ? ws.ghist + (size_t)B * NMS_NB : nullptr;
+    ws.zero_bytes = (size_t)B * NMS_NB * 4 + (size_t)B * 4;
+    ws.key32 = (unsigned int*)take((size_t)B * cap * 4);
+    ws.cls16 = (unsigned short*)take((size_t)B * rows * 2);
+    ws.chunk_cnt = (unsigned int*)take((size_t)B * ws.nchunks * 4);
     ws.total = off;
     return ICAF_OK;
 }
@@ -303,6 +550,7 @@ extern "C" int icaf_nms(const float* pred, int B, long long rows, int nc, float 
                         int* keep_idx, void* workspace, size_t workspace_bytes, icaf_stream_t s) {
     if (!pred || !det || !count || !workspace) return fail(ICAF_ERR_ARG, "icaf_nms: null pointer");
     if (max_det < 1 || max_det > MAX_KEEP) return fail(ICAF_ERR_ARG, "icaf_nms: max_det must be in [1, %d]", MAX_KEEP);
+    if (max_nms < 1) return fail(ICAF_ERR_ARG, "icaf_nms: max_nms must be positive");
     if (((uintptr_t)workspace & 255) != 0) return fail(ICAF_ERR_ARG, "icaf_nms: workspace must be 256-byte aligned");
     const int multi = multi_label && nc > 1;
     NmsWs ws;
@@ -318,15 +566,29 @@ extern "C" int icaf_nms(const float* pred, int B, long long rows, int nc, float 
     }
     const long long cap = rows * (multi ? nc : 1);
     hipStream_t hs = S(s);
-    nms_candidates_kernel<<<dim3((unsigned)B), dim3(1024), 0, hs>>>(pred, rows, nc, conf_thres, multi, cm, n_classes > 0 ? 1 : 0, cap,
-                                                                     ws.keys_in, ws.cdet, ws.ncand, ws.seg_begin, ws.seg_end);
+    static bool attr_set[ICAF_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
+    int dev = 0;
+    ICAF_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= ICAF_MAX_DEVICES) return fail(ICAF_ERR_UNSUPPORTED, "icaf_nms: device ordinal %d", dev);
+    if (!attr_set[dev]) {
+        ICAF_HIP(hipFuncSetAttribute((const void*)nms_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WalkSmem)));
+        attr_set[dev] = true;
+    }
+    ICAF_HIP(hipMemsetAsync(ws.ghist, 0, ws.zero_bytes, hs));
+    nms_keys_kernel<<<dim3((unsigned)ws.nchunks, (unsigned)B), dim3(256), 0, hs>>>(pred, rows, nc, conf_thres, multi, cm, n_classes > 0 ? 1 : 0,
+                                                                                   cap, ws.nchunks, ws.key32, ws.cls16, ws.ghist, ws.ncand,
+                                                                                   ws.chunk_cnt);
     ICAF_LAUNCH_CHECK();
-    size_t tmp = ws.sort_tmp_bytes;
-    ICAF_HIP(rocprim::segmented_radix_sort_keys_desc(ws.sort_tmp, tmp, ws.keys_in, ws.keys_out, (unsigned int)((long long)B * cap),
-                                                     (unsigned int)B, ws.seg_begin, ws.seg_end, 0, 64, hs));
-    nms_greedy_kernel<<<dim3((unsigned)B), dim3(256), 0, hs>>>(ws.keys_out, ws.cdet, ws.ncand, cap, iou_thres, agnostic ? 0.0f : max_wh,
-                                                                max_det, max_nms, det, count, keep_idx);
+    nms_walk_kernel<<<dim3((unsigned)B), dim3(WALK_THREADS), sizeof(WalkSmem), hs>>>(pred, rows, nc, multi, cap, ws.key32, ws.cls16, ws.ghist,
+                                                                                     ws.ncand, iou_thres, agnostic ? 0.0f : max_wh, max_det,
+                                                                                     max_nms, det, count, keep_idx);
     ICAF_LAUNCH_CHECK();
+    if (keep_idx) {
+        nms_rank_kernel<<<dim3((unsigned)((max_det + 3) / 4), (unsigned)B), dim3(256), 0, hs>>>(ws.key32, cap, multi ? nc : 1, ws.nchunks,
+                                                                                              ws.chunk_cnt, ws.ncand, count, max_det, max_nms,
+                                                                                              keep_idx);
+        ICAF_LAUNCH_CHECK();
+    }
     return ICAF_OK;
 }
 

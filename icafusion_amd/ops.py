@@ -487,7 +487,9 @@ def detect_decode(p, z, logits, raw, na, no, row_offset, stride, anchors_px, nam
 class NmsRunner:
     """Pre-allocated NMS launch for a fixed (B, rows, nc) — graph-capturable; results stay on the device."""
 
-    def __init__(self, B, rows, nc, device, multi_label=False, max_det=300):
+    def __init__(self, B, rows, nc, device, multi_label=False, max_det=300, want_keep=True):
+        """want_keep=False skips the kept-index output (torchvision's return value; one more small launch) — the serving
+        pipeline only needs the detection rows."""
         self.B, self.rows, self.nc, self.max_det = B, rows, nc, max_det
         self.multi_label = bool(multi_label) and nc > 1
         sz = C.c_size_t(0)
@@ -495,7 +497,7 @@ class NmsRunner:
         self.ws = torch.empty((max(sz.value, 16),), dtype=torch.uint8, device=device)
         self.det = torch.zeros((B, max_det, 6), dtype=torch.float32, device=device)
         self.count = torch.zeros((B,), dtype=torch.int32, device=device)
-        self.keep = torch.zeros((B, max_det), dtype=torch.int32, device=device)
+        self.keep = torch.zeros((B, max_det), dtype=torch.int32, device=device) if want_keep else None
 
     def launch(self, pred, conf_thres, iou_thres, agnostic=False, classes=None, max_nms=30000, max_wh=4096.0,
                stream_ptr=None):
@@ -506,7 +508,7 @@ class NmsRunner:
             cls_arr = (C.c_int * max(ncls, 1))(*[int(c) for c in classes])
         st = lib().icaf_nms(pred.data_ptr(), self.B, self.rows, self.nc, float(conf_thres), float(iou_thres),
                             int(self.multi_label), int(bool(agnostic)), cls_arr, ncls, self.max_det, int(max_nms),
-                            float(max_wh), self.det.data_ptr(), self.count.data_ptr(), self.keep.data_ptr(),
+                            float(max_wh), self.det.data_ptr(), self.count.data_ptr(), self.keep.data_ptr() if self.keep is not None else None,
                             self.ws.data_ptr(), self.ws.numel(),
                             stream_ptr if stream_ptr is not None else current_stream_ptr())
         check(st, "icaf_nms")

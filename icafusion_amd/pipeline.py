@@ -39,7 +39,7 @@ class DetectionPipeline:
         nslots = 2 if overlap else 1
         rows, no = self.z.shape[1], self.z.shape[2]
         ml = bool(multi_label) and no - 5 > 1
-        self.runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det) for _ in range(nslots)]
+        self.runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False) for _ in range(nslots)]
         self.gathered = [torch.empty((world * batch, max_det * 6 + 1), dtype=torch.float32, device=self.device)
                          for _ in range(nslots)] if self.gather else None
         self.n = 0

@@ -704,7 +704,8 @@ def _rand_pred(B, rows, nc, seed, ties=False):
     cls = g.uniform(0, 1, (B, rows, nc))
     p = np.concatenate((xy, wh, obj, cls), 2).astype(np.float32)
     if ties:
-        p[:, 50:400, 4:] = p[:, 50:51, 4:]           # many identical scores: order must fall back to the index
+        k = 350 if ties is True else int(ties)
+        p[:, 50:50 + k, 4:] = p[:, 50:51, 4:]        # many identical scores: order must fall back to the index
     return p
 
 
@@ -717,6 +718,13 @@ NMS_CASES = [
     dict(B=2, rows=1500, nc=1, conf=0.1, iou=0.5, ties=True),
     dict(B=2, rows=800, nc=3, conf=0.999, iou=0.5),                           # nothing survives
     dict(B=1, rows=37, nc=2, conf=0.05, iou=0.3, multi_label=True),
+    # the select / gather / sort / walk rounds of nms_walk_kernel (nms.hip):
+    dict(B=2, rows=25200, nc=1, conf=0.001, iou=0.05),                        # aggressive suppression: the walk needs many rounds
+    dict(B=2, rows=9000, nc=1, conf=0.05, iou=0.5, ties=6000),                # 6000 identical scores: one histogram bin > 4096 keys,
+    #                                                                           refined down to the slot-index digits
+    dict(B=2, rows=12000, nc=1, conf=0.05, iou=0.3, near=True),               # 12000 distinct scores inside ONE bin (upper 16 bits equal)
+    dict(B=1, rows=20000, nc=3, conf=0.01, iou=0.2, multi_label=True, ties=9000),   # > max_nms candidates AND a refined bin
+    dict(B=3, rows=1, nc=1, conf=0.1, iou=0.5),                               # a single row
 ]
 
 
@@ -725,8 +733,12 @@ def test_nms_bit_exact(case):
     from icafusion_amd.utils.general import nms_device, non_max_suppression
     c = dict(case)
     B, rows, nc = c.pop("B"), c.pop("rows"), c.pop("nc")
-    conf, iou, ties = c.pop("conf"), c.pop("iou"), c.pop("ties", False)
+    conf, iou, ties, near = c.pop("conf"), c.pop("iou"), c.pop("ties", False), c.pop("near", False)
     pred = _rand_pred(B, rows, nc, seed=rows + nc, ties=ties)
+    if near:                                         # scores in [0.5, 0.5 + 2^-9): same exponent and upper mantissa bits
+        g = np.random.default_rng(9)
+        pred[..., 4] = 1.0
+        pred[..., 5:] = (0.5 + g.uniform(0, 2.0 ** -9, pred[..., 5:].shape)).astype(np.float32)
     ref, ref_idx = oracle.non_max_suppression(pred, conf, iou, return_indices=True, **c)
     pt = torch.from_numpy(pred).to(DEV)
     got = non_max_suppression(pt, conf, iou, **c)
