@@ -158,7 +158,9 @@ def test_detect_twostream_and_test_py_end_to_end(tmp_path):
     import yaml
     from icafusion_amd.models.yolo import Model
     from icafusion_amd.synth import synth_state_dict
-    rgb_dir, ir_dir = make_dataset(str(tmp_path), n=4, size=(96, 128), nc=3, seed=5)
+    # 120x128 / 128x120 images at img-size 320 -> rectangular batches of 320x352 / 352x320: the smallest side must stay >= 320,
+    # or the P5 map (stride 32) has fewer than the DMFF's 10x10 anchors and the model raises — as the reference does
+    rgb_dir, ir_dir = make_dataset(str(tmp_path), n=4, size=(120, 128), nc=3, seed=5)
     cfg_path = os.path.join(REPO, "models", "transformer", "yolov5s_Transfusion_FLIR.yaml")
     opt = dt.parse_opt(["--cfg", cfg_path, "--source1", rgb_dir, "--source2", ir_dir, "--img-size", "320", "--conf-thres", "0.3",
                         "--save-txt", "--save-conf", "--project", str(tmp_path / "runs"), "--name", "exp"])

@@ -110,6 +110,8 @@ def test_plan_cache_does_not_grow_over_many_shapes():
     held by plans stays bounded (VERDICT r1 #10: one never-freed plan per shape, ~40 GB each at 1280x1280 b16)."""
     m = build("yolov5l_Transfusion_kaist.yaml", torch.bfloat16)
     shapes = [(4, 544, 672), (4, 512, 640), (4, 640, 640), (4, 640, 512), (3, 544, 672), (4, 576, 640), (4, 608, 672), (2, 640, 640)]
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()                  # model parameters
     first = m.plan_for(*shapes[0], device=DEV)
     one = first.nbytes
     del first
@@ -121,7 +123,12 @@ def test_plan_cache_does_not_grow_over_many_shapes():
         assert torch.isfinite(z).all()
         held = sum(p.nbytes for p in m._plans.values())
         assert held <= m.plan_cache_bytes and len(m._plans) <= 3
+        del z, rgb, ir
         torch.cuda.synchronize()
-        peak.append(torch.cuda.memory_allocated())
-    assert max(peak[8:]) <= max(peak[:8]) * 1.05, "second pass over the same shapes must not allocate more than the first"
-    assert max(peak) < 6 * one + 2 * 2 ** 30
+        peak.append(torch.cuda.memory_allocated() - base)
+    # live device memory = the cached plans (<= cap) + packed weights (one set per dtype, ~ the parameters again in bf16) + NMS-free
+    # outputs; it must not creep upwards from pass to pass: without the cap the 16 forwards would pin 8 plans (~8 x one)
+    packed = base
+    assert max(peak) <= m.plan_cache_bytes + packed + 0.25 * one, (max(peak), m.plan_cache_bytes, packed, one)
+    assert max(peak[8:]) <= m.plan_cache_bytes + packed + 0.25 * one
+    assert max(peak) < 5 * one

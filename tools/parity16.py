@@ -16,7 +16,9 @@ detections), which raises both errors alike — hence the yardstick is re-measur
 
 Also: mAP@50 of the 16-bit HIP detections vs the fp32 oracle's detections through the same ap_per_class, on (a) random
 synthetic labels and (b) pseudo ground truth cut from the oracle's own strongest detections (mAP far from zero, sensitive
-to box shifts and score re-ordering).
+to box shifts and score re-ordering) — next to the same two numbers for the reference evaluated in the 16-bit type.  With
+random weights thousands of candidates have nearly equal scores, so (b) is a stress test of RANK stability: a score change
+of 5e-3 (bf16) reorders true and false positives and moves AP by points, for the reference's own bf16 mode as for ours.
 
     python tools/parity16.py [--out gpurun_out/parity_16bit.json] [--only c2,c4]      # on the GPU box
 
@@ -74,10 +76,17 @@ def err_stats(z, ref):
             "score_max": float(sc.max()), "score_mean": float(sc.mean())}
 
 
+def _cpu_threads():
+    """torch's CPU kernels oversubscribe badly on these layers with every hardware thread of a 256-thread host (the same
+    observation as bench.py's cpu_baseline): cap the oracle at 32."""
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+
+
 def measure(name):
     """Run one configuration; returns the record written to profiles/parity_16bit.json."""
     from icafusion_amd.synth import synth_images
     from oracle import icaf_oracle as oracle
+    _cpu_threads()
     yaml_name, dtype, B, H, W, loops, pick, seed = CONFIGS[name]
     cfg, fsd, m = build(yaml_name, dtype, loops, seed)
     rgb, ir = synth_images(B, H, W, seed=seed)
@@ -121,13 +130,16 @@ def measure_map(dtype, B=16, H=640, W=640, seed=6, yaml_name="yolov5s_Transfusio
     from icafusion_amd.synth import synth_images, synth_labels
     from icafusion_amd.utils.general import non_max_suppression
     from oracle import icaf_oracle as oracle
+    _cpu_threads()
     cfg, fsd, m = build(yaml_name, dtype, 1, seed)
     nc = cfg["nc"]
     rgb, ir = synth_images(B, H, W, seed=seed)
     zr = oracle.OracleModel(cfg, fsd).forward(rgb, ir)[0].numpy()
+    z16 = oracle.OracleModel(cfg, fsd, dtype=DT[dtype]).forward(rgb, ir)[0].float().numpy()      # the reference in the same 16-bit type
     zg = m(rgb.cuda(), ir.cuda())[0].float()
     dets_g = [d.cpu().numpy() for d in non_max_suppression(zg, 0.001, 0.5, multi_label=True)]
     dets_r = oracle.non_max_suppression(zr, 0.001, 0.5, multi_label=True)
+    dets_16 = oracle.non_max_suppression(z16, 0.001, 0.5, multi_label=True)
     iouv = np.linspace(0.5, 0.95, 10)
     lab = synth_labels(B, nc, seed=seed).numpy()
     gt_rand = [_xyxy(lab[lab[:, 0] == b][:, 1:].copy(), W, H) for b in range(B)]
@@ -140,8 +152,11 @@ def measure_map(dtype, B=16, H=640, W=640, seed=6, yaml_name="yolov5s_Transfusio
     for tag, gts in (("random_labels", gt_rand), ("pseudo_gt", gt_pseudo)):
         a50, a = map_metrics(dets_g, gts, iouv)
         b50, b = map_metrics(dets_r, gts, iouv)
+        c50, c = map_metrics(dets_16, gts, iouv)
         out[tag] = {"map50_hip16": round(a50, 4), "map50_oracle_fp32": round(b50, 4), "map50_delta": round(a50 - b50, 4),
-                    "map_hip16": round(a, 4), "map_oracle_fp32": round(b, 4), "map_delta": round(a - b, 4)}
+                    "map_hip16": round(a, 4), "map_oracle_fp32": round(b, 4), "map_delta": round(a - b, 4),
+                    "map50_reference16": round(c50, 4), "map50_delta_reference16": round(c50 - b50, 4),
+                    "map_reference16": round(c, 4), "map_delta_reference16": round(c - b, 4)}
     del m
     torch.cuda.empty_cache()
     return out
