@@ -50,6 +50,22 @@ class Stem2Args(C.Structure):
                 ("y", C.c_void_p), ("y_gs", C.c_longlong), ("ldy", C.c_int), ("reserved", C.c_int)]
 
 
+class DmffArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("qkv", C.c_void_p), ("y", C.c_void_p),
+                ("wqkv", C.c_void_p), ("bqkv", C.c_void_p), ("wo", C.c_void_p), ("bo", C.c_void_p),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("ln_attn_gamma", C.c_void_p * 2), ("ln_attn_beta", C.c_void_p * 2),
+                ("ln_mlp_gamma", C.c_void_p), ("ln_mlp_beta", C.c_void_p),
+                ("wqkv_gs", C.c_longlong), ("bqkv_gs", C.c_longlong), ("wo_gs", C.c_longlong), ("bo_gs", C.c_longlong),
+                ("w1_gs", C.c_longlong), ("b1_gs", C.c_longlong), ("w2_gs", C.c_longlong), ("b2_gs", C.c_longlong),
+                ("x_gs", C.c_longlong), ("y_gs", C.c_longlong),
+                ("dtype", C.c_int), ("B", C.c_int), ("N", C.c_int), ("C", C.c_int), ("heads", C.c_int), ("Kp", C.c_int),
+                ("Kp4", C.c_int), ("hidden", C.c_int), ("ldy", C.c_int), ("reserved", C.c_int),
+                ("eps_attn", C.c_float), ("eps_mlp", C.c_float),
+                ("coef_res_attn", C.c_float * 2), ("coef_acc_attn", C.c_float * 2),
+                ("coef_res_mlp", C.c_float * 2), ("coef_acc_mlp", C.c_float * 2)]
+
+
 _p, _i, _ll, _f, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 # symbol -> (restype, argtypes); must list every function declared in include/icaf.h
 SIGNATURES = {
@@ -71,6 +87,9 @@ SIGNATURES = {
                                    _f, _f, _f, _f, _p]),
     "icaf_layernorm": (_i, [_p, _p, _p, _p, _p, _p, _i, _ll, _i, _i, _f, _p]),
     "icaf_cross_attention": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "icaf_dmff_ln_qkv": (_i, [C.POINTER(DmffArgs), _p]),
+    "icaf_dmff_attn_mlp": (_i, [C.POINTER(DmffArgs), _p]),
+    "icaf_dmff_attn_mlp_lds_bytes": (_i, [_i, _i, _i, _i, C.POINTER(_sz)]),
     "icaf_dmff_upsample_merge": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_detect_decode": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _ll, _ll, _f, C.POINTER(_f), _p]),
     "icaf_match_predictions": (_i, [_p, _p, _i, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p]),

@@ -1,0 +1,601 @@
+// Fused DMFF block kernels for gfx950 (16-bit types) — one CrossTransformerBlock iteration (reference models/common.py:737-759,
+// CrossAttention :641-687, MLP :704-709) in TWO launches instead of seven:
+//
+//   dmff_ln_qkv_kernel     LayerNorm (CrossAttention.LN1 on RGB tokens, LN2 on IR tokens, :661-662) as the prologue of the
+//                          six Linear(C, C) projections (:664-669) run as one [64 x C] x [C x 3C] GEMM per workgroup.
+//   dmff_attn_mlp_kernel   one workgroup = 64 token rows of one (image, modality):
+//                            A. crossed attention of its rows, all heads (softmax(q_other k^T / sqrt(dk)) v, :670-681), K and
+//                               V^T of two heads at a time in LDS, online softmax in registers (as cross_attn_kernel);
+//                               the heads' outputs land in an LDS tile [64 x C] — never in HBM;
+//                            B. out-projection + coefficient mix  x_att = c_res * x + c_acc * (att W_o^T + b)  (:682-685,:745-746);
+//                            C. the block's shared LayerNorm LN2 over x_att (:749-750), in LDS;
+//                            D. MLP  Linear(C,4C) -> GELU(erf) -> Linear(4C,C)  in 128-column hidden chunks: each chunk is
+//                               produced into LDS and immediately contracted into the output accumulators, so the [64 x 4C]
+//                               hidden tile never exists (:704-709);  x' = c_res2 * x_att + c_acc2 * (mlp + b)  (:751-752).
+//
+// All four GEMMs share one building block (gemm_pass): the 64-row operand tile is RESIDENT in LDS, weights stream from L2
+// through a two-stage LDS ring in 128-byte K slices (global -> registers -> LDS, one LDS-only barrier per slice), MFMA
+// 32x32x16 with the weights as the A operand so that a lane owns 4 consecutive channels of ONE token row — LayerNorm
+// statistics, bias, GELU, the coefficient mixes and the residual are per-lane register work.
+// Rounding points are those of the unfused launches (activations rounded to the storage type between layers, fp32 accumulate).
+// fp32 tokens do not fit this LDS plan; the fp32 parity build keeps the per-layer launches (dmff.hip + igemm.hip).
+#include "icaf_common.h"
+#include "conv_common.h"
+
+namespace icaf {
+
+struct DmffP {
+    const void* x;            // tokens [2][rows][C]: LN + QKV input / residual of the attention mix
+    void* qkv;                // [2][rows][3C]  (q | k | v per modality)
+    void* y;                  // output tokens: element (g, row, c) at y + g * y_gs + row * ldy + c
+    const void* wqkv; const float* bqkv;      // [2][Np][Kp], [2][Np]   rows = (que | key | val) output channels
+    const void* wo; const float* bo;
+    const void* w1; const float* b1;
+    const void* w2; const float* b2;
+    const float* ln_a_g[2]; const float* ln_a_b[2];     // CrossAttention.LN1 (RGB) / LN2 (IR)
+    const float* ln_m_g; const float* ln_m_b;           // CrossTransformerBlock.LN2, shared by both modalities
+    long long wqkv_gs, bqkv_gs, wo_gs, bo_gs, w1_gs, b1_gs, w2_gs, b2_gs, x_gs, y_gs;
+    int B, N, C, heads, dk, Kp, Kp4, hid, ldy;
+    float eps_a, eps_m, scale_l2e;
+    float c_res_a[2], c_acc_a[2], c_res_m[2], c_acc_m[2];
+};
+
+constexpr int FT = 256;              // threads per workgroup (4 wavefronts)
+constexpr int TMROWS = 64;           // token rows per workgroup
+// One ring stage = 128 output channels x SLB bytes of K, rows padded by 16 bytes (odd multiple of 16: conflict-free b128 reads).
+template <int SLB> struct Ring {
+    static constexpr int WROW = SLB + 16;
+    static constexpr int STAGE = 128 * WROW;
+    static constexpr int BYTES = 2 * STAGE;
+};
+
+// acc[t] += W[n0 + wn*64 + t*32 + i][k] * A[wm*32 + j][k]   over K elements; the caller has synchronised the A tile.
+// SLB = 128 (default) or 64 bytes of K per slice (wide tokens: the ring has to share LDS with two [64 x C] tiles).
+template <int DT, int SLB>
+__device__ __forceinline__ void gemm_pass(f32x16 (&acc)[2], const unsigned char* A, int SA, int K,
+                                          const typename Elem<DT>::type* __restrict__ W, long long ldw, unsigned char* ring) {
+    using E = Elem<DT>;
+    using R = Ring<SLB>;
+    constexpr int BKE = SLB / E::BYTES;                 // K elements per slice
+    constexpr int VPR = SLB / 16;                       // 16-byte vectors per row of a slice
+    constexpr int NV = 128 * VPR / FT;                  // vectors per thread per slice
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int nchunks = K / BKE;
+    u32x4 stage[NV];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * FT, row = v / VPR, kv = v % VPR;
+            stage[i] = *(const u32x4*)(W + (long long)row * ldw + (long long)c * BKE + kv * E::VEC);
+        }
+    };
+    auto commit = [&](int c) {
+        unsigned char* buf = ring + (c & 1) * R::STAGE;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * FT, row = v / VPR, kv = v % VPR;
+            *(u32x4*)(buf + row * R::WROW + kv * 16) = stage[i];
+        }
+    };
+    fetch(0);
+    commit(0);
+    lds_barrier();
+    const unsigned char* arow = A + (size_t)(wm * 32 + l31) * SA + hi * 16;
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) fetch(c + 1);
+        const unsigned char* buf = ring + (c & 1) * R::STAGE + (size_t)(wn * 64 + l31) * R::WROW + hi * 16;
+#pragma unroll
+        for (int ks = 0; ks < SLB / 32; ++ks) {
+            const u32x4 xf = *(const u32x4*)(arow + (size_t)c * SLB + ks * 32);
+            const u32x4 w0 = *(const u32x4*)(buf + ks * 32);
+            const u32x4 w1 = *(const u32x4*)(buf + 32 * R::WROW + ks * 32);
+            mma_step<DT>(acc[0], w0, xf);
+            mma_step<DT>(acc[1], w1, xf);
+        }
+        if (c + 1 < nchunks) commit(c + 1);
+        lds_barrier();
+    }
+}
+
+template <int DT> __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
+    u32x2 v;
+    if constexpr (DT == ICAF_BF16) { v[0] = pack2_bf16(a, b); v[1] = pack2_bf16(c, d); }
+    else { v[0] = pack2_f16(a, b); v[1] = pack2_f16(c, d); }
+    return v;
+}
+template <int DT> __device__ __forceinline__ void unpack4(const u32x2& v, float* f) {
+    if constexpr (DT == ICAF_BF16) {
+        f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xffff0000u);
+        f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xffff0000u);
+    } else {
+        f[0] = f16_to_f32((unsigned short)(v[0] & 0xffffu)); f[1] = f16_to_f32((unsigned short)(v[0] >> 16));
+        f[2] = f16_to_f32((unsigned short)(v[1] & 0xffffu)); f[3] = f16_to_f32((unsigned short)(v[1] >> 16));
+    }
+}
+
+// LayerNorm of the 64 rows of an LDS tile (row stride S bytes, C channels), in place or into `dst`: 4 threads per row,
+// two-pass statistics in fp32 on the stored (16-bit) values, exactly the arithmetic of layernorm_kernel (dmff.hip).
+template <int DT>
+__device__ __forceinline__ void tile_layernorm(const unsigned char* src, unsigned char* dst, int S, int C, const float* __restrict__ gam,
+                                               const float* __restrict__ bet, float eps) {
+    using E = Elem<DT>;
+    const int tid = threadIdx.x, row = tid >> 2, part = tid & 3;
+    const int nv = C / E::VEC;                           // 16-byte vectors per row; vectors part, part+4, ... belong to this thread
+    const unsigned char* r = src + (size_t)row * S;
+    float s = 0.0f;
+    for (int v = part; v < nv; v += 4) {
+        float t[E::VEC];
+        unpack16<DT>(*(const u32x4*)(r + v * 16), t);
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) s += t[j];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    const float mean = s / (float)C;
+    float q = 0.0f;
+    for (int v = part; v < nv; v += 4) {
+        float t[E::VEC];
+        unpack16<DT>(*(const u32x4*)(r + v * 16), t);
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) { const float d = t[j] - mean; q += d * d; }
+    }
+    q += __shfl_xor(q, 1);
+    q += __shfl_xor(q, 2);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    unsigned char* w = dst + (size_t)row * S;
+    for (int v = part; v < nv; v += 4) {
+        float t[E::VEC], o[E::VEC];
+        unpack16<DT>(*(const u32x4*)(r + v * 16), t);
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) o[j] = (t[j] - mean) * rstd * gam[v * E::VEC + j] + bet[v * E::VEC + j];
+        *(u32x4*)(w + v * 16) = pack16<DT>(o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm + QKV projection.  grid = (ceil(rows / 64), 2 modalities)
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT, int SLB>
+__global__ __launch_bounds__(FT) void dmff_ln_qkv_kernel(const DmffP p) {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = p.C, SA = C * E::BYTES + 16;
+    unsigned char* tile = smem;                                  // [64][SA]
+    unsigned char* ring = smem + (size_t)TMROWS * SA;            // Ring<SLB>::BYTES
+    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const long long rows = (long long)p.B * p.N, r0 = (long long)blockIdx.x * TMROWS;
+    const T* xg = (const T*)p.x + g * p.x_gs;
+    const int nv = C / E::VEC;
+    for (int idx = tid; idx < TMROWS * nv; idx += FT) {          // raw tokens -> LDS (rows beyond the tensor: clamped, never stored)
+        const int row = idx / nv, v = idx - row * nv;
+        long long r = r0 + row;
+        r = r < rows ? r : rows - 1;
+        *(u32x4*)(tile + (size_t)row * SA + v * 16) = *(const u32x4*)(xg + r * C + v * E::VEC);
+    }
+    __syncthreads();
+    tile_layernorm<DT>(tile, tile, SA, C, p.ln_a_g[g], p.ln_a_b[g], p.eps_a);
+    __syncthreads();
+    const T* W = (const T*)p.wqkv + g * p.wqkv_gs;
+    const float* bias = p.bqkv + g * p.bqkv_gs;
+    T* out = (T*)p.qkv + (long long)g * rows * 3 * C;
+    const int nout = 3 * C;
+    const long long row = r0 + wm * 32 + l31;
+    for (int n0 = 0; n0 < nout; n0 += 128) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        gemm_pass<DT, SLB>(acc, tile, SA, C, W + (long long)n0 * p.Kp, p.Kp, ring);
+        if (row < rows) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + t * 32 + 8 * q + 4 * hi;
+                    if (n < nout) {
+                        const f32x4 b = *(const f32x4*)(bias + n);
+                        *(u32x2*)(out + row * nout + n) = pack4<DT>(acc[t][4 * q] + b[0], acc[t][4 * q + 1] + b[1], acc[t][4 * q + 2] + b[2],
+                                                                    acc[t][4 * q + 3] + b[3]);
+                    }
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// attention + out-projection + LayerNorm + MLP.  grid = (ceil(N / 64), B, 2 directions)
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT> __device__ __forceinline__ int vt_phys16(int key) {
+    const int k16 = key & 15;
+    return (key & ~15) + (((k16 >> 2) & 1) << 3) + (k16 & 3) + ((k16 >> 3) << 2);
+}
+template <int DT> __device__ __forceinline__ u32x4 pack_p16(const f32x16& s, int st) {
+    u32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if constexpr (DT == ICAF_BF16) v[e] = pack2_bf16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
+        else v[e] = pack2_f16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
+    }
+    return v;
+}
+
+template <int DT, int DKP, int NP2>
+__global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
+    constexpr int SLB = NP2 >= 4 ? 64 : 128;           // C >= 512: two [64 x C] tiles leave room for 64-byte ring slices only
+    using E = Elem<DT>;
+    using T = typename E::type;
+    constexpr int VEC = E::VEC, EB = E::BYTES;
+    constexpr int KSTEP = 2 * VEC, QSTEPS = DKP / KSTEP, TD = (DKP + 31) / 32, PSTEPS = 32 / KSTEP;
+    constexpr int KS = DKP * EB + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = p.C, N = p.N, DK = p.dk, NP = (N + 31) & ~31;
+    const int SA = C * EB + 16, VS = NP * EB + 16;
+    const size_t tile_bytes = (size_t)TMROWS * SA;
+    constexpr int SH = 128 * EB + 16;
+    const size_t hb_bytes = (size_t)TMROWS * SH;
+    unsigned char* T0 = smem;                        // attention output -> later the LayerNorm'ed MLP input
+    unsigned char* U = smem + tile_bytes;            // union: {K, V^T of two heads}  |  {T1 = x_att (phase B, C), H = hidden chunk (phase D); weight ring}
+    const size_t kv_head = (size_t)NP * KS + (size_t)DKP * VS;
+    unsigned char* T1 = U;
+    unsigned char* Hb = U;                           // x_att moves to registers before the MLP, its tile becomes the hidden chunk
+    unsigned char* ring = U + (tile_bytes > hb_bytes ? tile_bytes : hb_bytes);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int dir = blockIdx.z, b = blockIdx.y, q0 = blockIdx.x * TMROWS;
+    const long long rows = (long long)p.B * N, row3 = 3LL * C;
+    const T* qkv = (const T*)p.qkv;
+    const T* kvb = qkv + ((long long)dir * rows + (long long)b * N) * row3;
+    const T* qb = qkv + ((long long)(1 - dir) * rows + (long long)b * N) * row3;
+
+    // ---- A. attention: two heads per round (wave pair = head, wave parity = 32-query tile) ----------------------
+    {
+        const int hsel = wave >> 1, qt = wave & 1;
+        const int q = q0 + qt * 32 + l31;
+        const bool qok = q < N;
+        const int nkt = NP >> 5;
+        constexpr int NVK = DKP / VEC;
+        for (int h0 = 0; h0 < p.heads; h0 += 2) {
+            if (h0) __syncthreads();                       // previous round's K / V^T are free again
+            for (int hh = 0; hh < 2; ++hh) {
+                if (h0 + hh >= p.heads) break;
+                unsigned char* Ks = U + hh * kv_head;
+                unsigned char* Vt = Ks + (size_t)NP * KS;
+                const T* base = kvb + (long long)(h0 + hh) * DK;
+                for (int idx = tid; idx < NP * NVK; idx += FT) {
+                    const int key = idx / NVK, v = idx - key * NVK;
+                    u32x4 kvv = {0u, 0u, 0u, 0u}, vvv = {0u, 0u, 0u, 0u};
+                    if (key < N && v * VEC < DK) {
+                        kvv = *(const u32x4*)(base + key * row3 + C + v * VEC);
+                        vvv = *(const u32x4*)(base + key * row3 + 2 * C + v * VEC);
+                    }
+                    *(u32x4*)(Ks + (size_t)key * KS + v * 16) = kvv;
+                    const int pk = vt_phys16<DT>(key);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        *(unsigned short*)(Vt + (size_t)(v * 8 + j) * VS + pk * 2) = (unsigned short)((vvv[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+                }
+            }
+            __syncthreads();
+            const int h = h0 + hsel;
+            if (h < p.heads) {
+                const unsigned char* Ks = U + hsel * kv_head;
+                const unsigned char* Vt = Ks + (size_t)NP * KS;
+                u32x4 qf[QSTEPS];
+#pragma unroll
+                for (int st = 0; st < QSTEPS; ++st) {
+                    const int off = st * KSTEP + hi * VEC;
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (qok && off < DK) v = *(const u32x4*)(qb + (long long)q * row3 + (long long)h * DK + off);
+                    qf[st] = v;
+                }
+                float m = -INFINITY, l = 0.0f;
+                f32x16 o[TD];
+#pragma unroll
+                for (int td = 0; td < TD; ++td)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[td][r] = 0.0f;
+                for (int kt = 0; kt < nkt; ++kt) {
+                    f32x16 s;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+                    for (int st = 0; st < QSTEPS; ++st) {
+                        const u32x4 kf = *(const u32x4*)(Ks + (size_t)(kt * 32 + l31) * KS + st * 32 + hi * 16);
+                        mma_step<DT>(s, kf, qf[st]);
+                    }
+                    if (kt == nkt - 1 && NP != N) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            s[r] = key < N ? s[r] : -INFINITY;
+                        }
+                    }
+                    float tmax = s[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                    const float m_new = fmaxf(m, tmax);
+                    const float mc = m_new * p.scale_l2e;
+                    float psum = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.scale_l2e, -mc));
+                        s[r] = pv;
+                        psum += pv;
+                    }
+                    if (!__all(m_new == m)) {
+                        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * p.scale_l2e);
+                        l *= alpha;
+#pragma unroll
+                        for (int td = 0; td < TD; ++td)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
+                        m = m_new;
+                    }
+                    l += psum;
+#pragma unroll
+                    for (int st = 0; st < PSTEPS; ++st) {
+                        const u32x4 pf = pack_p16<DT>(s, st);
+#pragma unroll
+                        for (int td = 0; td < TD; ++td) {
+                            int drow = td * 32 + l31;
+                            drow = drow < DKP ? drow : DKP - 1;
+                            const u32x4 vf = *(const u32x4*)(Vt + (size_t)drow * VS + (size_t)(kt * 32 + st * KSTEP + hi * VEC) * EB);
+                            mma_step<DT>(o[td], vf, pf);
+                        }
+                    }
+                }
+                l += __shfl_xor(l, 32);
+                const float inv = qok ? 1.0f / l : 0.0f;
+                unsigned char* orow = T0 + (size_t)(qt * 32 + l31) * SA + (size_t)h * DK * EB;
+#pragma unroll
+                for (int td = 0; td < TD; ++td)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int d0 = td * 32 + 8 * g4 + 4 * hi;
+                        if (d0 < DK)
+                            *(u32x2*)(orow + d0 * EB) = pack4<DT>(o[td][4 * g4] * inv, o[td][4 * g4 + 1] * inv, o[td][4 * g4 + 2] * inv,
+                                                                   o[td][4 * g4 + 3] * inv);
+                    }
+            }
+        }
+    }
+    __syncthreads();              // T0 = attention output of the 64 rows; the K / V^T region is free
+
+    // ---- B. out-projection + coefficient mix -> T1 = x_att (storage type, as the unfused launch stores it) --------
+    const int wm = wave & 1, wn = wave >> 1;
+    const int lrow = wm * 32 + l31;                        // local token row of this lane
+    const int tok = q0 + lrow;
+    const bool rok = tok < N;
+    const long long grow = (long long)b * N + (rok ? tok : N - 1);      // clamped global row (loads only)
+    const T* xres = (const T*)p.x + dir * p.x_gs + grow * C;
+    {
+        const T* W = (const T*)p.wo + dir * p.wo_gs;
+        const float* bias = p.bo + dir * p.bo_gs;
+        const float ca = p.c_acc_a[dir], cr = p.c_res_a[dir];
+        for (int n0 = 0; n0 < C; n0 += 128) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+            gemm_pass<DT, SLB>(acc, T0, SA, C, W + (long long)n0 * p.Kp, p.Kp, ring);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + t * 32 + 8 * q + 4 * hi;
+                    if (n < C) {
+                        const f32x4 bv = *(const f32x4*)(bias + n);
+                        float rv[4];
+                        unpack4<DT>(*(const u32x2*)(xres + n), rv);
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (acc[t][4 * q + j] + bv[j]) * ca);
+                        *(u32x2*)(T1 + (size_t)lrow * SA + n * EB) = pack4<DT>(v[0], v[1], v[2], v[3]);
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    // ---- C. shared LayerNorm: T1 (x_att) -> T0 (MLP input); this lane's x_att values move to registers (packed), in the
+    //         accumulator layout of the output passes, because the tile becomes the hidden-chunk buffer of the MLP ---------
+    tile_layernorm<DT>(T1, T0, SA, C, p.ln_m_g, p.ln_m_b, p.eps_m);
+    u32x2 xatt[NP2][2][4];
+#pragma unroll
+    for (int i = 0; i < NP2; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = i * 128 + wn * 64 + t * 32 + 8 * q + 4 * hi;
+                xatt[i][t][q] = n < C ? *(const u32x2*)(T1 + (size_t)lrow * SA + n * EB) : u32x2{0u, 0u};
+            }
+    __syncthreads();
+    // ---- D. MLP in 128-column hidden chunks ----------------------------------------------------------------------------
+    f32x16 acc2[NP2][2];
+#pragma unroll
+    for (int i = 0; i < NP2; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][t][r] = 0.0f;
+    {
+        const T* W1 = (const T*)p.w1 + dir * p.w1_gs;
+        const T* W2 = (const T*)p.w2 + dir * p.w2_gs;
+        const float* b1 = p.b1 + dir * p.b1_gs;
+        for (int hc = 0; hc < p.hid; hc += 128) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+            gemm_pass<DT, SLB>(acc, T0, SA, C, W1 + (long long)hc * p.Kp, p.Kp, ring);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nl = wn * 64 + t * 32 + 8 * q + 4 * hi;          // column inside the chunk
+                    const f32x4 bv = *(const f32x4*)(b1 + hc + nl);
+                    *(u32x2*)(Hb + (size_t)lrow * SH + nl * EB) = pack4<DT>(gelu_f(acc[t][4 * q] + bv[0]), gelu_f(acc[t][4 * q + 1] + bv[1]),
+                                                                            gelu_f(acc[t][4 * q + 2] + bv[2]), gelu_f(acc[t][4 * q + 3] + bv[3]));
+                }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NP2; ++i)
+                if (i * 128 < C) gemm_pass<DT, SLB>(acc2[i], Hb, SH, 128, W2 + (long long)(i * 128) * p.Kp4 + hc, p.Kp4, ring);
+            // (gemm_pass ends with a barrier: every wave is done with Hb before the next chunk overwrites it)
+        }
+    }
+    // ---- output: x' = c_res2 * x_att + c_acc2 * (mlp + b2) ----------------------------------------------------------
+    if (rok) {
+        const float* b2 = p.b2 + dir * p.b2_gs;
+        const float ca = p.c_acc_m[dir], cr = p.c_res_m[dir];
+        T* yrow = (T*)p.y + dir * p.y_gs + ((long long)b * N + tok) * p.ldy;
+#pragma unroll
+        for (int i = 0; i < NP2; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = i * 128 + wn * 64 + t * 32 + 8 * q + 4 * hi;
+                    if (n < C) {
+                        const f32x4 bv = *(const f32x4*)(b2 + n);
+                        float rv[4];
+                        unpack4<DT>(xatt[i][t][q], rv);
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (acc2[i][t][4 * q + j] + bv[j]) * ca);
+                        *(u32x2*)(yrow + n) = pack4<DT>(v[0], v[1], v[2], v[3]);
+                    }
+                }
+    }
+}
+
+static size_t attn_mlp_lds(int C, int N, int dkp, int eb) {
+    const int NP = (N + 31) & ~31;
+    const size_t tile = (size_t)TMROWS * (C * eb + 16), hb = (size_t)TMROWS * (128 * eb + 16);
+    const size_t kv2 = 2 * ((size_t)NP * (dkp * eb + 16) + (size_t)dkp * (NP * eb + 16));
+    const size_t ring = (C + 127) / 128 >= 4 ? Ring<64>::BYTES : Ring<128>::BYTES;     // as the kernel: NP2 >= 4 (C > 384) -> 64-byte slices
+    const size_t chain = (tile > hb ? tile : hb) + ring;
+    return tile + (kv2 > chain ? kv2 : chain);
+}
+
+template <int DT, int DKP, int NP2>
+static int launch_attn_mlp(const DmffP& p, hipStream_t s) {
+    const size_t lds = attn_mlp_lds(p.C, p.N, DKP, Elem<DT>::BYTES);
+    if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_attn_mlp: %zu bytes of LDS (C=%d, N=%d, dk=%d) exceed 160 KiB", lds, p.C, p.N, p.dk);
+    static bool attr_set[ICAF_MAX_DEVICES] = {};
+    int dev = 0;
+    ICAF_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= ICAF_MAX_DEVICES) return fail(ICAF_ERR_UNSUPPORTED, "device ordinal %d", dev);
+    if (!attr_set[dev]) {
+        ICAF_HIP(hipFuncSetAttribute((const void*)dmff_attn_mlp_kernel<DT, DKP, NP2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[dev] = true;
+    }
+    dim3 grid((unsigned)((p.N + TMROWS - 1) / TMROWS), (unsigned)p.B, 2u);
+    hipLaunchKernelGGL((dmff_attn_mlp_kernel<DT, DKP, NP2>), grid, dim3(FT), lds, s, p);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+template <int DT, int DKP>
+static int dispatch_np2(const DmffP& p, hipStream_t s) {
+    const int np2 = (p.C + 127) / 128;
+    if (np2 <= 1) return launch_attn_mlp<DT, DKP, 1>(p, s);
+    if (np2 <= 2) return launch_attn_mlp<DT, DKP, 2>(p, s);
+    if (np2 <= 3) return launch_attn_mlp<DT, DKP, 3>(p, s);
+    if (np2 <= 4) return launch_attn_mlp<DT, DKP, 4>(p, s);
+    return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_attn_mlp: C=%d > 512 (two [64 x C] token tiles exceed the LDS)", p.C);
+}
+
+template <int DT>
+static int dispatch_attn_mlp(const DmffP& p, hipStream_t s) {
+    if (p.dk <= 16) return dispatch_np2<DT, 16>(p, s);
+    if (p.dk <= 32) return dispatch_np2<DT, 32>(p, s);
+    if (p.dk <= 48) return dispatch_np2<DT, 48>(p, s);
+    if (p.dk <= 64) return dispatch_np2<DT, 64>(p, s);
+    if (p.dk <= 96) return dispatch_np2<DT, 96>(p, s);
+    if (p.dk <= 128) return dispatch_np2<DT, 128>(p, s);
+    return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_attn_mlp: head dim %d > 128", p.dk);
+}
+
+template <int DT, int SLB>
+static int launch_ln_qkv_t(const DmffP& p, hipStream_t s) {
+    const size_t lds = (size_t)TMROWS * (p.C * Elem<DT>::BYTES + 16) + Ring<SLB>::BYTES;
+    if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_ln_qkv: C=%d too wide", p.C);
+    static bool attr_set[ICAF_MAX_DEVICES] = {};
+    int dev = 0;
+    ICAF_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= ICAF_MAX_DEVICES) return fail(ICAF_ERR_UNSUPPORTED, "device ordinal %d", dev);
+    if (!attr_set[dev]) {
+        ICAF_HIP(hipFuncSetAttribute((const void*)dmff_ln_qkv_kernel<DT, SLB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[dev] = true;
+    }
+    const long long rows = (long long)p.B * p.N;
+    dim3 grid((unsigned)((rows + TMROWS - 1) / TMROWS), 2u);
+    hipLaunchKernelGGL((dmff_ln_qkv_kernel<DT, SLB>), grid, dim3(FT), lds, s, p);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+template <int DT>
+static int launch_ln_qkv(const DmffP& p, hipStream_t s) {
+    return p.C > 768 ? launch_ln_qkv_t<DT, 64>(p, s) : launch_ln_qkv_t<DT, 128>(p, s);
+}
+
+static int fill(const icaf_dmff_args* a, DmffP& p, const char* who) {
+    if (!a || !a->x || !a->qkv || !a->wqkv || !a->bqkv) return fail(ICAF_ERR_ARG, "%s: null pointer", who);
+    if (a->dtype != ICAF_BF16 && a->dtype != ICAF_F16) return fail(ICAF_ERR_UNSUPPORTED, "%s: 16-bit token types only (the fp32 build uses the per-layer launches)", who);
+    if (a->B < 1 || a->N < 1 || a->heads < 1 || a->C % a->heads || a->B > 65535) return fail(ICAF_ERR_ARG, "%s: bad B/N/heads", who);
+    if (a->C % 64 || a->C > 1024) return fail(ICAF_ERR_UNSUPPORTED, "%s: C=%d must be a multiple of 64 and <= 1024", who, a->C);
+    if ((a->C / a->heads) % 8) return fail(ICAF_ERR_UNSUPPORTED, "%s: head dim %d must be a multiple of 8", who, a->C / a->heads);
+    if (a->Kp < a->C || a->Kp % 64) return fail(ICAF_ERR_ARG, "%s: Kp=%d", who, a->Kp);
+    p.x = a->x; p.qkv = a->qkv; p.y = a->y;
+    p.wqkv = a->wqkv; p.bqkv = a->bqkv; p.wo = a->wo; p.bo = a->bo; p.w1 = a->w1; p.b1 = a->b1; p.w2 = a->w2; p.b2 = a->b2;
+    p.ln_a_g[0] = a->ln_attn_gamma[0]; p.ln_a_g[1] = a->ln_attn_gamma[1]; p.ln_a_b[0] = a->ln_attn_beta[0]; p.ln_a_b[1] = a->ln_attn_beta[1];
+    p.ln_m_g = a->ln_mlp_gamma; p.ln_m_b = a->ln_mlp_beta;
+    p.wqkv_gs = a->wqkv_gs; p.bqkv_gs = a->bqkv_gs; p.wo_gs = a->wo_gs; p.bo_gs = a->bo_gs; p.w1_gs = a->w1_gs; p.b1_gs = a->b1_gs;
+    p.w2_gs = a->w2_gs; p.b2_gs = a->b2_gs; p.x_gs = a->x_gs; p.y_gs = a->y_gs;
+    p.B = a->B; p.N = a->N; p.C = a->C; p.heads = a->heads; p.dk = a->C / a->heads; p.Kp = a->Kp; p.Kp4 = a->Kp4; p.hid = a->hidden; p.ldy = a->ldy;
+    p.eps_a = a->eps_attn; p.eps_m = a->eps_mlp;
+    p.scale_l2e = (float)((1.0 / sqrt((double)p.dk)) * 1.4426950408889634);
+    for (int g = 0; g < 2; ++g) {
+        p.c_res_a[g] = a->coef_res_attn[g]; p.c_acc_a[g] = a->coef_acc_attn[g];
+        p.c_res_m[g] = a->coef_res_mlp[g]; p.c_acc_m[g] = a->coef_acc_mlp[g];
+    }
+    return ICAF_OK;
+}
+
+}  // namespace icaf
+
+using namespace icaf;
+
+extern "C" int icaf_dmff_attn_mlp_lds_bytes(int C, int N, int heads, int dtype, size_t* bytes) {
+    if (!bytes || heads < 1 || C % heads) return fail(ICAF_ERR_ARG, "icaf_dmff_attn_mlp_lds_bytes: bad arguments");
+    const int dk = C / heads;
+    const int dkp = dk <= 16 ? 16 : dk <= 32 ? 32 : dk <= 48 ? 48 : dk <= 64 ? 64 : dk <= 96 ? 96 : 128;
+    *bytes = (dtype == ICAF_BF16 || dtype == ICAF_F16) && C % 64 == 0 && C <= 512 && dk % 8 == 0 && dk <= 128 ? attn_mlp_lds(C, N, dkp, 2) : (size_t)-1;
+    return ICAF_OK;
+}
+
+extern "C" int icaf_dmff_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s) {
+    DmffP p;
+    int st = fill(a, p, "icaf_dmff_ln_qkv");
+    if (st) return st;
+    if (!a->ln_attn_gamma[0] || !a->ln_attn_gamma[1] || !a->ln_attn_beta[0] || !a->ln_attn_beta[1]) return fail(ICAF_ERR_ARG, "icaf_dmff_ln_qkv: LayerNorm parameters missing");
+    return a->dtype == ICAF_BF16 ? launch_ln_qkv<ICAF_BF16>(p, S(s)) : launch_ln_qkv<ICAF_F16>(p, S(s));
+}
+
+extern "C" int icaf_dmff_attn_mlp(const icaf_dmff_args* a, icaf_stream_t s) {
+    DmffP p;
+    int st = fill(a, p, "icaf_dmff_attn_mlp");
+    if (st) return st;
+    if (!a->y || !a->wo || !a->bo || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ln_mlp_gamma || !a->ln_mlp_beta) return fail(ICAF_ERR_ARG, "icaf_dmff_attn_mlp: null pointer");
+    if (a->hidden % 128 || a->hidden < 128 || a->Kp4 < a->hidden || a->Kp4 % 64) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_attn_mlp: hidden width %d must be a multiple of 128", a->hidden);
+    if (a->ldy < a->C || a->ldy % 4) return fail(ICAF_ERR_ARG, "icaf_dmff_attn_mlp: ldy=%d", a->ldy);
+    return a->dtype == ICAF_BF16 ? dispatch_attn_mlp<ICAF_BF16>(p, S(s)) : dispatch_attn_mlp<ICAF_F16>(p, S(s));
+}

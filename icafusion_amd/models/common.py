@@ -723,6 +723,15 @@ class CrossTransformerBlock(HipModule):
                             cin, cout, act, res=rows_act(res, cout) if res is not None else None,
                             alpha_acc=alpha_acc, alpha_res=alpha_res, groups=2, group_strides=gs, name=name))
 
+    fuse_block = True    # 16-bit types: one iteration = icaf_dmff_ln_qkv + icaf_dmff_attn_mlp (2 launches) instead of 7
+
+    def fusable(self, plan, C, N):
+        hid, h = self.mlp_vis[0].out_features, self.crossatt.h
+        return (self.fuse_block and plan.dtype in (torch.bfloat16, torch.float16) and C % 64 == 0 and (C // h) % 8 == 0
+                and hid % 128 == 0 and self.mlp_vis[2].in_features == hid
+                and (plan.device.type != "cuda" or ops.dmff_fused_lds_bytes(C, N, h, plan.dtype) is not None)
+                and (plan.device.type == "cuda" or C <= 512))
+
     def emit_tokens(self, plan, tok, B, N, final_out=None):
         """tok: (2, B*N, C) [0]=RGB [1]=IR -> same shape after `loops` shared-weight iterations.  final_out: optional
         (2, B*N, C) view (any row / group strides) that the last iteration writes instead of a fresh buffer."""
@@ -732,6 +741,17 @@ class CrossTransformerBlock(HipModule):
         co, ln = p["co"], p["ln"]
         hid = self.mlp_vis[0].out_features
         nloops = int(self.loops)
+        if self.fusable(plan, C, N):
+            # fused block (dmff_fused.hip): LayerNorm + QKV, then attention + out-projection + LayerNorm + MLP; attention output,
+            # x_att, the normalised tile and the hidden activations never reach HBM
+            coef = dict(co=co, hidden=hid)
+            qkv = plan.tokens(2, rows, 3 * C)
+            for it in range(nloops):
+                plan.add(ops.dmff_ln_qkv(tok, qkv, p, ln, coef, p["eps"], B, N, self.crossatt.h))
+                nxt = final_out if (final_out is not None and it == nloops - 1) else plan.tokens(2, rows, C)
+                plan.add(ops.dmff_attn_mlp(tok, qkv, nxt, p, ln, coef, p["eps"], B, N, self.crossatt.h))
+                tok = nxt
+            return tok
         for it in range(nloops):
             n1 = plan.tokens(2, rows, C)
             plan.add(ops.layernorm(tok, n1, ln["a1w"], ln["a1b"], ln["a2w"], ln["a2b"], p["eps"][0], name="ln_attn"))

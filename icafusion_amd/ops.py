@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import BneckArgs, ConvArgs, Stem2Args, check, lib, F32, BF16, F16, ACT_NONE, ACT_SILU, ACT_GELU  # noqa: F401
+from ._lib import BneckArgs, ConvArgs, DmffArgs, Stem2Args, check, lib, F32, BF16, F16, ACT_NONE, ACT_SILU, ACT_GELU  # noqa: F401
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 VEC = {torch.float32: 4, torch.bfloat16: 8, torch.float16: 8}     # elements per 16-byte vector
@@ -458,6 +458,66 @@ def cross_attention(qkv, out, B, N, heads, name="cross_attention"):
     nb = (qkv.numel() + out.numel()) * qkv.element_size()
     return Launch(lib().icaf_cross_attention, (qkv.data_ptr(), out.data_ptr(), dtype_code(qkv.dtype), B, N, Cc,
                                                heads), keep=(qkv, out), name=name, flops=flops, nbytes=nb)
+
+
+def dmff_fused_lds_bytes(C_, N, heads, dt):
+    """LDS bytes one icaf_dmff_attn_mlp workgroup needs for this shape, or None when the fused block kernels do not cover it."""
+    if dt not in (torch.bfloat16, torch.float16):
+        return None
+    sz = C.c_size_t(0)
+    check(lib().icaf_dmff_attn_mlp_lds_bytes(int(C_), int(N), int(heads), dtype_code(dt), C.byref(sz)), "dmff_attn_mlp_lds_bytes")
+    return None if sz.value == C.c_size_t(-1).value or sz.value > 160 * 1024 else sz.value
+
+
+def _dmff_args(x, qkv, y, packs, ln, coef, eps, B, N, heads):
+    """icaf_dmff_args for one block iteration.  x: (2, B*N, C) contiguous tokens; qkv: (2, B*N, 3C); y: (2, B*N, C) view with
+    any group / row stride; packs = dict(qkv=, out=, fc1=, fc2=) of (weights [2][Np][Kp], Kp, bias [2][Np]) stacks."""
+    G, rows, Cc = x.shape
+    assert G == 2 and rows == B * N and x.is_contiguous() and qkv.shape == (2, rows, 3 * Cc) and qkv.is_contiguous()
+    a = DmffArgs()
+    a.x, a.qkv = x.data_ptr(), qkv.data_ptr()
+    a.x_gs = x.stride(0)
+    if y is not None:
+        assert y.shape == (2, rows, Cc) and y.stride(2) == 1 and y.dtype == x.dtype
+        a.y, a.y_gs, a.ldy = y.data_ptr(), y.stride(0), y.stride(1)
+    for name, key in (("wqkv", "qkv"), ("wo", "out"), ("w1", "fc1"), ("w2", "fc2")):
+        w, kp, b = packs[key]
+        assert w.dtype == x.dtype and w.dim() == 3 and b.dim() == 2
+        setattr(a, name, w.data_ptr()); setattr(a, "b" + name[1:], b.data_ptr())
+        setattr(a, name + "_gs", w.stride(0)); setattr(a, "b" + name[1:] + "_gs", b.stride(0))
+    a.Kp, a.Kp4 = packs["qkv"][1], packs["fc2"][1]
+    assert packs["out"][1] == a.Kp and packs["fc1"][1] == a.Kp
+    a.hidden = coef["hidden"]
+    a.ln_attn_gamma[0], a.ln_attn_gamma[1] = ln["a1w"].data_ptr(), ln["a2w"].data_ptr()
+    a.ln_attn_beta[0], a.ln_attn_beta[1] = ln["a1b"].data_ptr(), ln["a2b"].data_ptr()
+    a.ln_mlp_gamma, a.ln_mlp_beta = ln["mw"].data_ptr(), ln["mb"].data_ptr()
+    a.dtype, a.B, a.N, a.C, a.heads = dtype_code(x.dtype), B, N, Cc, heads
+    a.eps_attn, a.eps_mlp = float(eps[0]), float(eps[2])
+    co = coef["co"]
+    a.coef_res_attn[0], a.coef_res_attn[1] = co[0], co[2]
+    a.coef_acc_attn[0], a.coef_acc_attn[1] = co[1], co[3]
+    a.coef_res_mlp[0], a.coef_res_mlp[1] = co[4], co[6]
+    a.coef_acc_mlp[0], a.coef_acc_mlp[1] = co[5], co[7]
+    return a
+
+
+def dmff_ln_qkv(x, qkv, packs, ln, coef, eps, B, N, heads, name="dmff_ln_qkv"):
+    """LayerNorm + the six Linear(C, C) projections of CrossAttention as one launch (icaf_dmff_ln_qkv)."""
+    a = _dmff_args(x, qkv, None, packs, ln, coef, eps, B, N, heads)
+    rows, Cc = x.shape[1], x.shape[2]
+    es = x.element_size()
+    return Launch(lib().icaf_dmff_ln_qkv, (C.byref(a),), keep=(a, x, qkv, packs, ln), name=name, flops=2.0 * 2 * rows * Cc * 3 * Cc,
+                  nbytes=2 * (rows * Cc * es + 3 * Cc * Cc * es + rows * 3 * Cc * es))
+
+
+def dmff_attn_mlp(x, qkv, y, packs, ln, coef, eps, B, N, heads, name="dmff_attn_mlp"):
+    """Crossed attention + out-projection + LayerNorm + MLP of one block iteration as one launch (icaf_dmff_attn_mlp)."""
+    a = _dmff_args(x, qkv, y, packs, ln, coef, eps, B, N, heads)
+    rows, Cc = x.shape[1], x.shape[2]
+    es, hid = x.element_size(), coef["hidden"]
+    flops = 2.0 * (B * heads * 4.0 * N * N * (Cc // heads)) + 2.0 * 2 * rows * (Cc * Cc + 2 * Cc * hid)
+    nbytes = 2 * (rows * 3 * Cc * es + 2 * rows * Cc * es + (Cc * Cc + 2 * Cc * hid) * es)
+    return Launch(lib().icaf_dmff_attn_mlp, (C.byref(a),), keep=(a, x, qkv, y, packs, ln), name=name, flops=flops, nbytes=nbytes)
 
 
 def dmff_upsample_merge(tokens, fea_rgb, fea_ir, out, th, tw, name="dmff_upsample_merge"):

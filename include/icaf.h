@@ -217,6 +217,38 @@ int icaf_detect_decode(const float* p, int ldp, float* z, float* logits, float* 
                        int no, long long rows_total, long long row_offset, float stride, const float* anchors_px,
                        icaf_stream_t s);
 
+/* ---- fused DMFF block (16-bit token types) -------------------------------------------------------------------
+ * One CrossTransformerBlock iteration (models/common.py:737-759) in two launches:
+ *   icaf_dmff_ln_qkv    qkv[g] = LayerNorm_g(x[g]) W_qkv,g^T + b   — CrossAttention.LN1 / LN2 (:661-662) fused in front of the
+ *                       six Linear(C, C) projections (:664-669); qkv[g][row][3C] = [que | key | val] of modality g.
+ *   icaf_dmff_attn_mlp  per 64 token rows of one (image, modality g): the crossed attention of those rows over all heads
+ *                       (softmax(q_{1-g} k_g^T / sqrt(dk)) v_g, :670-681), out-projection and coefficient mix
+ *                       x_att = coef_res_attn[g] * x + coef_acc_attn[g] * (att W_o,g^T + b) (:682-685, :745-746), the block's shared
+ *                       LayerNorm LN2 (:749-750), MLP Linear(C, 4C) -> GELU(erf) -> Linear(4C, C) (:704-709) and
+ *                       y = coef_res_mlp[g] * x_att + coef_acc_mlp[g] * (mlp + b) (:751-752).  Attention output, x_att, the
+ *                       normalised tile and the hidden activations stay in LDS / registers.
+ * x: tokens [2][B*N][C] (group stride x_gs elements); y: element (g, row, c) at y + g*y_gs + row*ldy + c (may alias neither x
+ * nor qkv).  Weights are packed [2][Np][Kp] (Np multiple of 128, Kp of 64; *_gs = per-modality strides), biases fp32 [2][Np].
+ * Requirements: dtype bf16 / f16, C % 64 == 0, head dim % 8 == 0, hidden % 128 == 0; icaf_dmff_attn_mlp additionally C <= 512
+ * (icaf_dmff_attn_mlp_lds_bytes returns the LDS bytes a launch needs, or (size_t)-1 when the shape is not covered: callers
+ * then run the per-layer entry points above).  Rounding points equal those of the per-layer launches. */
+typedef struct icaf_dmff_args {
+    const void* x; void* qkv; void* y;
+    const void* wqkv; const float* bqkv;
+    const void* wo; const float* bo;
+    const void* w1; const float* b1;
+    const void* w2; const float* b2;
+    const float* ln_attn_gamma[2]; const float* ln_attn_beta[2];   /* CrossAttention.LN1 (RGB tokens), LN2 (IR tokens) */
+    const float* ln_mlp_gamma; const float* ln_mlp_beta;           /* CrossTransformerBlock.LN2, both modalities */
+    long long wqkv_gs, bqkv_gs, wo_gs, bo_gs, w1_gs, b1_gs, w2_gs, b2_gs, x_gs, y_gs;
+    int dtype, B, N, C, heads, Kp, Kp4, hidden, ldy, reserved;
+    float eps_attn, eps_mlp;
+    float coef_res_attn[2], coef_acc_attn[2], coef_res_mlp[2], coef_acc_mlp[2];   /* coefficient1/3, 2/4, 5/7, 6/8 */
+} icaf_dmff_args;
+int icaf_dmff_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s);
+int icaf_dmff_attn_mlp(const icaf_dmff_args* a, icaf_stream_t s);
+int icaf_dmff_attn_mlp_lds_bytes(int C, int N, int heads, int dtype, size_t* bytes);
+
 /* ---- NMS (utils/general.py:518-607 + torchvision.ops.nms semantics) ----------------------------------------
  * pred: [B][rows][5+nc] fp32 (cx, cy, w, h, obj, cls...).  Per image: obj > conf filter, conf = obj*cls, best
  * class or multi-label expansion, optional class filter (host int array), top max_nms by score (stable),

@@ -1,0 +1,95 @@
+"""Fused DMFF block kernels (dmff_fused.hip: icaf_dmff_ln_qkv + icaf_dmff_attn_mlp, 2 launches per iteration) against the fp32
+oracle statement of CrossTransformerBlock (reference models/common.py:737-759) and against the per-layer launches they replace
+(LayerNorm, QKV / out-projection / MLP GEMMs, cross_attn_kernel: 7 launches) in the same 16-bit type."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import load_golden, sample_idx                         # noqa: E402
+from icafusion_amd.engine import Plan                                # noqa: E402
+from icafusion_amd.models.common import CrossTransformerBlock, TransformerFusionBlock   # noqa: E402
+from icafusion_amd.synth import synth_tensor                         # noqa: E402
+from oracle import icaf_oracle as oracle                             # noqa: E402
+
+DEV = "cuda:0"
+
+
+def make_block(C, heads, loops, seed):
+    blk = CrossTransformerBlock(C, C, C, heads, 4, 0.1, 0.1, loops_num=loops).eval()
+    sd = {k: synth_tensor("model.20.crosstransformer.0." + k, v.shape, seed=seed) for k, v in blk.state_dict().items()}
+    blk.load_state_dict(sd)
+    return blk, {"b." + k: v for k, v in sd.items()}
+
+
+def run_block(blk, tok, B, N, dtype, fused):
+    blk.fuse_block = fused
+    blk.invalidate()
+    plan = Plan(DEV, dtype)
+    t = plan.tokens(2, B * N, tok.shape[2])
+    t.copy_(tok.to(DEV).to(dtype))
+    out = blk.emit_tokens(plan, t, B, N)
+    plan.run()
+    torch.cuda.synchronize()
+    return out.float().cpu(), [l.name for l in plan.launches]
+
+
+# (C, heads, N, B, loops): the three yolov5s levels, a yolov5n level (dk = 8), yolov5m levels (dk = 24 / 48, C not a power of two),
+# ragged token counts, several iterations
+SHAPES = [(128, 8, 400, 3, 1), (256, 8, 256, 2, 1), (512, 8, 100, 3, 1), (64, 8, 400, 2, 1), (192, 8, 400, 1, 1), (384, 8, 256, 1, 1),
+          (128, 8, 77, 2, 3), (256, 8, 400, 1, 2), (512, 8, 64, 1, 1), (128, 4, 130, 1, 1)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_fused_block_vs_oracle_and_per_layer_launches(shape, dtype):
+    C, heads, N, B, loops = shape
+    blk, sd = make_block(C, heads, loops, seed=C + N)
+    blk = blk.to(DEV)
+    g = np.random.default_rng(C * 1000 + N)
+    tok = torch.from_numpy(g.normal(0.2, 0.8, (2, B * N, C)).astype(np.float32))
+    tq = tok.to(dtype).float()                                      # both paths start from the same 16-bit tokens
+    rv, ri = oracle.cross_transformer(tq[0].reshape(B, N, C), tq[1].reshape(B, N, C), sd, "b", heads, loops)
+    ref = torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
+    fused, names_f = run_block(blk, tok, B, N, dtype, True)
+    plain, names_p = run_block(blk, tok, B, N, dtype, False)
+    assert names_f == ["dmff_ln_qkv", "dmff_attn_mlp"] * loops and len(names_p) == 7 * loops
+    scale = ref.abs().max().item()
+    e_f, e_p = (fused - ref).abs().max().item() / scale, (plain - ref).abs().max().item() / scale
+    m_f, m_p = (fused - ref).abs().mean().item() / scale, (plain - ref).abs().mean().item() / scale
+    print(f"C={C} N={N} B={B} loops={loops} {dtype}: fused max {e_f:.3e} mean {m_f:.3e} | per-layer max {e_p:.3e} mean {m_p:.3e}")
+    assert torch.isfinite(fused).all()
+    # same rounding points as the per-layer launches (only fp32 summation orders differ): the error against the fp32 oracle must
+    # be of the same size, and the two 16-bit results must agree to a few units of the storage type's precision
+    assert e_f <= 1.5 * e_p + 1e-4 and m_f <= 1.25 * m_p + 1e-5
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert (fused - plain).abs().max().item() / scale <= 24 * ulp
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name", ["dmff_c128_20x20_in40x40", "dmff_c256_16x16_in40x40_overlap",
+                                  "dmff_c128_20x20_in64x80_rect_loops3", "dmff_c512_10x10_in10x10_identity"])
+def test_fused_dmff_block_vs_reference_golden_16bit(name, dtype):
+    """The whole TransformerFusionBlock in a 16-bit type with the fused block kernels vs the real reference's fp32 output: the error
+    stays that of the per-layer 16-bit launches (the fp32 build is held to 1e-3 in test_gpu_model.py)."""
+    g = load_golden(name)
+    c, va, ha, batch, h, w, seed, loops = [int(v) for v in g["meta"]]
+    blk = TransformerFusionBlock(c, va, ha, loops_num=loops)
+    sd = {k: (v if k.endswith("num_batches_tracked") else synth_tensor("model.20." + k, v.shape, seed=seed)) for k, v in blk.state_dict().items()}
+    blk.load_state_dict(sd)
+    blk.conv1x1_out.bn.eps = 1e-3
+    blk = blk.eval().to(DEV)
+    blk.compute_dtype = dtype
+    rg = np.random.default_rng([seed, 77, c, h, w])
+    rgb = torch.from_numpy(rg.normal(0, 1, (batch, c, h, w)).astype(np.float32)).to(DEV)
+    ir = torch.from_numpy(rg.normal(0, 1, (batch, c, h, w)).astype(np.float32)).to(DEV)
+    errs = {}
+    for fused in (True, False):
+        blk.crosstransformer[0].fuse_block = fused
+        blk.invalidate()
+        out = blk([rgb, ir]).float().cpu()
+        got = out.reshape(-1)[torch.from_numpy(sample_idx(out.numel(), 200, 8192))].numpy()
+        errs[fused] = np.abs(got - g["out"]).max() / max(1.0, np.abs(g["out"]).max())
+    print(f"{name} {dtype}: fused {errs[True]:.3e}, per-layer {errs[False]:.3e}")
+    assert errs[True] <= 1.5 * errs[False] + 1e-4
