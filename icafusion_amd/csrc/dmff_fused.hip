@@ -49,54 +49,73 @@ template <int SLB> struct Ring {
     static constexpr int BYTES = 2 * STAGE;
 };
 
-// acc[t] += W[n0 + wn*64 + t*32 + i][k] * A[wm*32 + j][k]   over K elements; the caller has synchronised the A tile.
-// SLB = 128 (default) or 64 bytes of K per slice (wide tokens: the ring has to share LDS with two [64 x C] tiles).
-template <int DT, int SLB>
-__device__ __forceinline__ void gemm_pass(f32x16 (&acc)[2], const unsigned char* A, int SA, int K,
-                                          const typename Elem<DT>::type* __restrict__ W, long long ldw, unsigned char* ring) {
+// Weight-slice stream.  The GEMM passes of a phase form ONE continuous sequence of 128-channel x SLB-byte weight slices:
+// slice s of a pass is consumed from LDS stage s & 1 while slice s + 1 sits in registers and slice s + 2 is being fetched
+// (two slices of L2 latency hidden behind two slices of MFMAs); the last two steps of a pass fetch the first two slices of the
+// NEXT pass, so only the first pass of a phase exposes a load.  Every pass has an even number of slices (SLB is chosen for
+// that), so stage / register parity is a compile-time property of the code position — no dynamic register indexing.
+template <int DT, int SLB> struct WS {
     using E = Elem<DT>;
+    using T = typename E::type;
     using R = Ring<SLB>;
-    constexpr int BKE = SLB / E::BYTES;                 // K elements per slice
-    constexpr int VPR = SLB / 16;                       // 16-byte vectors per row of a slice
-    constexpr int NV = 128 * VPR / FT;                  // vectors per thread per slice
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int wm = wave & 1, wn = wave >> 1;
-    const int nchunks = K / BKE;
-    u32x4 stage[NV];
-    auto fetch = [&](int c) {
+    static constexpr int BKE = SLB / E::BYTES;              // K elements per slice
+    static constexpr int VPR = SLB / 16;                    // 16-byte vectors per row of a slice
+    static constexpr int NV = 128 * VPR / FT;               // vectors per thread per slice
+    static __device__ __forceinline__ void fetch(u32x4 (&r)[NV], const T* __restrict__ base, long long ldw) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int v = tid + i * FT, row = v / VPR, kv = v % VPR;
-            stage[i] = *(const u32x4*)(W + (long long)row * ldw + (long long)c * BKE + kv * E::VEC);
+            const int v = threadIdx.x + i * FT, row = v / VPR, kv = v % VPR;
+            r[i] = *(const u32x4*)(base + (long long)row * ldw + kv * E::VEC);
         }
-    };
-    auto commit = [&](int c) {
-        unsigned char* buf = ring + (c & 1) * R::STAGE;
+    }
+    static __device__ __forceinline__ void commit(const u32x4 (&r)[NV], unsigned char* stage) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int v = tid + i * FT, row = v / VPR, kv = v % VPR;
-            *(u32x4*)(buf + row * R::WROW + kv * 16) = stage[i];
+            const int v = threadIdx.x + i * FT, row = v / VPR, kv = v % VPR;
+            *(u32x4*)(stage + row * R::WROW + kv * 16) = r[i];
         }
-    };
-    fetch(0);
-    commit(0);
-    lds_barrier();
-    const unsigned char* arow = A + (size_t)(wm * 32 + l31) * SA + hi * 16;
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) fetch(c + 1);
-        const unsigned char* buf = ring + (c & 1) * R::STAGE + (size_t)(wn * 64 + l31) * R::WROW + hi * 16;
+    }
+    // acc[t] += W[wn*64 + t*32 + i][k] * A[wm*32 + j][k] over the SLB bytes of K of one slice
+    static __device__ __forceinline__ void compute(f32x16 (&acc)[2], const unsigned char* arow, const unsigned char* wrow) {
 #pragma unroll
         for (int ks = 0; ks < SLB / 32; ++ks) {
-            const u32x4 xf = *(const u32x4*)(arow + (size_t)c * SLB + ks * 32);
-            const u32x4 w0 = *(const u32x4*)(buf + ks * 32);
-            const u32x4 w1 = *(const u32x4*)(buf + 32 * R::WROW + ks * 32);
+            const u32x4 xf = *(const u32x4*)(arow + ks * 32);
+            const u32x4 w0 = *(const u32x4*)(wrow + ks * 32);
+            const u32x4 w1 = *(const u32x4*)(wrow + 32 * R::WROW + ks * 32);
             mma_step<DT>(acc[0], w0, xf);
             mma_step<DT>(acc[1], w1, xf);
         }
-        if (c + 1 < nchunks) commit(c + 1);
+    }
+    // first pass of a phase: slice 0 -> stage 0 (visible after the barrier), slice 1 -> r1 (in flight)
+    static __device__ __forceinline__ void start(u32x4 (&r0)[NV], u32x4 (&r1)[NV], const T* W, long long ldw, unsigned char* ring) {
+        fetch(r0, W, ldw);
+        fetch(r1, W + BKE, ldw);
+        commit(r0, ring);
         lds_barrier();
     }
-}
+    // One pass over n (even) slices.  Pre: stage 0 holds slice 0, r1 holds slice 1.  Post: the same for the pass at Wn (if any).
+    // The caller has made the A tile visible (barrier) before the call.
+    static __device__ __forceinline__ void pass(f32x16 (&acc)[2], const unsigned char* A, int SA, int n, const T* __restrict__ W, long long ldw,
+                                                const T* __restrict__ Wn, long long ldwn, unsigned char* ring, u32x4 (&r0)[NV], u32x4 (&r1)[NV]) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+        const int wm = wave & 1, wn = wave >> 1;
+        const unsigned char* arow = A + (size_t)(wm * 32 + l31) * SA + hi * 16;
+        const unsigned char* w0 = ring + (size_t)(wn * 64 + l31) * R::WROW + hi * 16;
+        const unsigned char* w1 = w0 + R::STAGE;
+        for (int c = 0; c < n; c += 2) {
+            if (c + 2 < n) fetch(r0, W + (long long)(c + 2) * BKE, ldw);
+            else if (Wn) fetch(r0, Wn, ldwn);
+            compute(acc, arow + (size_t)c * SLB, w0);
+            commit(r1, ring + R::STAGE);                       // slice c + 1
+            lds_barrier();
+            if (c + 3 < n) fetch(r1, W + (long long)(c + 3) * BKE, ldw);
+            else if (Wn) fetch(r1, Wn + BKE, ldwn);
+            compute(acc, arow + (size_t)(c + 1) * SLB, w1);
+            if (c + 2 < n || Wn) commit(r0, ring);             // slice c + 2, or slice 0 of the next pass
+            lds_barrier();
+        }
+    }
+};
 
 template <int DT> __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
     u32x2 v;
@@ -154,19 +173,27 @@ __device__ __forceinline__ void tile_layernorm(const unsigned char* src, unsigne
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LayerNorm + QKV projection.  grid = (ceil(rows / 64), 2 modalities)
+// LayerNorm + QKV projection.  grid = (ceil(rows / 64), column groups of 384 output channels, 2 modalities)
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int QKV_GROUP = 384;       // output channels per workgroup (3 passes of 128): C / 128 groups cover the 3C outputs
+
 template <int DT, int SLB>
 __global__ __launch_bounds__(FT) void dmff_ln_qkv_kernel(const DmffP p) {
     using E = Elem<DT>;
     using T = typename E::type;
+    using S = WS<DT, SLB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int C = p.C, SA = C * E::BYTES + 16;
     unsigned char* tile = smem;                                  // [64][SA]
     unsigned char* ring = smem + (size_t)TMROWS * SA;            // Ring<SLB>::BYTES
-    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int g = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int wm = wave & 1, wn = wave >> 1;
     const long long rows = (long long)p.B * p.N, r0 = (long long)blockIdx.x * TMROWS;
+    const int nout = 3 * C, nbeg = blockIdx.y * QKV_GROUP, nend = nbeg + QKV_GROUP < nout ? nbeg + QKV_GROUP : nout;
+    const T* W = (const T*)p.wqkv + g * p.wqkv_gs;
+    u32x4 r0v[S::NV], r1v[S::NV];
+    S::fetch(r0v, W + (long long)nbeg * p.Kp, p.Kp);             // the first weight slices travel while the tokens are normalised
+    S::fetch(r1v, W + (long long)nbeg * p.Kp + S::BKE, p.Kp);
     const T* xg = (const T*)p.x + g * p.x_gs;
     const int nv = C / E::VEC;
     for (int idx = tid; idx < TMROWS * nv; idx += FT) {          // raw tokens -> LDS (rows beyond the tensor: clamped, never stored)
@@ -175,21 +202,22 @@ __global__ __launch_bounds__(FT) void dmff_ln_qkv_kernel(const DmffP p) {
         r = r < rows ? r : rows - 1;
         *(u32x4*)(tile + (size_t)row * SA + v * 16) = *(const u32x4*)(xg + r * C + v * E::VEC);
     }
+    S::commit(r0v, ring);
     __syncthreads();
     tile_layernorm<DT>(tile, tile, SA, C, p.ln_a_g[g], p.ln_a_b[g], p.eps_a);
     __syncthreads();
-    const T* W = (const T*)p.wqkv + g * p.wqkv_gs;
     const float* bias = p.bqkv + g * p.bqkv_gs;
     T* out = (T*)p.qkv + (long long)g * rows * 3 * C;
-    const int nout = 3 * C;
     const long long row = r0 + wm * 32 + l31;
-    for (int n0 = 0; n0 < nout; n0 += 128) {
+    const int nsl = C / S::BKE;
+    for (int n0 = nbeg; n0 < nend; n0 += 128) {
         f32x16 acc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        gemm_pass<DT, SLB>(acc, tile, SA, C, W + (long long)n0 * p.Kp, p.Kp, ring);
+        const T* Wn = n0 + 128 < nend ? W + (long long)(n0 + 128) * p.Kp : nullptr;
+        S::pass(acc, tile, SA, nsl, W + (long long)n0 * p.Kp, p.Kp, Wn, p.Kp, ring, r0v, r1v);
         if (row < rows) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -223,11 +251,11 @@ template <int DT> __device__ __forceinline__ u32x4 pack_p16(const f32x16& s, int
     return v;
 }
 
-template <int DT, int DKP, int NP2>
+template <int DT, int DKP, int NP2, int SLB>
 __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
-    constexpr int SLB = NP2 >= 4 ? 64 : 128;           // C >= 512: two [64 x C] tiles leave room for 64-byte ring slices only
     using E = Elem<DT>;
     using T = typename E::type;
+    using S = WS<DT, SLB>;
     constexpr int VEC = E::VEC, EB = E::BYTES;
     constexpr int KSTEP = 2 * VEC, QSTEPS = DKP / KSTEP, TD = (DKP + 31) / 32, PSTEPS = 32 / KSTEP;
     constexpr int KS = DKP * EB + 16;
@@ -238,11 +266,11 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
     constexpr int SH = 128 * EB + 16;
     const size_t hb_bytes = (size_t)TMROWS * SH;
     unsigned char* T0 = smem;                        // attention output -> later the LayerNorm'ed MLP input
-    unsigned char* U = smem + tile_bytes;            // union: {K, V^T of two heads}  |  {T1 = x_att (phase B, C), H = hidden chunk (phase D); weight ring}
+    unsigned char* U = smem + tile_bytes;            // union: {K, V^T of two heads}  |  {H = hidden chunk, weight ring, LayerNorm partial sums}
     const size_t kv_head = (size_t)NP * KS + (size_t)DKP * VS;
-    unsigned char* T1 = U;
-    unsigned char* Hb = U;                           // x_att moves to registers before the MLP, its tile becomes the hidden chunk
-    unsigned char* ring = U + (tile_bytes > hb_bytes ? tile_bytes : hb_bytes);
+    unsigned char* Hb = U;
+    unsigned char* ring = U + hb_bytes;
+    float* red = (float*)(ring + Ring<SLB>::BYTES);  // [2][64] row partial sums of the two column halves
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int dir = blockIdx.z, b = blockIdx.y, q0 = blockIdx.x * TMROWS;
@@ -366,57 +394,116 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
     }
     __syncthreads();              // T0 = attention output of the 64 rows; the K / V^T region is free
 
-    // ---- B. out-projection + coefficient mix -> T1 = x_att (storage type, as the unfused launch stores it) --------
+    // ---- B. out-projection + coefficient mix: x_att = c_res * x + c_acc * (att W_o^T + b), rounded to the storage type (as the
+    //         per-layer launch stores it) and kept in REGISTERS, in the accumulator layout of the 128-channel passes --------------
     const int wm = wave & 1, wn = wave >> 1;
     const int lrow = wm * 32 + l31;                        // local token row of this lane
     const int tok = q0 + lrow;
     const bool rok = tok < N;
     const long long grow = (long long)b * N + (rok ? tok : N - 1);      // clamped global row (loads only)
     const T* xres = (const T*)p.x + dir * p.x_gs + grow * C;
+    const T* Wo = (const T*)p.wo + dir * p.wo_gs;
+    const T* W1 = (const T*)p.w1 + dir * p.w1_gs;
+    const T* W2 = (const T*)p.w2 + dir * p.w2_gs;
+    const int nsl = C / S::BKE, nsl2 = 128 / S::BKE, npass = (C + 127) / 128;
+    T* yrow = (T*)p.y + dir * p.y_gs + ((long long)b * N + (rok ? tok : 0)) * p.ldy;
+    u32x4 r0v[S::NV], r1v[S::NV];
+    S::start(r0v, r1v, Wo, p.Kp, ring);
+    u32x2 xatt[NP2][2][4];
     {
-        const T* W = (const T*)p.wo + dir * p.wo_gs;
         const float* bias = p.bo + dir * p.bo_gs;
         const float ca = p.c_acc_a[dir], cr = p.c_res_a[dir];
-        for (int n0 = 0; n0 < C; n0 += 128) {
-            f32x16 acc[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int i = 0; i < NP2; ++i) {
+            if (i < npass) {
+                f32x16 acc[2];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-            gemm_pass<DT, SLB>(acc, T0, SA, C, W + (long long)n0 * p.Kp, p.Kp, ring);
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+                const T* Wn = i + 1 < npass ? Wo + (long long)(i + 1) * 128 * p.Kp : W1;       // then the first MLP chunk
+                S::pass(acc, T0, SA, nsl, Wo + (long long)i * 128 * p.Kp, p.Kp, Wn, p.Kp, ring, r0v, r1v);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = i * 128 + wn * 64 + t * 32 + 8 * q + 4 * hi;
+                        u32x2 pk = {0u, 0u};
+                        if (n < C) {
+                            const f32x4 bv = *(const f32x4*)(bias + n);
+                            float rv[4];
+                            unpack4<DT>(*(const u32x2*)(xres + n), rv);
+                            float v[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (acc[t][4 * q + j] + bv[j]) * ca);
+                            pk = pack4<DT>(v[0], v[1], v[2], v[3]);
+                        }
+                        xatt[i][t][q] = pk;
+                    }
+            }
+        }
+    }
+    // ---- C. the block's shared LayerNorm over x_att, from registers: row sums = this lane's channels + the other lane half
+    //         (shuffle) + the other column half (two floats per row through LDS); two-pass statistics on the rounded values.
+    //         The normalised tile overwrites T0 (every out-projection pass has finished reading it: each ends with a barrier). -----
+    {
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NP2; ++i)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * 64 + t * 32 + 8 * q + 4 * hi;
-                    if (n < C) {
-                        const f32x4 bv = *(const f32x4*)(bias + n);
-                        float rv[4];
-                        unpack4<DT>(*(const u32x2*)(xres + n), rv);
-                        float v[4];
+                    float v[4];
+                    unpack4<DT>(xatt[i][t][q], v);                     // (channels >= C hold zeros)
+                    sum += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+        sum += __shfl_xor(sum, 32);
+        if (hi == 0) red[wn * 64 + lrow] = sum;
+        lds_barrier();
+        const float mean = (red[lrow] + red[64 + lrow]) / (float)C;
+        lds_barrier();
+        float sq = 0.0f;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (acc[t][4 * q + j] + bv[j]) * ca);
-                        *(u32x2*)(T1 + (size_t)lrow * SA + n * EB) = pack4<DT>(v[0], v[1], v[2], v[3]);
+        for (int i = 0; i < NP2; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = i * 128 + wn * 64 + t * 32 + 8 * q + 4 * hi;
+                    if (n < C) {
+                        float v[4];
+                        unpack4<DT>(xatt[i][t][q], v);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const float d = v[j] - mean; sq += d * d; }
                     }
                 }
-        }
+        sq += __shfl_xor(sq, 32);
+        if (hi == 0) red[wn * 64 + lrow] = sq;
+        lds_barrier();
+        const float rstd = 1.0f / sqrtf((red[lrow] + red[64 + lrow]) / (float)C + p.eps_m);
+#pragma unroll
+        for (int i = 0; i < NP2; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = i * 128 + wn * 64 + t * 32 + 8 * q + 4 * hi;
+                    if (n < C) {
+                        const f32x4 gv = *(const f32x4*)(p.ln_m_g + n), bv = *(const f32x4*)(p.ln_m_b + n);
+                        float v[4], o[4];
+                        unpack4<DT>(xatt[i][t][q], v);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean) * rstd * gv[j] + bv[j];
+                        *(u32x2*)(T0 + (size_t)lrow * SA + n * EB) = pack4<DT>(o[0], o[1], o[2], o[3]);
+                        // x_att is needed once more, as the residual of the MLP mix: park it in this workgroup's own rows of the
+                        // output tensor (read back by the same lane at the end) instead of holding 16 * NP2 registers through the MLP
+                        if (rok) *(u32x2*)(yrow + n) = xatt[i][t][q];
+                    }
+                }
+        lds_barrier();
     }
-    __syncthreads();
-    // ---- C. shared LayerNorm: T1 (x_att) -> T0 (MLP input); this lane's x_att values move to registers (packed), in the
-    //         accumulator layout of the output passes, because the tile becomes the hidden-chunk buffer of the MLP ---------
-    tile_layernorm<DT>(T1, T0, SA, C, p.ln_m_g, p.ln_m_b, p.eps_m);
-    u32x2 xatt[NP2][2][4];
-#pragma unroll
-    for (int i = 0; i < NP2; ++i)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = i * 128 + wn * 64 + t * 32 + 8 * q + 4 * hi;
-                xatt[i][t][q] = n < C ? *(const u32x2*)(T1 + (size_t)lrow * SA + n * EB) : u32x2{0u, 0u};
-            }
-    __syncthreads();
-    // ---- D. MLP in 128-column hidden chunks ----------------------------------------------------------------------------
+    // ---- D. MLP in 128-column hidden chunks: H = GELU(n2 W1_chunk^T + b1) -> LDS, then acc2 += H W2[:, chunk]^T ------------------
     f32x16 acc2[NP2][2];
 #pragma unroll
     for (int i = 0; i < NP2; ++i)
@@ -425,8 +512,6 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[i][t][r] = 0.0f;
     {
-        const T* W1 = (const T*)p.w1 + dir * p.w1_gs;
-        const T* W2 = (const T*)p.w2 + dir * p.w2_gs;
         const float* b1 = p.b1 + dir * p.b1_gs;
         for (int hc = 0; hc < p.hid; hc += 128) {
             f32x16 acc[2];
@@ -434,7 +519,7 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-            gemm_pass<DT, SLB>(acc, T0, SA, C, W1 + (long long)hc * p.Kp, p.Kp, ring);
+            S::pass(acc, T0, SA, nsl, W1 + (long long)hc * p.Kp, p.Kp, W2 + hc, p.Kp4, ring, r0v, r1v);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -444,18 +529,22 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
                     *(u32x2*)(Hb + (size_t)lrow * SH + nl * EB) = pack4<DT>(gelu_f(acc[t][4 * q] + bv[0]), gelu_f(acc[t][4 * q + 1] + bv[1]),
                                                                             gelu_f(acc[t][4 * q + 2] + bv[2]), gelu_f(acc[t][4 * q + 3] + bv[3]));
                 }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int i = 0; i < NP2; ++i)
-                if (i * 128 < C) gemm_pass<DT, SLB>(acc2[i], Hb, SH, 128, W2 + (long long)(i * 128) * p.Kp4 + hc, p.Kp4, ring);
-            // (gemm_pass ends with a barrier: every wave is done with Hb before the next chunk overwrites it)
+                if (i < npass) {
+                    const T* Wn = i + 1 < npass ? W2 + (long long)(i + 1) * 128 * p.Kp4 + hc
+                                                : (hc + 128 < p.hid ? W1 + (long long)(hc + 128) * p.Kp : nullptr);
+                    const long long ldn = i + 1 < npass ? p.Kp4 : p.Kp;
+                    S::pass(acc2[i], Hb, SH, nsl2, W2 + (long long)i * 128 * p.Kp4 + hc, p.Kp4, Wn, ldn, ring, r0v, r1v);
+                }
+            // (every pass ends with a barrier: all waves are done with Hb before the next chunk overwrites it)
         }
     }
     // ---- output: x' = c_res2 * x_att + c_acc2 * (mlp + b2) ----------------------------------------------------------
     if (rok) {
         const float* b2 = p.b2 + dir * p.b2_gs;
         const float ca = p.c_acc_m[dir], cr = p.c_res_m[dir];
-        T* yrow = (T*)p.y + dir * p.y_gs + ((long long)b * N + tok) * p.ldy;
 #pragma unroll
         for (int i = 0; i < NP2; ++i)
 #pragma unroll
@@ -466,7 +555,7 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
                     if (n < C) {
                         const f32x4 bv = *(const f32x4*)(b2 + n);
                         float rv[4];
-                        unpack4<DT>(xatt[i][t][q], rv);
+                        unpack4<DT>(*(const u32x2*)(yrow + n), rv);              // x_att, parked here after the LayerNorm
                         float v[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (acc2[i][t][4 * q + j] + bv[j]) * ca);
@@ -476,16 +565,18 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
     }
 }
 
+static inline int slice_bytes(int C) { return C % 128 == 0 ? 128 : 64; }     // every pass needs an even number of slices
+
 static size_t attn_mlp_lds(int C, int N, int dkp, int eb) {
     const int NP = (N + 31) & ~31;
     const size_t tile = (size_t)TMROWS * (C * eb + 16), hb = (size_t)TMROWS * (128 * eb + 16);
     const size_t kv2 = 2 * ((size_t)NP * (dkp * eb + 16) + (size_t)dkp * (NP * eb + 16));
-    const size_t ring = (C + 127) / 128 >= 4 ? Ring<64>::BYTES : Ring<128>::BYTES;     // as the kernel: NP2 >= 4 (C > 384) -> 64-byte slices
-    const size_t chain = (tile > hb ? tile : hb) + ring;
+    const size_t ring = slice_bytes(C) == 128 ? Ring<128>::BYTES : Ring<64>::BYTES;
+    const size_t chain = hb + ring + 2 * 64 * sizeof(float);
     return tile + (kv2 > chain ? kv2 : chain);
 }
 
-template <int DT, int DKP, int NP2>
+template <int DT, int DKP, int NP2, int SLB>
 static int launch_attn_mlp(const DmffP& p, hipStream_t s) {
     const size_t lds = attn_mlp_lds(p.C, p.N, DKP, Elem<DT>::BYTES);
     if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_attn_mlp: %zu bytes of LDS (C=%d, N=%d, dk=%d) exceed 160 KiB", lds, p.C, p.N, p.dk);
@@ -494,11 +585,11 @@ static int launch_attn_mlp(const DmffP& p, hipStream_t s) {
     ICAF_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= ICAF_MAX_DEVICES) return fail(ICAF_ERR_UNSUPPORTED, "device ordinal %d", dev);
     if (!attr_set[dev]) {
-        ICAF_HIP(hipFuncSetAttribute((const void*)dmff_attn_mlp_kernel<DT, DKP, NP2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ICAF_HIP(hipFuncSetAttribute((const void*)dmff_attn_mlp_kernel<DT, DKP, NP2, SLB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[dev] = true;
     }
     dim3 grid((unsigned)((p.N + TMROWS - 1) / TMROWS), (unsigned)p.B, 2u);
-    hipLaunchKernelGGL((dmff_attn_mlp_kernel<DT, DKP, NP2>), grid, dim3(FT), lds, s, p);
+    hipLaunchKernelGGL((dmff_attn_mlp_kernel<DT, DKP, NP2, SLB>), grid, dim3(FT), lds, s, p);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
@@ -506,11 +597,17 @@ static int launch_attn_mlp(const DmffP& p, hipStream_t s) {
 template <int DT, int DKP>
 static int dispatch_np2(const DmffP& p, hipStream_t s) {
     const int np2 = (p.C + 127) / 128;
-    if (np2 <= 1) return launch_attn_mlp<DT, DKP, 1>(p, s);
-    if (np2 <= 2) return launch_attn_mlp<DT, DKP, 2>(p, s);
-    if (np2 <= 3) return launch_attn_mlp<DT, DKP, 3>(p, s);
-    if (np2 <= 4) return launch_attn_mlp<DT, DKP, 4>(p, s);
-    return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_attn_mlp: C=%d > 512 (two [64 x C] token tiles exceed the LDS)", p.C);
+    if (slice_bytes(p.C) == 128) {
+        if (np2 <= 1) return launch_attn_mlp<DT, DKP, 1, 128>(p, s);
+        if (np2 <= 2) return launch_attn_mlp<DT, DKP, 2, 128>(p, s);
+        if (np2 <= 3) return launch_attn_mlp<DT, DKP, 3, 128>(p, s);
+        if (np2 <= 4) return launch_attn_mlp<DT, DKP, 4, 128>(p, s);
+    } else {                                    // C = 64, 192, 320, 448: 64-byte slices
+        if (np2 <= 1) return launch_attn_mlp<DT, DKP, 1, 64>(p, s);
+        if (np2 <= 2) return launch_attn_mlp<DT, DKP, 2, 64>(p, s);
+        if (np2 <= 4) return launch_attn_mlp<DT, DKP, 4, 64>(p, s);
+    }
+    return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_attn_mlp: C=%d > 512 (the [64 x C] token tile and K / V^T of two heads exceed the LDS)", p.C);
 }
 
 template <int DT>
@@ -537,14 +634,14 @@ static int launch_ln_qkv_t(const DmffP& p, hipStream_t s) {
         attr_set[dev] = true;
     }
     const long long rows = (long long)p.B * p.N;
-    dim3 grid((unsigned)((rows + TMROWS - 1) / TMROWS), 2u);
+    dim3 grid((unsigned)((rows + TMROWS - 1) / TMROWS), (unsigned)((3 * p.C + QKV_GROUP - 1) / QKV_GROUP), 2u);
     hipLaunchKernelGGL((dmff_ln_qkv_kernel<DT, SLB>), grid, dim3(FT), lds, s, p);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
 template <int DT>
 static int launch_ln_qkv(const DmffP& p, hipStream_t s) {
-    return p.C > 768 ? launch_ln_qkv_t<DT, 64>(p, s) : launch_ln_qkv_t<DT, 128>(p, s);
+    return slice_bytes(p.C) == 128 ? launch_ln_qkv_t<DT, 128>(p, s) : launch_ln_qkv_t<DT, 64>(p, s);
 }
 
 static int fill(const icaf_dmff_args* a, DmffP& p, const char* who) {

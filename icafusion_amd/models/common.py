@@ -10,6 +10,7 @@ There is deliberately no PyTorch / CPU fallback: calling a module with CPU tenso
 libicaf.so raises.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -723,7 +724,8 @@ class CrossTransformerBlock(HipModule):
                             cin, cout, act, res=rows_act(res, cout) if res is not None else None,
                             alpha_acc=alpha_acc, alpha_res=alpha_res, groups=2, group_strides=gs, name=name))
 
-    fuse_block = True    # 16-bit types: one iteration = icaf_dmff_ln_qkv + icaf_dmff_attn_mlp (2 launches) instead of 7
+    # 16-bit types: one iteration = icaf_dmff_ln_qkv + icaf_dmff_attn_mlp (2 launches) instead of 7 (ICAF_DMFF_FUSE=0: A/B switch)
+    fuse_block = os.environ.get("ICAF_DMFF_FUSE", "1") != "0"
 
     def fusable(self, plan, C, N):
         hid, h = self.mlp_vis[0].out_features, self.crossatt.h
