@@ -25,9 +25,10 @@ constexpr int ROWB = 64;        // bytes of K per LDS row per slice
 constexpr int ROWS = 80;        // padded LDS row stride in bytes (register-staged pipeline)
 constexpr int NTHREADS = 256;
 
-template <int ACT> __device__ __forceinline__ float apply_act(float v) {
+// DT = the layer's storage type: the 16-bit builds evaluate GELU's erf by a 1.5e-7-accurate polynomial (gelu_fast_f), fp32 by erff
+template <int ACT, int DT = ICAF_F32> __device__ __forceinline__ float apply_act(float v) {
     if constexpr (ACT == ICAF_ACT_SILU) return silu_f(v);
-    else if constexpr (ACT == ICAF_ACT_GELU) return gelu_f(v);
+    else if constexpr (ACT == ICAF_ACT_GELU) return DT == ICAF_F32 ? gelu_f(v) : gelu_fast_f(v);
     else return v;
 }
 
@@ -135,7 +136,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
                 }
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT>(acc[a][b][4 * q + j] + bv[j] + pv[j]) * alpha_acc;
+                for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, DT>(acc[a][b][4 * q + j] + bv[j] + pv[j]) * alpha_acc;
                 unsigned char* dst = lds + ml * SO + nl * EO::BYTES;
                 if constexpr (EO::BYTES == 4) {
                     *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};

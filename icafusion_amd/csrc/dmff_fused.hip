@@ -38,6 +38,7 @@ struct DmffP {
     int B, N, C, heads, dk, Kp, Kp4, hid, ldy;
     float eps_a, eps_m, scale_l2e;
     float c_res_a[2], c_acc_a[2], c_res_m[2], c_acc_m[2];
+    long long* dbg;           // optional: workgroup (0, 0, 0) records s_memtime at its phase boundaries (tools/probes/dmff_phases.py)
 };
 
 constexpr int FT = 256;              // threads per workgroup (4 wavefronts)
@@ -252,13 +253,15 @@ template <int DT> __device__ __forceinline__ u32x4 pack_p16(const f32x16& s, int
 }
 
 template <int DT, int DKP, int NP2, int SLB>
-__global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
+__global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32) ? 2 : 1) void dmff_attn_mlp_kernel(const DmffP p) {      // C <= 128: two workgroups per CU (<= 256 registers)
     using E = Elem<DT>;
     using T = typename E::type;
     using S = WS<DT, SLB>;
     constexpr int VEC = E::VEC, EB = E::BYTES;
     constexpr int KSTEP = 2 * VEC, QSTEPS = DKP / KSTEP, TD = (DKP + 31) / 32, PSTEPS = 32 / KSTEP;
-    constexpr int KS = DKP * EB + 16;
+    // K row stride: 32-byte rows (dk <= 16) are read as ONE contiguous kilobyte per b128 wave read — no padding needed, and the
+    // 13 KB it saves at N = 400 lets two workgroups share a CU (2 waves / SIMD); wider rows keep the odd-multiple-of-16 stride
+    constexpr int KS = DKP * EB == 32 ? 32 : DKP * EB + 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int C = p.C, N = p.N, DK = p.dk, NP = (N + 31) & ~31;
     const int SA = C * EB + 16, VS = NP * EB + 16;
@@ -279,35 +282,81 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
     const T* kvb = qkv + ((long long)dir * rows + (long long)b * N) * row3;
     const T* qb = qkv + ((long long)(1 - dir) * rows + (long long)b * N) * row3;
 
-    // ---- A. attention: two heads per round (wave pair = head, wave parity = 32-query tile) ----------------------
+#define DMFF_STAMP(i) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) p.dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    DMFF_STAMP(0);
+    // ---- A. attention: two heads per round (wave pair = head, wave parity = 32-query tile).  K and V of the NEXT round travel
+    //         from L2 into registers while this round computes (its staging loads were the longest serial chain of the kernel:
+    //         ~7 dependent L2 round trips per round); V^T is transposed by the 2-byte LDS writes. -----------------------------
     {
         const int hsel = wave >> 1, qt = wave & 1;
         const int q = q0 + qt * 32 + l31;
         const bool qok = q < N;
         const int nkt = NP >> 5;
         constexpr int NVK = DKP / VEC;
-        for (int h0 = 0; h0 < p.heads; h0 += 2) {
-            if (h0) __syncthreads();                       // previous round's K / V^T are free again
+        constexpr int MAXI = 4;                               // (key, vector) items per thread and head held in registers
+        const int items = NP * NVK;
+        const bool pre = items <= MAXI * FT;                  // otherwise (N * dk > 8192): plain staging loop, no prefetch
+        u32x4 kreg[2][MAXI], vreg[2][MAXI];
+        auto load_round = [&](int h0) {
+#pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                if (h0 + hh >= p.heads) break;
+                const T* base = kvb + (long long)(h0 + hh) * DK;
+#pragma unroll
+                for (int i = 0; i < MAXI; ++i) {
+                    const int idx = tid + i * FT, key = idx / NVK, v = idx - key * NVK;
+                    const bool ok = idx < items && h0 + hh < p.heads && key < N && v * VEC < DK;
+                    const T* src = base + (long long)(ok ? key : 0) * row3 + (ok ? v * VEC : 0);
+                    const u32x4 a = *(const u32x4*)(src + C), c2 = *(const u32x4*)(src + 2 * C);     // unconditional loads from a clamped address
+                    kreg[hh][i] = ok ? a : u32x4{0u, 0u, 0u, 0u};
+                    vreg[hh][i] = ok ? c2 : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        };
+        auto store_round = [&]() {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
                 unsigned char* Ks = U + hh * kv_head;
                 unsigned char* Vt = Ks + (size_t)NP * KS;
-                const T* base = kvb + (long long)(h0 + hh) * DK;
-                for (int idx = tid; idx < NP * NVK; idx += FT) {
-                    const int key = idx / NVK, v = idx - key * NVK;
-                    u32x4 kvv = {0u, 0u, 0u, 0u}, vvv = {0u, 0u, 0u, 0u};
-                    if (key < N && v * VEC < DK) {
-                        kvv = *(const u32x4*)(base + key * row3 + C + v * VEC);
-                        vvv = *(const u32x4*)(base + key * row3 + 2 * C + v * VEC);
-                    }
-                    *(u32x4*)(Ks + (size_t)key * KS + v * 16) = kvv;
-                    const int pk = vt_phys16<DT>(key);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        *(unsigned short*)(Vt + (size_t)(v * 8 + j) * VS + pk * 2) = (unsigned short)((vvv[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+                for (int i = 0; i < MAXI; ++i) {
+                    const int idx = tid + i * FT, key = idx / NVK, v = idx - key * NVK;
+                    if (idx < items) {
+                        *(u32x4*)(Ks + (size_t)key * KS + v * 16) = kreg[hh][i];
+                        const int pk = vt_phys16<DT>(key);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            *(unsigned short*)(Vt + (size_t)(v * 8 + j) * VS + pk * 2) = (unsigned short)((vreg[hh][i][j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+                    }
+                }
+            }
+        };
+        if (pre) { load_round(0); store_round(); }
+        for (int h0 = 0; h0 < p.heads; h0 += 2) {
+            if (!pre) {
+                if (h0) __syncthreads();                   // previous round's K / V^T are free again
+                for (int hh = 0; hh < 2; ++hh) {
+                    if (h0 + hh >= p.heads) break;
+                    unsigned char* Ks = U + hh * kv_head;
+                    unsigned char* Vt = Ks + (size_t)NP * KS;
+                    const T* base = kvb + (long long)(h0 + hh) * DK;
+                    for (int idx = tid; idx < items; idx += FT) {
+                        const int key = idx / NVK, v = idx - key * NVK;
+                        u32x4 kvv = {0u, 0u, 0u, 0u}, vvv = {0u, 0u, 0u, 0u};
+                        if (key < N && v * VEC < DK) {
+                            kvv = *(const u32x4*)(base + key * row3 + C + v * VEC);
+                            vvv = *(const u32x4*)(base + key * row3 + 2 * C + v * VEC);
+                        }
+                        *(u32x4*)(Ks + (size_t)key * KS + v * 16) = kvv;
+                        const int pk = vt_phys16<DT>(key);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            *(unsigned short*)(Vt + (size_t)(v * 8 + j) * VS + pk * 2) = (unsigned short)((vvv[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+                    }
                 }
             }
             __syncthreads();
+            if (h0 == 0) DMFF_STAMP(1);
+            if (pre && h0 + 2 < p.heads) load_round(h0 + 2);
             const int h = h0 + hsel;
             if (h < p.heads) {
                 const unsigned char* Ks = U + hsel * kv_head;
@@ -390,9 +439,14 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
                                                                    o[td][4 * g4 + 3] * inv);
                     }
             }
+            if (pre && h0 + 2 < p.heads) {
+                __syncthreads();                           // every wave is done with this round's K / V^T
+                store_round();
+            }
         }
     }
     __syncthreads();              // T0 = attention output of the 64 rows; the K / V^T region is free
+    DMFF_STAMP(2);
 
     // ---- B. out-projection + coefficient mix: x_att = c_res * x + c_acc * (att W_o^T + b), rounded to the storage type (as the
     //         per-layer launch stores it) and kept in REGISTERS, in the accumulator layout of the 128-channel passes --------------
@@ -443,6 +497,7 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
             }
         }
     }
+    DMFF_STAMP(3);
     // ---- C. the block's shared LayerNorm over x_att, from registers: row sums = this lane's channels + the other lane half
     //         (shuffle) + the other column half (two floats per row through LDS); two-pass statistics on the rounded values.
     //         The normalised tile overwrites T0 (every out-projection pass has finished reading it: each ends with a barrier). -----
@@ -503,6 +558,7 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
                 }
         lds_barrier();
     }
+    DMFF_STAMP(4);
     // ---- D. MLP in 128-column hidden chunks: H = GELU(n2 W1_chunk^T + b1) -> LDS, then acc2 += H W2[:, chunk]^T ------------------
     f32x16 acc2[NP2][2];
 #pragma unroll
@@ -526,8 +582,8 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
                 for (int q = 0; q < 4; ++q) {
                     const int nl = wn * 64 + t * 32 + 8 * q + 4 * hi;          // column inside the chunk
                     const f32x4 bv = *(const f32x4*)(b1 + hc + nl);
-                    *(u32x2*)(Hb + (size_t)lrow * SH + nl * EB) = pack4<DT>(gelu_f(acc[t][4 * q] + bv[0]), gelu_f(acc[t][4 * q + 1] + bv[1]),
-                                                                            gelu_f(acc[t][4 * q + 2] + bv[2]), gelu_f(acc[t][4 * q + 3] + bv[3]));
+                    *(u32x2*)(Hb + (size_t)lrow * SH + nl * EB) = pack4<DT>(gelu_fast_f(acc[t][4 * q] + bv[0]), gelu_fast_f(acc[t][4 * q + 1] + bv[1]),
+                                                                            gelu_fast_f(acc[t][4 * q + 2] + bv[2]), gelu_fast_f(acc[t][4 * q + 3] + bv[3]));
                 }
             lds_barrier();
 #pragma unroll
@@ -541,6 +597,7 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
             // (every pass ends with a barrier: all waves are done with Hb before the next chunk overwrites it)
         }
     }
+    DMFF_STAMP(5);
     // ---- output: x' = c_res2 * x_att + c_acc2 * (mlp + b2) ----------------------------------------------------------
     if (rok) {
         const float* b2 = p.b2 + dir * p.b2_gs;
@@ -563,6 +620,7 @@ __global__ __launch_bounds__(FT) void dmff_attn_mlp_kernel(const DmffP p) {
                     }
                 }
     }
+    DMFF_STAMP(6);
 }
 
 static inline int slice_bytes(int C) { return C % 128 == 0 ? 128 : 64; }     // every pass needs an even number of slices
@@ -570,7 +628,8 @@ static inline int slice_bytes(int C) { return C % 128 == 0 ? 128 : 64; }     // 
 static size_t attn_mlp_lds(int C, int N, int dkp, int eb) {
     const int NP = (N + 31) & ~31;
     const size_t tile = (size_t)TMROWS * (C * eb + 16), hb = (size_t)TMROWS * (128 * eb + 16);
-    const size_t kv2 = 2 * ((size_t)NP * (dkp * eb + 16) + (size_t)dkp * (NP * eb + 16));
+    const size_t ks = dkp * eb == 32 ? 32 : dkp * eb + 16;
+    const size_t kv2 = 2 * ((size_t)NP * ks + (size_t)dkp * (NP * eb + 16));
     const size_t ring = slice_bytes(C) == 128 ? Ring<128>::BYTES : Ring<64>::BYTES;
     const size_t chain = hb + ring + 2 * 64 * sizeof(float);
     return tile + (kv2 > chain ? kv2 : chain);
@@ -660,6 +719,7 @@ static int fill(const icaf_dmff_args* a, DmffP& p, const char* who) {
     p.B = a->B; p.N = a->N; p.C = a->C; p.heads = a->heads; p.dk = a->C / a->heads; p.Kp = a->Kp; p.Kp4 = a->Kp4; p.hid = a->hidden; p.ldy = a->ldy;
     p.eps_a = a->eps_attn; p.eps_m = a->eps_mlp;
     p.scale_l2e = (float)((1.0 / sqrt((double)p.dk)) * 1.4426950408889634);
+    p.dbg = (long long*)a->debug_clock;
     for (int g = 0; g < 2; ++g) {
         p.c_res_a[g] = a->coef_res_attn[g]; p.c_acc_a[g] = a->coef_acc_attn[g];
         p.c_res_m[g] = a->coef_res_mlp[g]; p.c_acc_m[g] = a->coef_acc_mlp[g];
