@@ -184,6 +184,17 @@ def main():
         plan.run(sp)
     ev1.record(sp)
     fwd_ms = ev0.elapsed_ms(ev1) / args.steps
+    # NMS alone on an idle GPU (in the timed region it overlaps the next forward, and its kernels then wait for free CUs)
+    nsp = pipe.nms_stream.cuda_stream
+    torch.cuda.synchronize()
+    from icafusion_amd.utils.general import nms_device
+    nms_device(pipe.zbuf[0], stream_ptr=nsp, runner=pipe.runners[0], **pipe.nms_args)
+    n0, n1 = ops.Event(), ops.Event()
+    n0.record(nsp)
+    for _ in range(20):
+        nms_device(pipe.zbuf[0], stream_ptr=nsp, runner=pipe.runners[0], **pipe.nms_args)
+    n1.record(nsp)
+    nms_ms = n0.elapsed_ms(n1) / 20
     saved_graph, plan.graph = plan.graph, None
     per_kernel = {}
     reps = 3
@@ -234,6 +245,7 @@ def main():
                        "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap},
             "forward_only_pairs_per_s": round(B / (fwd_ms * 1e-3), 2),
             "forward_ms_per_batch": round(fwd_ms, 3),
+            "nms_ms_per_batch_standalone": round(nms_ms, 4),
             "model_tflops": round(gf * B / (fwd_ms * 1e-3) / 1e3, 2) if gf else None,
             "forward_roofline": {      # whole forward: algorithmic FLOPs and leaf-op bytes of all launches over the replay time
                 "tflops": round(sum(v[1] for v in per_kernel.values()) / reps / (fwd_ms * 1e-3) / 1e12, 1),

@@ -295,25 +295,27 @@ __global__ __launch_bounds__(WALK_THREADS) void nms_walk_kernel(const float* __r
         // ------------------------------------------------------------------ gather the keys of [lo, hi) into LDS (any order)
         if (tid == 0) sm.batch_n = 0;
         __syncthreads();
-        for (long long i0 = 0; i0 < cap; i0 += WALK_THREADS) {
-            const long long i = i0 + tid;
-            unsigned long long k = 0ull;
-            bool take = false;
-            if (i < cap) {
-                const unsigned int k32 = kb[i];
-                if (k32) {
-                    k = ((unsigned long long)k32 << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
-                    take = k >= lo && k < hi;
-                }
+        for (long long i0 = 0; i0 < cap; i0 += 8 * WALK_THREADS) {
+            unsigned int k32[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                      // eight independent loads in flight per thread (the scan is latency-bound)
+                const long long i = i0 + u * WALK_THREADS + tid;
+                k32[u] = i < cap ? kb[i] : 0u;
             }
-            const unsigned long long m = __ballot(take);
-            if (m) {
-                unsigned int base = 0;
-                if (lane == 0) base = atomicAdd(&sm.batch_n, (unsigned)__popcll(m));
-                base = __shfl(base, 0);
-                if (take) {
-                    const unsigned int slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                    if (slot < NMS_CAP) sm.keys[slot] = k;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long i = i0 + u * WALK_THREADS + tid;
+                const unsigned long long k = ((unsigned long long)k32[u] << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+                const bool take = k32[u] != 0u && k >= lo && k < hi;
+                const unsigned long long m = __ballot(take);
+                if (m) {
+                    unsigned int base = 0;
+                    if (lane == 0) base = atomicAdd(&sm.batch_n, (unsigned)__popcll(m));
+                    base = __shfl(base, 0);
+                    if (take) {
+                        const unsigned int slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                        if (slot < NMS_CAP) sm.keys[slot] = k;
+                    }
                 }
             }
         }

@@ -726,10 +726,14 @@ class CrossTransformerBlock(HipModule):
 
     # 16-bit types: one iteration = icaf_dmff_ln_qkv + icaf_dmff_attn_mlp (2 launches) instead of 7 (ICAF_DMFF_FUSE=0: A/B switch)
     fuse_block = os.environ.get("ICAF_DMFF_FUSE", "1") != "0"
+    # The fused kernels are built for C <= 512 but USED up to this width: at C <= 128 two workgroups share a CU (2 waves / SIMD) and
+    # the pair of launches beats the seven (MI355X, batch 32, N = 400: 111 vs 145 us); at C = 256 / 512 one workgroup per CU cannot
+    # hide its own latencies and each 64-row tile re-streams all 9 C^2 weights (166 vs 141 us, 430 vs 153 us) — DESIGN.md §11.
+    fuse_max_c = int(os.environ.get("ICAF_DMFF_FUSE_MAX_C", "128"))
 
     def fusable(self, plan, C, N):
         hid, h = self.mlp_vis[0].out_features, self.crossatt.h
-        return (self.fuse_block and plan.dtype in (torch.bfloat16, torch.float16) and C % 64 == 0 and (C // h) % 8 == 0
+        return (self.fuse_block and C <= self.fuse_max_c and plan.dtype in (torch.bfloat16, torch.float16) and C % 64 == 0 and (C // h) % 8 == 0
                 and hid % 128 == 0 and self.mlp_vis[2].in_features == hid
                 and (plan.device.type != "cuda" or ops.dmff_fused_lds_bytes(C, N, h, plan.dtype) is not None)
                 and (plan.device.type == "cuda" or C <= 512))

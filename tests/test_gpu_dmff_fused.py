@@ -24,7 +24,7 @@ def make_block(C, heads, loops, seed):
 
 
 def run_block(blk, tok, B, N, dtype, fused):
-    blk.fuse_block = fused
+    blk.fuse_block, blk.fuse_max_c = fused, 512          # (the plan uses the fused kernels up to C = 128 by default; they are built to 512)
     blk.invalidate()
     plan = Plan(DEV, dtype)
     t = plan.tokens(2, B * N, tok.shape[2])
@@ -86,7 +86,7 @@ def test_fused_dmff_block_vs_reference_golden_16bit(name, dtype):
     ir = torch.from_numpy(rg.normal(0, 1, (batch, c, h, w)).astype(np.float32)).to(DEV)
     errs = {}
     for fused in (True, False):
-        blk.crosstransformer[0].fuse_block = fused
+        blk.crosstransformer[0].fuse_block, blk.crosstransformer[0].fuse_max_c = fused, 512
         blk.invalidate()
         out = blk([rgb, ir]).float().cpu()
         got = out.reshape(-1)[torch.from_numpy(sample_idx(out.numel(), 200, 8192))].numpy()
