@@ -148,6 +148,10 @@ def test_pmc_summary_kernel_names_match_bench_names():
         "void icaf::pool_tokens_rows_kernel<1>(icaf::Elem<1>::type const*, int)": "dmff_pool_tokens",
         "void icaf::pool_tokens_kernel<1>(icaf::Elem<1>::type const*, int)": "dmff_pool_tokens",
         "void icaf::sppf_lds_kernel<1>(icaf::Elem<1>::type const*, int)": "sppf_pool",
+        "void icaf::dmff_attn_mlp_kernel<1, 16, 1, 128>(icaf::DmffP)": "dmff_attn_mlp",
+        "void icaf::dmff_ln_qkv_kernel<1, 128>(icaf::DmffP)": "dmff_ln_qkv",
+        "void icaf::cross_attn_kernel<1, 32>(icaf::Elem<1>::type const*, icaf::Elem<1>::type*, int, int, int, int, int, float)": "cross_attention",
+        "icaf::nms_walk_kernel(float const*, long long, int)": "nms_walk_kernel",
     }
     for raw, want in cases.items():
         assert mod.short(raw) == want, raw

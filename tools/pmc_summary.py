@@ -39,7 +39,8 @@ def short(name):
         return {"preprocess_kernel": "preprocess_s2d", "pool_tokens_kernel": "dmff_pool_tokens", "upsample_merge_kernel": "dmff_upsample_merge",
                 "cross_attn_kernel": "cross_attention", "detect_decode_kernel": "detect_decode", "sppf_lds_kernel": "sppf_pool",
                 "upsample_kernel": "upsample_nearest", "stem_kernel": "stem", "bneck_kernel": "bottleneck",
-                "stem2_kernel": "stem+conv3x3s2+1x1", "pool_tokens_rows_kernel": "dmff_pool_tokens"}.get(m.group(1), m.group(1))
+                "stem2_kernel": "stem+conv3x3s2+1x1", "pool_tokens_rows_kernel": "dmff_pool_tokens",
+                "dmff_attn_mlp_kernel": "dmff_attn_mlp", "dmff_ln_qkv_kernel": "dmff_ln_qkv", "layernorm_kernel": "layernorm"}.get(m.group(1), m.group(1))
     return name[:80]
 
 
