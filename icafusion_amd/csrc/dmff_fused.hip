@@ -276,13 +276,21 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32) ? 2 : 1) void dmff_attn
     float* red = (float*)(ring + Ring<SLB>::BYTES);  // [2][64] row partial sums of the two column halves
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int dir = blockIdx.z, b = blockIdx.y, q0 = blockIdx.x * TMROWS;
+    // Workgroup -> (64-row tile, image, direction).  The tiles of one (image, direction) pair all stage the same K / V^T, and the two
+    // directions of an image read each other's rows as queries: they are placed on ONE XCD (hardware deals consecutive workgroup ids
+    // round-robin over the 8 XCDs), so that those re-reads hit its L2 instead of each XCD fetching its own copy through the fabric
+    // (PMC before: 216 MB fetched per launch at yolov5s P3 / batch 32 for ~30 MB of distinct qkv + token bytes).
+    const int tiles = (N + TMROWS - 1) / TMROWS, pairs = 2 * p.B, bid = blockIdx.x;
+    int pair, tile;
+    if ((pairs & 7) == 0) { const int xcd = bid & 7, slot = bid >> 3; pair = xcd + 8 * (slot / tiles); tile = slot - (slot / tiles) * tiles; }
+    else { pair = bid / tiles; tile = bid - pair * tiles; }
+    const int dir = pair / p.B, b = pair - dir * p.B, q0 = tile * TMROWS;
     const long long rows = (long long)p.B * N, row3 = 3LL * C;
     const T* qkv = (const T*)p.qkv;
     const T* kvb = qkv + ((long long)dir * rows + (long long)b * N) * row3;
     const T* qb = qkv + ((long long)(1 - dir) * rows + (long long)b * N) * row3;
 
-#define DMFF_STAMP(i) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) p.dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define DMFF_STAMP(i) do { if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     DMFF_STAMP(0);
     // ---- A. attention: two heads per round (wave pair = head, wave parity = 32-query tile).  K and V of the NEXT round travel
     //         from L2 into registers while this round computes (its staging loads were the longest serial chain of the kernel:
@@ -647,7 +655,7 @@ static int launch_attn_mlp(const DmffP& p, hipStream_t s) {
         ICAF_HIP(hipFuncSetAttribute((const void*)dmff_attn_mlp_kernel<DT, DKP, NP2, SLB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[dev] = true;
     }
-    dim3 grid((unsigned)((p.N + TMROWS - 1) / TMROWS), (unsigned)p.B, 2u);
+    dim3 grid((unsigned)(((p.N + TMROWS - 1) / TMROWS) * p.B * 2));
     hipLaunchKernelGGL((dmff_attn_mlp_kernel<DT, DKP, NP2, SLB>), grid, dim3(FT), lds, s, p);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
