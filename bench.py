@@ -222,7 +222,7 @@ def main():
     roof.update({"intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
                  "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / PEAK_TFLOPS[args.dtype], 4),
                  "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)})
-    roof.update({"traffic": None, "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_traffic.json)",
+    roof.update({"traffic": None, "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_traffic*.json)",
                  "algorithmic_bytes_per_launch": round(dbytes / dn), "avg_launch_us": round(1e3 * dms / dn, 2), "launches_per_step": dn // reps,
                  "share_of_forward_kernel_time": round(dms / reps / total_ms, 3)})
     att = per_kernel.get("cross_attention")
@@ -260,15 +260,18 @@ def main():
             "plan_buffer_MB": round(plan.nbytes / 2 ** 20, 1),
             "detections_first_image": int(count[0]),
         }
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):          # PMC counters cannot be read from inside this process: the committed summary of
-            pm = json.load(open(tf))    # tools/gpu_pmc.sh (same command line) supplies the dominant kernel's HBM bytes
+        # PMC counters cannot be read from inside this process: the committed summaries of tools/gpu_pmc.sh (same command line, one
+        # file per workload: profiles/pmc_traffic*.json) supply the dominant kernel's HBM bytes
+        import glob
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic*.json"))):
+            pm = json.load(open(tf))
             k = pm.get("kernels", {}).get(dname)
             if pm.get("workload") == out["config"]["workload"] and k \
                     and "fetch_bytes_corrected" in k and "write_bytes_uncorrected" in k:
                 roof["traffic"] = round(k["fetch_bytes_corrected"] + k["write_bytes_uncorrected"])
                 roof["traffic_detail"] = {"fetch_bytes": round(k["fetch_bytes_corrected"]),
-                                          "write_bytes": round(k["write_bytes_uncorrected"])}
+                                          "write_bytes": round(k["write_bytes_uncorrected"]), "source": os.path.basename(tf)}
+                break
         if world == 1 and not args.no_cpu_baseline:
             fused = Model(cfg).eval()
             fused.load_state_dict(sd)

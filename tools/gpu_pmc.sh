@@ -3,16 +3,20 @@
 # together: MI355X_MICROARCH.md "rocprofv3 PMC slots").  Kernel-trace only — no other trace domain is combined with --pmc.
 # Loads the committed igemm tile choices (profiles/tune_cache.json): the same instantiations as tools/gpu_bench.sh.
 # Summary: gpurun_out/pmc_summary.json (copied to profiles/pmc_traffic.json by hand; bench.py reads roofline.traffic there).
+# PMC_NAME=<suffix> writes gpurun_out/pmc_summary_<suffix>.json (default: pmc_summary.json) and installs it as
+# profiles/pmc_traffic_<suffix>.json in the box's copy of the repo, so that a bench.py run later in the same call reports it.
 mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+SUF=${PMC_NAME:+_$PMC_NAME}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o pmc -- \
-      python $R/bench.py --no-cpu-baseline --no-graph --no-overlap --steps 3 --warmup 1 "$@" > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.err
+      python $R/bench.py --no-cpu-baseline --no-graph --no-overlap --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.err
   tail -2 $R/gpurun_out/pmc_$c.err
 done
 cd $R
 W=$(python -c "import json;print(json.load(open('gpurun_out/pmc_FETCH_SIZE.json'))['config']['workload'])")
-python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE "--workload=$W" > gpurun_out/pmc_summary.json
-head -c 1500 gpurun_out/pmc_summary.json
+python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE "--workload=$W" > gpurun_out/pmc_summary$SUF.json
+cp gpurun_out/pmc_summary$SUF.json profiles/pmc_traffic$SUF.json
+echo "pmc summary for: $W"

@@ -1,31 +1,34 @@
 #!/bin/bash
-# Round-2 evidence, one GPU call: every GPU test, the default bench line (with CPU baseline), rocprofv3 kernel stats, the two PMC
-# traffic passes + the SQ (MFMA busy) pass, the per-layer profile, the 16-bit parity table, and bench lines + kernel stats of the
-# per-GPU shards of BASELINE configs 3 / 4 / 5.  Everything lands in gpurun_out/; summaries are copied to profiles/ afterwards.
+# Round-2 evidence, one GPU call: every GPU test; for the default workload and the per-GPU shards of BASELINE configs 3 / 4 / 5: the two
+# PMC traffic passes (installed as profiles/pmc_traffic*.json so that the bench line that follows carries roofline.traffic), the bench
+# line, rocprofv3 kernel stats of the same command; for the default workload also the SQ (MFMA busy) pass, the per-layer profiles and
+# the 16-bit parity table.  Everything lands in gpurun_out/; summaries are copied to profiles/ afterwards.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
-bash tools/gpu_tests.sh 2>&1 | tail -40
-bash tools/gpu_bench.sh 2>&1 | tail -12
-cd $R && bash tools/gpu_pmc.sh 2>&1 | tail -3
-cd $R && bash tools/gpu_pmc_sq.sh 2>&1 | tail -40
-cd $R && timeout 300 python tools/layer_profile.py --autotune > gpurun_out/layer_profile.txt 2>/dev/null; head -2 gpurun_out/layer_profile.txt
-cd $R && timeout 900 python tools/parity16.py --out gpurun_out/parity_16bit.json > gpurun_out/parity16.log 2>&1; tail -2 gpurun_out/parity16.log | cut -c1-300
+bash tools/gpu_tests.sh 2>&1 | tail -30
+cd $R && bash tools/gpu_pmc.sh 2>&1 | tail -2
+cd $R && bash tools/gpu_pmc_sq.sh 2>&1 | grep "dmff\|cross_att\|128x128w8\|256x256 \|stem"
+cd $R && bash tools/gpu_bench.sh 2>&1 | grep -v "^\"\|^W2026" | tail -4
+cd $R && timeout 300 python tools/layer_profile.py --autotune > gpurun_out/layer_profile.txt 2>/dev/null; head -1 gpurun_out/layer_profile.txt
+cd $R && ICAF_DMFF_FUSE=0 timeout 300 python tools/layer_profile.py --autotune > gpurun_out/layer_profile_plain.txt 2>/dev/null; head -1 gpurun_out/layer_profile_plain.txt
+cd $R && timeout 900 python tools/parity16.py --out gpurun_out/parity_16bit.json > gpurun_out/parity16.log 2>&1; tail -1 gpurun_out/parity16.log | cut -c1-200
 run_cfg () {   # name, bench args...
   name=$1; shift
+  cd $R && PMC_NAME=$name bash tools/gpu_pmc.sh --tune-cache $R/profiles/tune_cache_$name.json "$@" 2>&1 | tail -1
   cd $R
-  timeout 900 python bench.py --no-cpu-baseline --tune-cache gpurun_out/tune_$name.json "$@" > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err
+  timeout 900 python bench.py --no-cpu-baseline --tune-cache $R/profiles/tune_cache_$name.json "$@" > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err
   python - "$name" <<'PY'
 import json, sys
 n = sys.argv[1]
 try:
     d = json.load(open(f"gpurun_out/bench_{n}.json"))
-    print(n, {k: d[k] for k in ("value", "value_min", "value_max", "ms_per_step", "forward_only_pairs_per_s", "nms_ms_per_batch_standalone", "forward_roofline")}, d["roofline"]["kernel"], d["roofline"]["frac"])
+    print(n, {k: d[k] for k in ("value", "value_min", "value_max", "ms_per_step", "forward_only_pairs_per_s", "nms_ms_per_batch_standalone", "forward_roofline")}, d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["traffic"], d["roofline"]["algorithmic_bytes_per_launch"])
 except Exception as e:
     print(n, "FAILED", e); print(open(f"gpurun_out/bench_{n}.err").read()[-1500:])
 PY
   cd /tmp && export TMPDIR=/tmp
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$name -o bench -- python $R/bench.py --no-cpu-baseline --tune-cache $R/gpurun_out/tune_$name.json "$@" > $R/gpurun_out/prof_bench_$name.json 2> $R/gpurun_out/prof_$name.err
-  f=$(find $R/gpurun_out/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-140 "$f" | head -6
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$name -o bench -- python $R/bench.py --no-cpu-baseline --tune-cache $R/profiles/tune_cache_$name.json "$@" > $R/gpurun_out/prof_bench_$name.json 2> $R/gpurun_out/prof_$name.err
+  f=$(find $R/gpurun_out/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-140 "$f" | sed -n 2,3p
 }
 run_cfg c3_l_bf16_b32_640 --model l --batch 32
 run_cfg c4_s_bf16_b64_512x640_loops3 --loops 3 --height 512 --width 640 --batch 64
