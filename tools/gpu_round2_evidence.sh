@@ -30,6 +30,8 @@ PY
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$name -o bench -- python $R/bench.py --no-cpu-baseline --tune-cache $R/profiles/tune_cache_$name.json "$@" > $R/gpurun_out/prof_bench_$name.json 2> $R/gpurun_out/prof_$name.err
   f=$(find $R/gpurun_out/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-140 "$f" | sed -n 2,3p
 }
+cd $R && timeout 600 python bench.py --no-cpu-baseline --tune-cache gpurun_out/tune_fresh.json > gpurun_out/bench_fresh_tune.json 2>/dev/null; python -c "
+import json; d = json.load(open('gpurun_out/bench_fresh_tune.json')); print('fresh tuning:', d['value'], d['forward_only_pairs_per_s'])"
 run_cfg c3_l_bf16_b32_640 --model l --batch 32
 run_cfg c4_s_bf16_b64_512x640_loops3 --loops 3 --height 512 --width 640 --batch 64
 run_cfg c5_l_vedai_f16_b16_1280 --model l --dataset VEDAI --dtype f16 --height 1280 --width 1280 --batch 16 --conf 0.3
