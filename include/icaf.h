@@ -253,10 +253,14 @@ int icaf_dmff_attn_mlp_lds_bytes(int C, int N, int heads, int dtype, size_t* byt
 /* ---- NMS (utils/general.py:518-607 + torchvision.ops.nms semantics) ----------------------------------------
  * pred: [B][rows][5+nc] fp32 (cx, cy, w, h, obj, cls...).  Per image: obj > conf filter, conf = obj*cls, best
  * class or multi-label expansion, optional class filter (host int array), top max_nms by score (stable),
- * class-offset boxes, greedy IoU suppression in descending score order, first max_det survivors.
+ * class-offset boxes, greedy IoU suppression in descending score order (ties: ascending candidate index), first
+ * max_det survivors.
  * det: [B][max_det][6] (x1,y1,x2,y2,conf,cls), count: [B], keep_idx: [B][max_det] = indices into the image's
- * candidate list exactly as torchvision.ops.nms would return them (may be NULL).
- */
+ * candidate list exactly as torchvision.ops.nms would return them (may be NULL: one small launch less).
+ * No candidate list and no full sort are materialised: the workspace (icaf_nms_workspace_bytes; 256-byte aligned, contents
+ * irrelevant on entry) holds one 32-bit score key per candidate slot, per-image score histograms and per-chunk candidate counts;
+ * only the score ranges the greedy walk actually reaches are gathered and sorted, in LDS (nms.hip).  Enqueues a memset and
+ * 2-3 kernels on `s`; conf_thres must be >= 0, max_det <= 1024, nc <= 65535, class filter ids 0..255. */
 /* Validation statistics of test.py:196-230 on the device, one workgroup per image: the NMS output block det
  * [B][max_det][6] / count[B] (letterboxed pixel space) is mapped to native image space with scale[b] = {gain, pad_x,
  * pad_y, w0, h0} (scale_coords + clip_coords, utils/general.py:386-407; NULL = already native), every detection is paired
