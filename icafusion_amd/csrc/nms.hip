@@ -553,7 +553,6 @@ extern "C" int icaf_nms(const float* pred, int B, long long rows, int nc, float 
     if (!pred || !det || !count || !workspace) return fail(ICAF_ERR_ARG, "icaf_nms: null pointer");
     if (max_det < 1 || max_det > MAX_KEEP) return fail(ICAF_ERR_ARG, "icaf_nms: max_det must be in [1, %d]", MAX_KEEP);
     if (max_nms < 1) return fail(ICAF_ERR_ARG, "icaf_nms: max_nms must be positive");
-    if (!(conf_thres >= 0.0f)) return fail(ICAF_ERR_ARG, "icaf_nms: conf_thres must be >= 0 (scores are compared as ordered bit patterns of positive floats)");
     if (((uintptr_t)workspace & 255) != 0) return fail(ICAF_ERR_ARG, "icaf_nms: workspace must be 256-byte aligned");
     const int multi = multi_label && nc > 1;
     NmsWs ws;

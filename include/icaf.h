@@ -260,7 +260,7 @@ int icaf_dmff_attn_mlp_lds_bytes(int C, int N, int heads, int dtype, size_t* byt
  * No candidate list and no full sort are materialised: the workspace (icaf_nms_workspace_bytes; 256-byte aligned, contents
  * irrelevant on entry) holds one 32-bit score key per candidate slot, per-image score histograms and per-chunk candidate counts;
  * only the score ranges the greedy walk actually reaches are gathered and sorted, in LDS (nms.hip).  Enqueues a memset and
- * 2-3 kernels on `s`; conf_thres must be >= 0, max_det <= 1024, nc <= 65535, class filter ids 0..255. */
+ * 2-3 kernels on `s`; max_det <= 1024, nc <= 65535, class filter ids 0..255. */
 /* Validation statistics of test.py:196-230 on the device, one workgroup per image: the NMS output block det
  * [B][max_det][6] / count[B] (letterboxed pixel space) is mapped to native image space with scale[b] = {gain, pad_x,
  * pad_y, w0, h0} (scale_coords + clip_coords, utils/general.py:386-407; NULL = already native), every detection is paired
