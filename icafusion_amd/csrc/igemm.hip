@@ -425,155 +425,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvP p) {
     epilogue<DT, ODT, BM, BN, WM, WN, ACT, false>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
 }
 
-// ===============================================================================================================
-// register-staged pipeline with a DEEP prefetch (pipeline id 5)
-// ===============================================================================================================
-// The LDS-DMA ring keeps NS - 1 slices of a workgroup in flight and LDS capacity caps NS x workgroups per CU at ~4 stages of a
-// 128x128 tile, i.e. ~64 KB in flight per CU; the layers whose pixel operand comes from HBM / MALL in 128-byte pieces wait for every
-// slice (PMC: waves 50-70 % of their life in s_waitcnt; a 40x40 3x3 layer spends 27 us per workgroup round on 1.9 us of MFMA work).
-// Registers are the larger buffer (512 KB per CU): here D 64-byte slices per workgroup travel global -> VGPR (4 registers per thread
-// and slice for the 128x128 tile), the slice needed next is written to one of TWO padded LDS buffers, and only 40 KB of LDS per
-// workgroup leave room for 3-4 workgroups per CU.  Loads are unconditional from clamped addresses (a load inside a conditional is
-// waited for at the end of the block) and the per-slice barrier orders LDS traffic only (__syncthreads would drain vmcnt, i.e. the
-// prefetch).  Same K order and MFMA step as every other pipeline => bit-identical results.
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int D>
-__global__ __launch_bounds__(NTHREADS) void igemm_regd_kernel(const ConvP p) {
-    using E = Elem<DT>;
-    using L = TileLds<DT, ODT, BM, BN>;
-    constexpr int VEC = E::VEC;
-    constexpr int BK = ROWB / E::BYTES;
-    constexpr int NA = BM * 4 / NTHREADS;
-    constexpr int NBv = BN * 4 / NTHREADS;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int WAVES_M = BM / WM;
-    constexpr int LDS_BYTES = L::REG_BYTES > L::OUT_BYTES ? L::REG_BYTES : L::OUT_BYTES;
-    static_assert((BM / WM) * (BN / WN) == 4 && BN % 64 == 0 && BM % 64 == 0, "4 waves per workgroup, whole 64-row groups");
-    static_assert(LDS_BYTES <= 65536, "static LDS limit");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int g = blockIdx.z;
-    const int tile = xcd_tile(p.mtiles * p.ntiles);
-    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const typename E::type* __restrict__ xg = (const typename E::type*)p.x + g * p.x_gs;
-    const typename E::type* __restrict__ wg = (const typename E::type*)p.w + g * p.w_gs;
-
-    long long a_base[NA];
-    int a_h0[NA], a_w0[NA];
-    bool a_ok[NA];
-    const int kv = tid & 3;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int row = (tid >> 2) + i * (NTHREADS / 4);
-        const int m = m0 + row;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
-        const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, b = t / p.Ho;
-        a_h0[i] = ho * p.sh - p.ph;
-        a_w0[i] = wo * p.sw - p.pw;
-        a_base[i] = (long long)b * p.H * p.W * p.ldx;
-    }
-    int kc = kv * VEC, ky = 0, kx = 0;
-    // tap walk without branches (a divergent loop between the loads makes the wait-count bookkeeping give up and drain them):
-    // a 64-byte chunk spans at most BK / VEC taps' worth of channels
-    auto wrap = [&]() {
-#pragma unroll
-        for (int r = 0; r < BK / VEC; ++r) {
-            const bool w = kc >= p.Cin;
-            kc -= w ? p.Cin : 0;
-            kx += w ? 1 : 0;
-            const bool wy = kx == p.kw;
-            kx = wy ? 0 : kx;
-            ky += wy ? 1 : 0;
-        }
-    };
-    wrap();
-    const long long w_row = (long long)(n0 + (tid >> 2)) * p.Kp + kv * VEC;
-
-    u32x4 ra[D][NA], rb[D][NBv];
-    unsigned zmask[D];                                                         // bit i: pixel vector i of the slot is padding / out of range
-    auto load_tiles = [&](int chunk, u32x4 (&a)[NA], u32x4 (&b)[NBv], unsigned& zm) {       // chunks are requested in ascending order
-        const bool kvalid = ky < p.kh;
-        zm = 0;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int h = a_h0[i] + ky, w = a_w0[i] + kx;
-            const bool ok = a_ok[i] && kvalid && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-            a[i] = *(const u32x4*)(xg + (ok ? a_base[i] + ((long long)h * p.W + w) * p.ldx + kc : 0));     // zeroed where it is CONSUMED
-            zm |= ok ? 0u : (1u << i);
-        }
-        const int cw = chunk < p.nchunks ? chunk : p.nchunks - 1;        // loads past the end are issued anyway (see the main loop) and never stored
-#pragma unroll
-        for (int i = 0; i < NBv; ++i) b[i] = *(const u32x4*)(wg + w_row + (long long)i * (NTHREADS / 4) * p.Kp + (long long)cw * BK);
-        kc += BK;
-        wrap();
-    };
-    auto store_tiles = [&](int buf, const u32x4 (&a)[NA], const u32x4 (&b)[NBv], unsigned zm) {
-        unsigned char* a_s = lds + buf * (BM + BN) * ROWS;
-        unsigned char* b_s = a_s + BM * ROWS;
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-            *(u32x4*)(a_s + ((tid >> 2) + i * (NTHREADS / 4)) * ROWS + kv * 16) = ((zm >> i) & 1u) ? u32x4{0u, 0u, 0u, 0u} : a[i];
-#pragma unroll
-        for (int i = 0; i < NBv; ++i) *(u32x4*)(b_s + ((tid >> 2) + i * (NTHREADS / 4)) * ROWS + kv * 16) = b[i];
-    };
-
-    f32x16 acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
-
-    auto compute = [&](int c) {
-        const unsigned char* a_s = lds + (c & 1) * (BM + BN) * ROWS;
-        const unsigned char* b_s = a_s + BM * ROWS;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            u32x4 fp[TM], fw[TN];
-#pragma unroll
-            for (int b = 0; b < TM; ++b) fp[b] = *(const u32x4*)(a_s + (wm * WM + b * 32 + l31) * ROWS + s * 32 + hi * 16);
-#pragma unroll
-            for (int a = 0; a < TN; ++a) fw[a] = *(const u32x4*)(b_s + (wn * WN + a * 32 + l31) * ROWS + s * 32 + hi * 16);
-#pragma unroll
-            for (int a = 0; a < TN; ++a)
-#pragma unroll
-                for (int b = 0; b < TM; ++b) mma_step<DT>(acc[a][b], fw[a], fp[b]);
-        }
-    };
-    // Every load of the steady state is UNCONDITIONAL (chunks past the end read clamped addresses and are never stored): a load
-    // behind a branch makes the compiler's wait-count bookkeeping assume nothing younger is in flight, i.e. s_waitcnt vmcnt(0)
-    // in front of every LDS write — which drains the whole prefetch (seen in the ISA of the first version).
-#pragma unroll
-    for (int j = 0; j < D; ++j) load_tiles(j, ra[j], rb[j], zmask[j]);
-    store_tiles(0, ra[0], rb[0], zmask[0]);
-    lds_barrier();
-    int c0 = 0;
-    for (; c0 + D <= p.nchunks; c0 += D) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const int c = c0 + j;                          // chunk c lives in register slot j (already copied to LDS buffer c & 1)
-            load_tiles(c + D, ra[j], rb[j], zmask[j]);
-            compute(c);
-            if (c + 1 < p.nchunks) store_tiles((c + 1) & 1, ra[(j + 1) % D], rb[(j + 1) % D], zmask[(j + 1) % D]);
-            lds_barrier();
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < D - 1; ++j) {                      // the last nchunks % D chunks: slot j = chunk c0 + j, nothing left to load
-        const int c = c0 + j;
-        if (c >= p.nchunks) break;
-        compute(c);
-        if (c + 1 < p.nchunks) store_tiles((c + 1) & 1, ra[j + 1], rb[j + 1], zmask[j + 1]);
-        lds_barrier();
-    }
-    __syncthreads();
-    epilogue<DT, ODT, BM, BN, WM, WN, ACT, false>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -585,7 +436,6 @@ static const TileCfg kTiles[] = {{1, 128, 128, "128x128"}, {2, 128, 64, "128x64"
 // Launch configuration id = tile (1..4) + 10 * pipeline:
 //   pipeline 0: LDS-DMA, 64-byte slices, 3-stage ring      pipeline 1: register-staged (fallback)
 //   pipeline 2: LDS-DMA, 128-byte slices, 2-stage ring     pipeline 3: LDS-DMA, 128-byte slices, 3-stage ring
-//   pipeline 5: register-staged with 4 slices of prefetch (tiles 1, 2, 4: ids 51, 52, 54)
 // Tiles 8 (128x128) and 9 (128x64) are the 128-row tiles with 8 wavefronts (the tuner uses 8: +1.3 % on the forward; 9 wins
 // isolated timings but loses in the graph, where it competes with the DMFF branches for wave slots, so it is not a candidate).
 // Tiles 5 (256x128) and 6 (256x256) are 8-wavefront workgroups (one per CU, 96 / 128 KB ring) that exist only on
@@ -607,7 +457,6 @@ static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
         return (pipe != 1 && !dma_ok) ? a->tile % 10 + 10 : a->tile;
     }
     if (a->tile == 25 || a->tile == 26 || a->tile == 28 || a->tile == 29) return a->tile;          // validated in launch_tile
-    if (a->tile == 51 || a->tile == 52 || a->tile == 54) return a->tile;                           // deep-prefetch register pipeline
     const bool f32 = a->dtype == ICAF_F32 || a->out_dtype == ICAF_F32;
     const int N = a->Cout;
     const long long M = p.M;
@@ -695,13 +544,6 @@ static int launch_act(const ConvP& q, dim3 grid, int pipe, hipStream_t s) {
         case 0: return launch_dma<DT, ODT, BM, BN, WM, WN, ACT, 64, 3>(q, grid, s);
         case 2: return launch_dma<DT, ODT, BM, BN, WM, WN, ACT, 128, 2>(q, grid, s);
         case 3: return launch_dma<DT, ODT, BM, BN, WM, WN, ACT, 128, 3>(q, grid, s);
-        case 5:
-            if (q.pre || q.w2) return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: `pre` / chained 1x1 are not built for the register-staged pipelines");
-            if constexpr ((BM / WM) * (BN / WN) == 4 && BM % 64 == 0 && BN % 64 == 0) {
-                igemm_regd_kernel<DT, ODT, BM, BN, WM, WN, ACT, 4><<<grid, dim3(NTHREADS), 0, s>>>(q);
-                ICAF_LAUNCH_CHECK();
-                return ICAF_OK;
-            } else return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: the deep-prefetch register pipeline is built for tiles 128x128 / 128x64 / 64x64");
         default:
             if (q.pre || q.w2) return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: `pre` / chained 1x1 are not built for the register-staged pipeline");
             igemm_kernel<DT, ODT, BM, BN, WM, WN, ACT><<<grid, dim3(NTHREADS), 0, s>>>(q);
@@ -715,7 +557,7 @@ static int launch_cfg(const ConvP& p, int groups, int pipe, hipStream_t s) {
     ConvP q = p;
     q.mtiles = (p.M + BM - 1) / BM;
     q.ntiles = (p.Cout + BN - 1) / BN;
-    if (pipe != 1 && pipe != 5) {       // the DMA pipelines walk K in RB-byte slices (the register pipelines: 64-byte chunks, as fill() set)
+    if (pipe != 1) {       // the DMA pipelines walk K in RB-byte slices
         const int eb = DT == ICAF_F32 ? 4 : 2, bk = (pipe == 0 ? 64 : 128) / eb;
         q.nchunks = (p.K + bk - 1) / bk;
     }
@@ -875,7 +717,7 @@ extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int b
         snprintf(buf, buf_len, "ctile_%s_%s", dn[a->dtype], ctile_tag(tile - 40));
         return ICAF_OK;
     }
-    static const char* pn[] = {"_dma64x3", "_reg", "_dma128x2", "_dma128x3", "_?", "_regd4"};
+    static const char* pn[] = {"_dma64x3", "_reg", "_dma128x2", "_dma128x3"};
     snprintf(buf, buf_len, "igemm%s_%s_%s_%s", pn[tile / 10], dn[a->dtype], dn[a->out_dtype], kTiles[tile % 10 - 1].tag);
     return ICAF_OK;
 }

@@ -228,11 +228,6 @@ def conv_candidates(a):
             if t == 3 and a.Cout > 32:
                 continue
             cands.append(t + 10 * pipe)
-    if not a.pre and not a.w2:                        # register-staged pipeline with 4 slices of prefetch (igemm_regd_kernel)
-        for t in (1, 2, 4):
-            if t == 1 and (a.out_dtype == F32 or a.Cout <= 64):
-                continue
-            cands.append(t + 50)
     if a.dtype != F32 and a.out_dtype == a.dtype and not a.pre and not a.w2:            # 8-wavefront tiles (128-byte LDS-DMA pipeline only)
         if a.Cout >= 128:
             cands.append(25)

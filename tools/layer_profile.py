@@ -63,10 +63,8 @@ if a.sweep:
         seen[key] = i
         auto = "?"
         res = []
-        for pipe in (0, 1, 2, 3, 5):
+        for pipe in (0, 1, 2, 3):
           for t in (1, 2, 3, 4):
-            if pipe == 5 and t == 3:
-                continue
             if t == 1 and (c.out_dtype == 0 or c.Cout <= 64):
                 continue
             if t == 3 and c.Cout > 32:

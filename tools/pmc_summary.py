@@ -24,10 +24,6 @@ def short(name):
         dt, odt, bm, bn, wm, wn, rb, ns = map(int, m.groups())
         w8 = "w8" if bm == 128 and (bm // wm) * (bn // wn) == 8 else ""          # 8-wavefront build of a 128-row tile
         return f"igemm_dma{rb}x{ns}_{_DN[dt]}_{_DN[odt]}_{bm}x{bn}{w8}"
-    m = re.match(r"icaf::igemm_regd_kernel<(\d+), (\d+), (\d+), (\d+),", name)
-    if m:
-        dt, odt, bm, bn = map(int, m.groups())
-        return f"igemm_regd4_{_DN[dt]}_{_DN[odt]}_{bm}x{bn}"
     m = re.match(r"icaf::igemm_kernel<(\d+), (\d+), (\d+), (\d+),", name)
     if m:
         dt, odt, bm, bn = map(int, m.groups())
