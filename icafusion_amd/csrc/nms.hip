@@ -45,7 +45,7 @@ constexpr int NMS_NB = 2178;                 // histogram bins over the upper 16
 constexpr unsigned NMS_BIN_LO = 0xB700u;     // bin 0 = everything below 2^-17 (and negative scores), bin NB-1 = [1.0, inf)
 constexpr int NMS_CAP = 4096;                // keys gathered / sorted per round
 constexpr int NMS_FIRST = 1024;              // target of the first round (the walk usually ends inside it)
-constexpr int NMS_CHUNK_ROWS = 1024;         // prediction rows per nms_keys workgroup
+constexpr int NMS_CHUNK_ROWS = 4096;         // prediction rows per nms_keys workgroup (one histogram flush per 4096 rows)
 constexpr int MAX_KEEP = 1024;
 constexpr int WALK_THREADS = 1024;
 
@@ -77,36 +77,46 @@ __global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__
     const float* pb = pred + (long long)b * rows * no;
     unsigned int* kb = key32 + (long long)b * cap;
     int cnt = 0;
+    for (int it0 = 0; it0 < NMS_CHUNK_ROWS / 256; it0 += 4) {
+        // four rows per thread at a time: their objectness loads are issued together (the kernel is latency-bound otherwise)
+        long long rr[4];
+        float objs[4];
 #pragma unroll
-    for (int it = 0; it < NMS_CHUNK_ROWS / 256; ++it) {
-        const long long r = (long long)chunk * NMS_CHUNK_ROWS + it * 256 + tid;
-        if (r >= rows) break;
-        const float* p = pb + r * no;
-        const float obj = p[4];
-        if (multi) {
-            for (int j = 0; j < nc; ++j) {
-                unsigned int k = 0;
-                if (obj > conf) {
-                    const float c = p[5 + j] * obj;
-                    if (c > conf && class_ok(cm, use_cm, j)) k = ordered_bits(c);
+        for (int u = 0; u < 4; ++u) {
+            rr[u] = (long long)chunk * NMS_CHUNK_ROWS + (it0 + u) * 256 + tid;
+            objs[u] = rr[u] < rows ? pb[rr[u] * no + 4] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long r = rr[u];
+            if (r >= rows) continue;
+            const float* p = pb + r * no;
+            const float obj = objs[u];
+            if (multi) {
+                for (int j = 0; j < nc; ++j) {
+                    unsigned int k = 0;
+                    if (obj > conf) {
+                        const float c = p[5 + j] * obj;
+                        if (c > conf && class_ok(cm, use_cm, j)) k = ordered_bits(c);
+                    }
+                    kb[r * nc + j] = k;
+                    if (k) { atomicAdd(&hist[bin_of(k)], 1u); ++cnt; }
                 }
-                kb[r * nc + j] = k;
+            } else {
+                unsigned int k = 0;
+                int best_j = 0;
+                if (obj > conf) {
+                    float best = -INFINITY;
+                    for (int j = 0; j < nc; ++j) {
+                        const float c = p[5 + j] * obj;
+                        if (c > best) { best = c; best_j = j; }
+                    }
+                    if (best > conf && class_ok(cm, use_cm, best_j)) k = ordered_bits(best);
+                }
+                kb[r] = k;
+                cls16[(long long)b * rows + r] = (unsigned short)best_j;
                 if (k) { atomicAdd(&hist[bin_of(k)], 1u); ++cnt; }
             }
-        } else {
-            unsigned int k = 0;
-            int best_j = 0;
-            if (obj > conf) {
-                float best = -INFINITY;
-                for (int j = 0; j < nc; ++j) {
-                    const float c = p[5 + j] * obj;
-                    if (c > best) { best = c; best_j = j; }
-                }
-                if (best > conf && class_ok(cm, use_cm, best_j)) k = ordered_bits(best);
-            }
-            kb[r] = k;
-            cls16[(long long)b * rows + r] = (unsigned short)best_j;
-            if (k) { atomicAdd(&hist[bin_of(k)], 1u); ++cnt; }
         }
     }
 #pragma unroll
