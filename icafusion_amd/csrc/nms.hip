@@ -415,26 +415,29 @@ __global__ __launch_bounds__(WALK_THREADS) void nms_walk_kernel(const float* __r
                 if (lane == 0 && dm) atomicOr(&sm.deadmask, dm);
                 __syncthreads();
                 if (wave == 0) {
-                    // phase B: resolve the step in order; each surviving candidate is kept and suppresses later lanes
-                    unsigned long long alive = ~sm.deadmask;
+                    // phase B: resolve the step in order; each surviving candidate is kept and suppresses later lanes.  The serial loop
+                    // only decides (ffs, five v_readlane broadcasts of the kept lane's box, one IoU per lane, one ballot: ~40 instructions
+                    // per kept box); the kept entries are written afterwards by all kept lanes at once.
+                    unsigned long long alive = ~sm.deadmask, keptmask = 0ull;
+                    const unsigned int nkept0 = nkept;
                     while (alive && nkept < (unsigned)max_det) {
                         const int j = __ffsll((long long)alive) - 1;          // wave-uniform
                         alive &= ~(1ull << j);
-                        // the kept candidate's box comes from lane j's registers (v_readlane: no LDS round trip in this serial chain)
+                        keptmask |= 1ull << j;
+                        ++nkept;
                         const float jx1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x1), j));
                         const float jy1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y1), j));
                         const float jx2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x2), j));
                         const float jy2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y2), j));
                         const float jar = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, area), j));
-                        const unsigned int cj = c0 + (unsigned)j;
-                        if (lane == j) {
-                            sm.kx1[nkept] = x1; sm.ky1[nkept] = y1; sm.kx2[nkept] = x2; sm.ky2[nkept] = y2; sm.kar[nkept] = area;
-                            sm.kslot[nkept] = 0xffffffffu - (unsigned)(sm.keys[base + cj] & 0xffffffffull);
-                            sm.kpos[nkept] = processed + base + cj;
-                        }
-                        ++nkept;
                         const bool over = iou_gt(jx1, jy1, jx2, jy2, jar, x1, y1, x2, y2, area, iou_thr);
-                        alive &= ~__ballot(over && lane > j);
+                        alive &= ~(__ballot(over) & ~((2ull << j) - 1ull));    // only lanes behind j
+                    }
+                    if ((keptmask >> lane) & 1ull) {
+                        const unsigned int kk = nkept0 + (unsigned)__popcll(keptmask & ((1ull << lane) - 1ull));
+                        sm.kx1[kk] = x1; sm.ky1[kk] = y1; sm.kx2[kk] = x2; sm.ky2[kk] = y2; sm.kar[kk] = area;
+                        sm.kslot[kk] = 0xffffffffu - (unsigned)(sm.keys[base + ci] & 0xffffffffull);
+                        sm.kpos[kk] = processed + base + ci;
                     }
                     if (lane == 0) { sm.nkept = nkept; sm.deadmask = 0ull; }
                 }
