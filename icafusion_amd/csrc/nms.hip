@@ -194,6 +194,7 @@ struct WalkSmem {
     unsigned int dh[256];
     unsigned int wsum[16];
     unsigned long long deadmask;
+    unsigned long long supp[64];                                          // supp[j]: lanes of the step that candidate j suppresses
     unsigned long long lo, hi;
     unsigned int batch_n, sel_cnt, sel_val, nkept;
     int mode_b_bin;
@@ -413,25 +414,35 @@ __global__ __launch_bounds__(WALK_THREADS) void nms_walk_kernel(const float* __r
                 }
                 const unsigned long long dm = __ballot(dead);
                 if (lane == 0 && dm) atomicOr(&sm.deadmask, dm);
+                // ... and the step's own 64 x 64 suppression relation, four candidates j per wavefront: supp[j] = the lanes that
+                // overlap candidate j (box broadcast from lane j's registers); the serial pass below then needs no IoU at all
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = wave * 4 + u;
+                    const float jx1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x1), j));
+                    const float jy1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y1), j));
+                    const float jx2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x2), j));
+                    const float jy2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y2), j));
+                    const float jar = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, area), j));
+                    const bool over = iou_gt(jx1, jy1, jx2, jy2, jar, x1, y1, x2, y2, area, iou_thr);
+                    const unsigned long long m = __ballot(over && valid);
+                    if (lane == 0) sm.supp[j] = m;
+                }
                 __syncthreads();
                 if (wave == 0) {
-                    // phase B: resolve the step in order; each surviving candidate is kept and suppresses later lanes.  The serial loop
-                    // only decides (ffs, five v_readlane broadcasts of the kept lane's box, one IoU per lane, one ballot: ~40 instructions
-                    // per kept box); the kept entries are written afterwards by all kept lanes at once.
+                    // phase B: resolve the step in order — a kept candidate j removes the LATER lanes of supp[j].  Lane l holds supp[l]
+                    // in registers; per kept box the serial pass is a find-first-set, two v_readlane and scalar mask arithmetic.
+                    const unsigned long long mysupp = sm.supp[lane];
+                    const int slo = (int)(unsigned)(mysupp & 0xffffffffull), shi = (int)(unsigned)(mysupp >> 32);
                     unsigned long long alive = ~sm.deadmask, keptmask = 0ull;
                     const unsigned int nkept0 = nkept;
                     while (alive && nkept < (unsigned)max_det) {
                         const int j = __ffsll((long long)alive) - 1;          // wave-uniform
-                        alive &= ~(1ull << j);
                         keptmask |= 1ull << j;
                         ++nkept;
-                        const float jx1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x1), j));
-                        const float jy1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y1), j));
-                        const float jx2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x2), j));
-                        const float jy2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y2), j));
-                        const float jar = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, area), j));
-                        const bool over = iou_gt(jx1, jy1, jx2, jy2, jar, x1, y1, x2, y2, area, iou_thr);
-                        alive &= ~(__ballot(over) & ~((2ull << j) - 1ull));    // only lanes behind j
+                        const unsigned long long sj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(shi, j) << 32) |
+                                                      (unsigned long long)(unsigned)__builtin_amdgcn_readlane(slo, j);
+                        alive &= ~((sj & ~((2ull << j) - 1ull)) | (1ull << j));
                     }
                     if ((keptmask >> lane) & 1ull) {
                         const unsigned int kk = nkept0 + (unsigned)__popcll(keptmask & ((1ull << lane) - 1ull));
