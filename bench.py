@@ -50,6 +50,7 @@ def parse():
                     "`value` is the median run, min / max are reported beside it")
     ap.add_argument("--no-fuse-tail", action="store_true", help="materialise DMFF's merged tensor instead of the fused-tail GEMM")
     ap.add_argument("--no-overlap", action="store_true", help="run NMS on the forward stream (no cross-batch overlap)")
+    ap.add_argument("--fold-upsample", action="store_true", help="head rows Upsample -> Concat -> C3: run the up-sampled half of the 1x1 at low resolution")
     ap.add_argument("--tune-cache", default=None, help="json file: load igemm tile choices if present, save after tuning")
     return ap.parse_args()
 
@@ -128,6 +129,7 @@ def main():
     model = model.to(dev)
     model.compute_dtype = DT[args.dtype]
     model.static_outputs = True
+    model.fold_upsample = args.fold_upsample
     model.autotune = not args.no_autotune
     B, H, W = args.batch, args.height, args.width
     default_cache = os.path.join(ROOT, "profiles", "tune_cache.json")     # committed igemm tile choices: the same kernels

@@ -525,12 +525,12 @@ static int launch_dma(const ConvP& q, dim3 grid, hipStream_t s) {
                                           "Cin*bytes %% %d == 0, no pre term, a residual only together with chain_keep, on pipelines 0 / 2", RB);
     }
     if (q.pre) {      // pre-activation bilinear term (DMFF fused tail): 1x1 + SiLU on the 128-row tiles only
-        if constexpr (ACT == ICAF_ACT_SILU && ODT == DT && BM == 128 && (BM / WM) * (BN / WN) == 4 && NS * RB != 384) {
+        if constexpr (ACT == ICAF_ACT_SILU && ODT == DT && BM == 128 && NS * RB != 384) {      // 4- and 8-wavefront 128-row tiles
             if (whole_taps && q.kh == 1 && q.kw == 1 && q.sh == 1 && q.sw == 1 && q.ph == 0 && q.pw == 0)
                 return launch_dma_mode<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, 1, true>(q, grid, s);
         }
         return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: `pre` is built for 1x1 / stride 1 SiLU layers with Cin*bytes %% %d == 0 on tiles 128x128 / 128x64 "
-                                          "(pipelines 0 and 2)", RB);
+                                          "(pipelines 0 and 2; 8-wavefront 128x128 on pipeline 2)", RB);
     }
     if (whole_taps && q.kh == 1 && q.kw == 1 && q.sh == 1 && q.sw == 1 && q.ph == 0 && q.pw == 0)
         return launch_dma_mode<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, 1>(q, grid, s);

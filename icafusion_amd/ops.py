@@ -221,6 +221,8 @@ def conv_candidates(a):
         cands = [t, t + 20]
     elif a.pre:                          # pre-activation term: built for tiles 128x128 / 128x64 on the LDS-DMA pipelines 0 / 2
         cands = [t + 10 * pipe for pipe in (0, 2) for t in (1, 2) if not (t == 1 and (a.out_dtype == F32 or a.Cout <= 64))]
+        if a.dtype != F32 and a.out_dtype == a.dtype and a.Cout >= 128 and (a.Cin * 2) % 128 == 0:
+            cands.append(28)                 # the 8-wavefront 128x128 tile carries the pre term as well
     for pipe in (() if (a.pre or a.w2) else CONV_PIPELINES):
         for t in (1, 2, 3, 4):
             if t == 1 and (a.out_dtype == F32 or a.Cout <= 64):
