@@ -50,6 +50,7 @@ def parse():
                     "`value` is the median run, min / max are reported beside it")
     ap.add_argument("--no-fuse-tail", action="store_true", help="materialise DMFF's merged tensor instead of the fused-tail GEMM")
     ap.add_argument("--no-overlap", action="store_true", help="run NMS on the forward stream (no cross-batch overlap)")
+    ap.add_argument("--depth", type=int, default=1, help="batches in flight (each with its own plan and forward stream)")
     ap.add_argument("--fold-upsample", action="store_true", help="head rows Upsample -> Concat -> C3: run the up-sampled half of the 1x1 at low resolution")
     ap.add_argument("--tune-cache", default=None, help="json file: load igemm tile choices if present, save after tuning")
     return ap.parse_args()
@@ -139,14 +140,15 @@ def main():
         ops.load_tune_cache(default_cache)
     model.use_graph = not args.no_graph
     pipe = DetectionPipeline(model, B, H, W, dev, conf_thres=args.conf, iou_thres=args.iou, world=world,
-                             overlap=not args.no_overlap)
+                             overlap=not args.no_overlap, depth=args.depth)
     plan = pipe.plan
     if args.tune_cache and rank == 0:
         ops.save_tune_cache(args.tune_cache)
     # inputs resident in HBM before the timed region: each rank synthesises its own shard of the global batch
     rgb, ir = synth_images(B, H, W, seed=100 + rank)
-    plan.inputs[0].copy_(rgb.to(dev))
-    plan.inputs[1].copy_(ir.to(dev))
+    for pl in pipe.plans:
+        pl.inputs[0].copy_(rgb.to(dev))
+        pl.inputs[1].copy_(ir.to(dev))
     nc = cfg["nc"]
     sp = pipe.fwd_stream.cuda_stream
     torch.cuda.synchronize()
@@ -244,7 +246,7 @@ def main():
             "config": {"workload": f"{yaml_name[:-5]} + DMFF(loops={args.loops}) {args.dtype}, batch {B}/GPU, "
                                    f"{H}x{W} synthetic RGB/IR pairs, seeded random weights, NMS conf {args.conf} iou {args.iou}",
                        "global_batch": B * world, "parallelism": f"dp{world} (pairs sharded, one all-gather of detections)",
-                       "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap},
+                       "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap, "batches_in_flight": args.depth},
             "forward_only_pairs_per_s": round(B / (fwd_ms * 1e-3), 2),
             "forward_ms_per_batch": round(fwd_ms, 3),
             "nms_ms_per_batch_standalone": round(nms_ms, 4),

@@ -502,7 +502,7 @@ class Model(HipModule):
             return z, logits, raws
         return z.clone(), logits.clone(), [r.clone() for r in raws]
 
-    def plan_for(self, B, H, W, device="cuda", dtype=None, u8=False):
+    def plan_for(self, B, H, W, device="cuda", dtype=None, u8=False, slot=0):
         """Pre-build (and return) the execution plan; its .inputs are the static RGB / IR staging buffers (u8: the one
         uint8 6-channel staging buffer).  Plans live in a least-recently-used cache capped at `plan_cache_bytes` of plan-owned
         buffers: a validation run with rectangular batches and a ragged last batch (test.py) meets a new (B, H, W) every few
@@ -513,6 +513,8 @@ class Model(HipModule):
         if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         key = (B, H, W, dt, device, "u8") if u8 else (B, H, W, dt, device)
+        if slot:                                    # further plans of the same shape (own buffers): batches in flight side by side
+            key = key + ("slot", slot)
         plans = self.__dict__.setdefault("_plans", {})
         plan = plans.pop(key, None)
         if plan is None:

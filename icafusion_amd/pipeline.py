@@ -22,15 +22,21 @@ from .utils.general import nms_device
 
 class DetectionPipeline:
     def __init__(self, model, batch, height, width, device, conf_thres=0.25, iou_thres=0.45, classes=None,
-                 agnostic=False, multi_label=False, max_det=300, world=1, overlap=True, force_gather=False):
+                 agnostic=False, multi_label=False, max_det=300, world=1, overlap=True, force_gather=False, depth=1):
         self.model, self.device, self.world = model, torch.device(device), world
         self.gather = world > 1 or bool(force_gather)       # force_gather: run the all-gather even with one rank (hardware test of the RCCL path)
         self.nms_args = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic,
                              multi_label=multi_label, max_det=max_det)
         model.static_outputs = True
-        self.plan = model.plan_for(batch, height, width, self.device)
+        # depth > 1: that many batches in flight, each with its own plan (buffers, hipGraph) and forward stream — the tails of one
+        # forward (20x20 layers, DMFF, Detect: launches that leave CUs idle) overlap the full-width layers of the next
+        self.depth = max(1, int(depth))
+        self.plans = [model.plan_for(batch, height, width, self.device, slot=s) for s in range(self.depth)]
+        self.plan = self.plans[0]
         self.z = self.plan.outputs[0]
-        self.fwd_stream = torch.cuda.Stream(device=self.device)
+        self.fwd_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        self.fwd_stream = self.fwd_streams[0]
+        self.fwd_done = [torch.cuda.Event() for _ in range(self.depth)]
         self.nms_stream = torch.cuda.Stream(device=self.device) if overlap else self.fwd_stream
         self.overlap = overlap
         self.zbuf = [torch.empty_like(self.z) for _ in range(2)] if overlap else [self.z]
@@ -42,17 +48,25 @@ class DetectionPipeline:
         self.runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False) for _ in range(nslots)]
         self.gathered = [torch.empty((world * batch, max_det * 6 + 1), dtype=torch.float32, device=self.device)
                          for _ in range(nslots)] if self.gather else None
+        if self.depth > 1:
+            self.nms_stream = torch.cuda.Stream(device=self.device)
+            self.deep_runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False) for _ in range(self.depth)]
+            self.nms_done_deep = [torch.cuda.Event() for _ in range(self.depth)]
+            self.deep_gathered = [torch.empty((world * batch, max_det * 6 + 1), dtype=torch.float32, device=self.device)
+                                  for _ in range(self.depth)] if self.gather else None
         self.n = 0
         self.last = None
 
     @property
     def inputs(self):
-        """Static RGB / IR staging tensors (NCHW fp32); fill them, then call step()."""
-        return self.plan.inputs
+        """Static RGB / IR staging tensors (NCHW fp32) of the NEXT step's plan; fill them, then call step()."""
+        return self.plans[self.n % self.depth].inputs
 
     def step(self):
         """Enqueue one batch: forward replay, then NMS (+ gather) on the second stream.  Returns (det, count[, all])
         device tensors that are valid once the nms stream has drained (see synchronize())."""
+        if self.depth > 1:
+            return self._step_deep()
         i = (self.n & 1) if self.overlap else 0
         fs, ns = self.fwd_stream, self.nms_stream
         self.plan.run(fs.cuda_stream)
@@ -74,8 +88,29 @@ class DetectionPipeline:
         self.last = out
         return out
 
+    def _step_deep(self):
+        """depth batches in flight: batch n runs plan n % depth on its own stream; its NMS reads that plan's z directly (no
+        snapshot: the plan is not replayed before its NMS has finished)."""
+        d = self.n % self.depth
+        fs, ns, plan = self.fwd_streams[d], self.nms_stream, self.plans[d]
+        if self.n >= self.depth:
+            fs.wait_event(self.nms_done_deep[d])           # NMS of batch n - depth has finished reading this plan's z
+        plan.run(fs.cuda_stream)
+        self.fwd_done[d].record(fs)
+        ns.wait_event(self.fwd_done[d])
+        det, count, keep = nms_device(plan.outputs[0], stream_ptr=ns.cuda_stream, runner=self.deep_runners[d], **self.nms_args)
+        out = (det, count)
+        if self.gather:
+            with torch.cuda.stream(ns):
+                out = D.gather_detections(det, count, out=self.deep_gathered[d], force_collective=True)
+        self.nms_done_deep[d].record(ns)
+        self.n += 1
+        self.last = out
+        return out
+
     def synchronize(self):
-        self.fwd_stream.synchronize()
+        for fs in self.fwd_streams:
+            fs.synchronize()
         self.nms_stream.synchronize()
 
     def __call__(self, rgb, ir):
