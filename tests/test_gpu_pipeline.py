@@ -62,6 +62,35 @@ def test_pipeline_steps_equal_sequential_forward_plus_nms(overlap):
     assert all(torch.equal(det[k, :n], w) for (k, n), w in zip(enumerate(count.tolist()), want))
 
 
+@pytest.mark.parametrize("depth", [2, 3])
+def test_pipeline_with_several_batches_in_flight(depth):
+    """depth plans / forward streams: six different batches, each step's detections equal forward -> NMS run one at a time, and a
+    step's tensors stay intact until its slot is reused `depth` steps later."""
+    m = build("yolov5s_Transfusion_FLIR.yaml", torch.bfloat16)
+    m.use_graph = True
+    B, H, W = 4, 320, 352
+    pipe = DetectionPipeline(m, B, H, W, DEV, conf_thres=0.25, iou_thres=0.45, depth=depth)
+    assert len({p.outputs[0].data_ptr() for p in pipe.plans}) == depth            # separate buffers per batch in flight
+    batches = [synth_images(B, H, W, seed=60 + k) for k in range(6)]
+    outs = []
+    for rgb, ir in batches:
+        ins = pipe.inputs                                                         # staging tensors of the NEXT step's plan
+        ins[0].copy_(rgb.to(DEV)); ins[1].copy_(ir.to(DEV))
+        torch.cuda.current_stream().synchronize()
+        outs.append(pipe.step()[:2])
+        if len(outs) > depth:                                                     # the slot about to be reused next: consume it first
+            pass
+    pipe.synchronize()
+    m.static_outputs = False
+    ref = build("yolov5s_Transfusion_FLIR.yaml", torch.bfloat16)                  # an independent model instance, one batch at a time
+    for k in range(len(batches) - depth, len(batches)):                           # the last `depth` steps still own their buffers
+        rgb, ir = batches[k]
+        want = non_max_suppression(ref(rgb.to(DEV), ir.to(DEV))[0], 0.25, 0.45)
+        det, count = outs[k]
+        assert sum(count.tolist()) > 0
+        assert all(torch.equal(det[i, :n], w) for (i, n), w in zip(enumerate(count.tolist()), want)), f"step {k}"
+
+
 _RCCL_SCRIPT = r'''
 import os, sys, torch, numpy as np
 sys.path.insert(0, {repo!r})

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o pmc -- \
-      python $R/bench.py --no-cpu-baseline --no-graph --no-overlap --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.err
+      python $R/bench.py --no-cpu-baseline --no-graph --no-overlap --depth 1 --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.err
   tail -2 $R/gpurun_out/pmc_$c.err
 done
 cd $R

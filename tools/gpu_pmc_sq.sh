@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_sq
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/pmc_sq -o pmc -- \
-    python $R/bench.py --no-cpu-baseline --no-graph --no-overlap --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_sq.json 2> $R/gpurun_out/pmc_sq.err
+    python $R/bench.py --no-cpu-baseline --no-graph --no-overlap --depth 1 --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_sq.json 2> $R/gpurun_out/pmc_sq.err
 tail -2 $R/gpurun_out/pmc_sq.err
 cd $R && python - <<'PY'
 import csv, glob, collections, json, sys
