@@ -7,7 +7,11 @@ image (32 of 256 CUs at batch 32), so here batch i's NMS runs concurrently with 
     forward stream : graph(i) -> snapshot z(i) -> graph(i+1) -> snapshot z(i+1) -> ...
     nms stream     :              wait snapshot(i) -> candidates / sort / greedy (i) [-> all_gather(i)] -> ...
 
-`z` is snapshotted into one of two staging buffers because the plan's output buffer is overwritten by the next
+With `depth` > 1 (bench default 2) that many batches are in flight: batch n replays plan n % depth (own buffers, own hipGraph) on
+forward stream n % depth, so the low-occupancy tail of one forward overlaps the full-width layers of the next (+13 % throughput on one
+MI355X); NMS then reads each plan's own `z` and the plan is not replayed before its NMS has finished.
+
+With depth 1, `z` is snapshotted into one of two staging buffers because the plan's output buffer is overwritten by the next
 replay; events order snapshot -> NMS -> reuse.  Each of the two slots also owns its NMS runner (workspace + det / count /
 keep output buffers) and its gathered block, so the tensors step n returned stay untouched until step n + 2 reuses the
 slot — and two pipelines of the same shape never share buffers.  Results of step i are valid after `synchronize()`.
@@ -115,8 +119,9 @@ class DetectionPipeline:
 
     def __call__(self, rgb, ir):
         """Convenience: copy one batch in, run it, wait, return list of (n, 6) detections per image."""
-        self.plan.inputs[0].copy_(rgb)
-        self.plan.inputs[1].copy_(ir)
+        ins = self.inputs                       # the staging tensors of the plan the next step replays
+        ins[0].copy_(rgb)
+        ins[1].copy_(ir)
         torch.cuda.current_stream(self.device).synchronize()
         det, count = self.step()[:2]
         self.synchronize()
