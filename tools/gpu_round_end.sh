@@ -1,8 +1,7 @@
 #!/bin/bash
-# Everything the round's committed numbers come from, in one GPU call: bench (with CPU baseline), rocprofv3 kernel stats
-# of the same command, the two PMC passes (HBM traffic per kernel) and the per-layer profile.  Outputs under gpurun_out/;
-# copy the summaries to profiles/ afterwards.
+# Everything the round's committed numbers come from: tools/gpu_round2_evidence.sh (all GPU tests; PMC traffic + MFMA busy passes, bench line,
+# rocprofv3 kernel stats, per-layer profiles, 16-bit parity table for the default workload; PMC + bench + kernel stats for the per-GPU shards of
+# BASELINE configs 3 / 4 / 5), then tools/gpu_bench_lines.sh for the four bench lines in one go.  Outputs under gpurun_out/; copy to profiles/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-bash $R/tools/gpu_bench.sh "$@" 2>&1 | tail -30
-cd $R && bash $R/tools/gpu_pmc.sh "$@" 2>&1 | tail -5
-cd $R && timeout 300 python tools/layer_profile.py --autotune > gpurun_out/layer_profile.txt 2>/dev/null; head -3 gpurun_out/layer_profile.txt
+bash $R/tools/gpu_round2_evidence.sh "$@"
+bash $R/tools/gpu_bench_lines.sh
