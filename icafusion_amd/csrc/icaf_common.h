@@ -162,6 +162,33 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf
 
 inline hipStream_t S(icaf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- division by a launch-constant divisor ----------------------------------------------------------------------
+// The element-per-thread kernels decompose a flat index into (b, y, x, c); with runtime divisors that is a chain of
+// 64-bit divisions (~1000 instructions in detect_decode's ISA for 8 bytes of traffic).  FastDiv holds the round-up
+// multiplier of Granlund & Montgomery for one divisor: q = (mulhi(n, m) + n) >> s, exact for every n < 2^31 (mulhi <= n,
+// so the sum stays below 2^32).  Launchers use it when the flat index space fits 31 bits and fall back to the 64-bit
+// kernel otherwise.
+struct FastDiv {
+    unsigned int d, m, s;
+};
+static inline FastDiv make_fastdiv(unsigned int d) {
+    unsigned int l = 0;
+    while ((1ull << l) < d) ++l;                                   // l = ceil(log2 d)
+    const unsigned long long m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+    return FastDiv{d, (unsigned int)m, l};
+}
+__host__ __device__ __forceinline__ unsigned int fd_div(unsigned int n, FastDiv f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (__umulhi(n, f.m) + n) >> f.s;
+#else
+    return ((unsigned int)(((unsigned long long)n * f.m) >> 32) + n) >> f.s;      // host twin (tests/test_host_logic.py)
+#endif
+}
+__host__ __device__ __forceinline__ void fd_divmod(unsigned int n, FastDiv f, unsigned int& q, unsigned int& r) {
+    q = fd_div(n, f);
+    r = n - q * f.d;
+}
+
 constexpr int ICAF_MAX_DEVICES = 64;      // per-device one-time kernel attribute flags (hipFuncSetAttribute is per device)
 
 }  // namespace icaf

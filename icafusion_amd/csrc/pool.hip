@@ -1,6 +1,7 @@
 // Bandwidth-bound layout / pooling kernels (HBM roofline): input staging, SPPF max pools, nearest upsample, channel
 // copy.  All use 16-byte vectors along the contiguous NHWC channel axis; one thread = one (pixel, channel-vector).
 #include "icaf_common.h"
+#include <cstdlib>
 
 namespace icaf {
 
@@ -210,17 +211,29 @@ __global__ __launch_bounds__(256) void sppf_lds_kernel(const typename Elem<DT>::
 }
 
 // ---- nearest-neighbour integer upsample (writes a channel slice of the consumer's concat buffer) ---------------
+struct UpsampleDiv { FastDiv nv, wo, ho, scale; };
+
+template <bool I32>          // I32: flat vector index below 2^31 -> FastDiv (icaf_common.h) instead of 64-bit divisions
 __global__ __launch_bounds__(256) void upsample_kernel(const u32x4* __restrict__ x, int ldxv, u32x4* __restrict__ y, int ldyv,
-                                                       int B, int H, int W, int nv, int scale) {
+                                                       int B, int H, int W, int nv, int scale, UpsampleDiv dv) {
     const int Ho = H * scale, Wo = W * scale;
     const long long total = (long long)B * Ho * Wo * nv;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int v = (int)(idx % nv);
-        const long long pix = idx / nv;
-        const int wo = (int)(pix % Wo);
-        const long long t = pix / Wo;
-        const int ho = (int)(t % Ho), b = (int)(t / Ho);
-        y[pix * ldyv + v] = x[(((long long)b * H + ho / scale) * W + wo / scale) * ldxv + v];
+        if constexpr (I32) {
+            unsigned int pix, v, t, wo, b, ho;
+            fd_divmod((unsigned int)idx, dv.nv, pix, v);
+            fd_divmod(pix, dv.wo, t, wo);
+            fd_divmod(t, dv.ho, b, ho);
+            const unsigned int hi = fd_div(ho, dv.scale), wi = fd_div(wo, dv.scale);
+            y[(long long)pix * ldyv + v] = x[(((long long)b * H + hi) * W + wi) * ldxv + v];
+        } else {
+            const int v = (int)(idx % nv);
+            const long long pix = idx / nv;
+            const int wo = (int)(pix % Wo);
+            const long long t = pix / Wo;
+            const int ho = (int)(t % Ho), b = (int)(t / Ho);
+            y[pix * ldyv + v] = x[(((long long)b * H + ho / scale) * W + wo / scale) * ldxv + v];
+        }
     }
 }
 
@@ -308,9 +321,10 @@ extern "C" int icaf_sppf_pool(const void* x, int ldx, void* y1, void* y2, void* 
     const int vec = vec_of(dtype);
     if (C % vec || ldx % vec || ldy % vec || !(k & 1)) return fail(ICAF_ERR_ARG, "icaf_sppf_pool: C/ld must be multiples of %d and k odd", vec);
     const int nv = C / vec;
-    int vpb = 0;
+    int vpb = 0, cap = 8;
+    if (const char* e = getenv("ICAF_SPPF_VPB")) cap = atoi(e) > 0 ? atoi(e) : cap;       // probe knob (tools/probes/sppf_vpb.py)
     for (int c : {8, 4, 2, 1})
-        if (nv % c == 0 && (size_t)H * W * c * 32 <= 60 * 1024) { vpb = c; break; }
+        if (c <= cap && nv % c == 0 && (size_t)H * W * c * 32 <= 60 * 1024) { vpb = c; break; }
     if (vpb) {
         const size_t lds = (size_t)H * W * vpb * 32;
         dim3 grid((unsigned)(B * (nv / vpb))), block(256);
@@ -336,8 +350,15 @@ extern "C" int icaf_upsample_nearest(const void* x, int ldx, void* y, int ldy, i
     const int vec = vec_of(dtype);
     if (C % vec || ldx % vec || ldy % vec || scale < 1) return fail(ICAF_ERR_ARG, "icaf_upsample_nearest: bad geometry");
     const long long total = (long long)B * H * scale * W * scale * (C / vec);
-    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, S(s), (const u32x4*)x, ldx / vec, (u32x4*)y, ldy / vec, B, H, W,
-                       C / vec, scale);
+    if (total < 1) return fail(ICAF_ERR_ARG, "icaf_upsample_nearest: empty tensor");
+    const UpsampleDiv dv{make_fastdiv((unsigned)(C / vec)), make_fastdiv((unsigned)(W * scale)), make_fastdiv((unsigned)(H * scale)),
+                         make_fastdiv((unsigned)scale)};
+    if (total < (1ll << 31))
+        hipLaunchKernelGGL(upsample_kernel<true>, dim3(grid_for(total)), dim3(256), 0, S(s), (const u32x4*)x, ldx / vec, (u32x4*)y,
+                           ldy / vec, B, H, W, C / vec, scale, dv);
+    else
+        hipLaunchKernelGGL(upsample_kernel<false>, dim3(grid_for(total)), dim3(256), 0, S(s), (const u32x4*)x, ldx / vec, (u32x4*)y,
+                           ldy / vec, B, H, W, C / vec, scale, dv);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }

@@ -191,3 +191,17 @@ def test_no_counted_vmcnt_kernel_uses_scratch():
     assert len(guarded) > 100 and len(rep) > len(guarded)
     assert all(v.get("scratch", 0) == 0 and v.get("vgpr_spill", 0) == 0 for v in guarded.values())
     assert all(v["vgpr"] + v.get("agpr", 0) <= 512 for v in rep.values())
+
+
+def test_fastdiv_matches_integer_division(tmp_path):
+    """icaf::FastDiv (multiply-high division used by the element-per-thread kernels' index math) against `/` on the host:
+    tests/native/fastdiv_check.cpp includes the kernels' own header and sweeps divisors x the 31-bit range."""
+    import subprocess
+
+    from icafusion_amd.build import hipcc
+    exe = tmp_path / "fastdiv_check"
+    r = subprocess.run([hipcc(), "-O2", "-x", "hip", "--cuda-host-only", "-I", os.path.join(REPO, "icafusion_amd", "csrc"),
+                        os.path.join(REPO, "tests", "native", "fastdiv_check.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fastdiv ok" in r.stdout, r.stdout + r.stderr
