@@ -2,6 +2,7 @@
 // Built with fp contraction off so every expression rounds exactly like the reference's separate torch ops.
 #pragma clang fp contract(off)
 #include "icaf_common.h"
+#include <cstdlib>
 
 namespace icaf {
 
@@ -65,6 +66,76 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restr
     }
 }
 
+// One thread per PIXEL (b, y, x) for the common heads (3 anchors; no = 6 / 8 / 14): the NA * NO conv outputs of the pixel are one contiguous
+// run (16-byte loads), the index is taken apart once per pixel instead of once per element, and each anchor's z / raw row leaves as
+// 8-byte stores.  Same expressions, same rounding as the element kernel above (which remains the general path).
+template <int NA, int NO>
+__global__ __launch_bounds__(256) void detect_pixel_kernel(const float* __restrict__ p, int ldp, float* __restrict__ z,
+                                                           float* __restrict__ logits, float* __restrict__ raw, int B, int ny, int nx,
+                                                           long long rows_total, long long row_offset, float stride, Anchors anc,
+                                                           FastDiv dnx, FastDiv dny) {
+    constexpr int NV = NA * NO;                            // floats per pixel (18 / 24 / 42), NV % 2 == 0
+    const unsigned int total = (unsigned int)B * ny * nx;
+    for (unsigned int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += gridDim.x * blockDim.x) {
+        unsigned int t, x, b, y;
+        fd_divmod(pix, dnx, t, x);
+        fd_divmod(t, dny, b, y);
+        const float* src = p + (long long)pix * ldp;
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i + 4 <= NV; i += 4) {
+            const f32x4 q = *(const f32x4*)(src + i);
+            v[i] = q[0]; v[i + 1] = q[1]; v[i + 2] = q[2]; v[i + 3] = q[3];
+        }
+        if constexpr (NV % 4) {
+            const float2 q = *(const float2*)(src + NV - 2);
+            v[NV - 2] = q.x; v[NV - 1] = q.y;
+        }
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const long long cell = ((long long)a * ny + y) * nx + x;
+            const long long row = (long long)b * rows_total + row_offset + cell;
+            float o[NO];
+#pragma unroll
+            for (int k = 0; k < NO; ++k) {
+                const float sg = 1.0f / (1.0f + expf(-v[a * NO + k]));
+                float out = sg;
+                if (k == 0) out = ((sg * 2.0f - 0.5f) + (float)x) * stride;
+                else if (k == 1) out = ((sg * 2.0f - 0.5f) + (float)y) * stride;
+                else if (k == 2 || k == 3) {
+                    const float d = sg * 2.0f;
+                    out = (d * d) * anc.v[2 * a + (k - 2)];
+                }
+                o[k] = out;
+            }
+            float* zr = z + row * NO;
+#pragma unroll
+            for (int k = 0; k < NO; k += 2) *(float2*)(zr + k) = float2{o[k], o[k + 1]};
+            if (raw) {
+                float* rr = raw + (((long long)b * NA) * ny * nx + cell) * NO;
+#pragma unroll
+                for (int k = 0; k < NO; k += 2) *(float2*)(rr + k) = float2{v[a * NO + k], v[a * NO + k + 1]};
+            }
+            if (logits) {
+#pragma unroll
+                for (int k = 5; k < NO; ++k) logits[row * (NO - 5) + (k - 5)] = v[a * NO + k];
+            }
+        }
+    }
+}
+
+template <int NA, int NO>
+static int launch_detect_pixel(const float* p, int ldp, float* z, float* logits, float* raw, int B, int ny, int nx, long long rows_total,
+                               long long row_offset, float stride, const Anchors& anc, hipStream_t s) {
+    const long long pixels = (long long)B * ny * nx;
+    long long blocks = (pixels + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL((detect_pixel_kernel<NA, NO>), dim3((unsigned)blocks), dim3(256), 0, s, p, ldp, z, logits, raw, B, ny, nx, rows_total,
+                       row_offset, stride, anc, make_fastdiv((unsigned)nx), make_fastdiv((unsigned)ny));
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
 }  // namespace icaf
 
 using namespace icaf;
@@ -80,6 +151,13 @@ extern "C" int icaf_detect_decode(const float* p, int ldp, float* z, float* logi
     long long blocks = (cells + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (B < 1 || ny < 1 || nx < 1) return fail(ICAF_ERR_ARG, "icaf_detect_decode: empty level");
+    // per-pixel kernel: 3 anchors, even `no` in use, 16-byte aligned pixel runs, row offsets that keep the 8-byte stores aligned
+    const bool aligned = ldp % 4 == 0 && ((uintptr_t)p & 15) == 0 && ((uintptr_t)z & 7) == 0 && (!raw || ((uintptr_t)raw & 7) == 0);
+    if (na == 3 && aligned && (long long)B * ny * nx < (1ll << 31) && !getenv("ICAF_DETECT_ELEMENTWISE")) {
+        if (no == 6) return launch_detect_pixel<3, 6>(p, ldp, z, logits, raw, B, ny, nx, rows_total, row_offset, stride, anc, S(s));
+        if (no == 8) return launch_detect_pixel<3, 8>(p, ldp, z, logits, raw, B, ny, nx, rows_total, row_offset, stride, anc, S(s));
+        if (no == 14) return launch_detect_pixel<3, 14>(p, ldp, z, logits, raw, B, ny, nx, rows_total, row_offset, stride, anc, S(s));
+    }
     const DetectDiv dv{make_fastdiv((unsigned)no), make_fastdiv((unsigned)nx), make_fastdiv((unsigned)ny), make_fastdiv((unsigned)na)};
     if (cells < (1ll << 31))
         hipLaunchKernelGGL(detect_decode_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, S(s), p, ldp, z, logits, raw, B, ny, nx, na,

@@ -83,13 +83,16 @@ __global__ __launch_bounds__(256) void pool_tokens_kernel(const typename Elem<DT
 //      the vectors of a pixel, into fp32 column sums / maxima in LDS  (each pixel is read kh/sh times, not kh*kw/(sh*sw));
 //   2. reduces kw columns per token horizontally from LDS, applies the LearnableWeights mix and the positional embedding.
 // Consecutive token rows (which share kh - sh input rows) run on ONE XCD, so the re-reads hit its L2.
-template <int DT>
-__global__ __launch_bounds__(256) void pool_tokens_rows_kernel(const typename Elem<DT>::type* __restrict__ f0, int ld0,
-                                                               const typename Elem<DT>::type* __restrict__ f1, int ld1,
-                                                               const float* __restrict__ pos0, const float* __restrict__ pos1,
-                                                               typename Elem<DT>::type* __restrict__ tok, int B, int H, int W, int C,
-                                                               int th, int tw, int kh, int kw, int sh, int sw, float w1_0, float w2_0,
-                                                               float w1_1, float w2_1) {
+// 1024 threads and all R (>= kh for the windows in use) row loads of an item in flight: with 256 threads and four rows at a time a
+// workgroup was a chain of 15 dependent L2 round trips (5 items x 3 batches) and the P4 level took 42 us for 52 MB.  The loads are
+// unconditional (row index clamped; the duplicates hit L1) — a load under `if (d < kh)` makes the compiler wait for each one.
+template <int DT, int R>
+__global__ __launch_bounds__(1024) void pool_tokens_rows_kernel(const typename Elem<DT>::type* __restrict__ f0, int ld0,
+                                                                const typename Elem<DT>::type* __restrict__ f1, int ld1,
+                                                                const float* __restrict__ pos0, const float* __restrict__ pos1,
+                                                                typename Elem<DT>::type* __restrict__ tok, int B, int H, int W, int C,
+                                                                int th, int tw, int kh, int kw, int sh, int sw, float w1_0, float w2_0,
+                                                                float w1_1, float w2_1) {
     using E = Elem<DT>;
     constexpr int V = E::VEC;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -103,25 +106,31 @@ __global__ __launch_bounds__(256) void pool_tokens_rows_kernel(const typename El
     const typename E::type* f = g ? f1 : f0;
     const int ld = g ? ld1 : ld0;
     const typename E::type* frow = f + ((long long)b * H + oy * sh) * W * ld;
-    for (int item = threadIdx.x; item < nitem; item += 256) {
+    const long long rstride = (long long)W * ld;
+    for (int item = threadIdx.x; item < nitem; item += blockDim.x) {
         const int x = item / nv, v = item - x * nv;
         const typename E::type* p0 = frow + (long long)x * ld + v * V;
         float sum[V], mx[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) { sum[j] = 0.0f; mx[j] = -INFINITY; }
-        for (int d0 = 0; d0 < kh; d0 += 4) {           // four rows in flight
-            u32x4 raw[4];
+        for (int d0 = 0; d0 < kh; d0 += R) {
+            u32x4 raw[R];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (d0 + u < kh) raw[u] = *(const u32x4*)(p0 + (long long)(d0 + u) * W * ld);
+            for (int u = 0; u < R; ++u) {
+                const int d = d0 + u < kh ? d0 + u : kh - 1;
+                raw[u] = *(const u32x4*)(p0 + d * rstride);
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (d0 + u < kh) {
-                    float t[V];
-                    unpack16<DT>(raw[u], t);
+            for (int u = 0; u < R; ++u) {
+                const bool on = d0 + u < kh;
+                float t[V];
+                unpack16<DT>(raw[u], t);
 #pragma unroll
-                    for (int j = 0; j < V; ++j) { sum[j] += t[j]; mx[j] = fmaxf(mx[j], t[j]); }
+                for (int j = 0; j < V; ++j) {
+                    sum[j] = on ? sum[j] + t[j] : sum[j];
+                    mx[j] = on ? fmaxf(mx[j], t[j]) : mx[j];
                 }
+            }
         }
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(256) void pool_tokens_rows_kernel(const typename El
     const float inv_area = 1.0f / (float)(kh * kw);
     const float w1 = g ? w1_1 : w1_0, w2 = g ? w2_1 : w2_0;
     const int N = th * tw;
-    for (int o = threadIdx.x; o < tw * nv; o += 256) {
+    for (int o = threadIdx.x; o < tw * nv; o += blockDim.x) {
         const int ox = o / nv, v = o - ox * nv;
         float sum[V], mx[V];
 #pragma unroll
@@ -504,15 +513,24 @@ int run_pool_tokens(const void* f0, int ld0, const void* f1, int ld1, const floa
     using T = typename Elem<DT>::type;
     const size_t rows_lds = (size_t)W * C * 2 * sizeof(float);        // fp32 column sums + maxima of one token row
     if ((kh > sh || kw > sw) && rows_lds <= 160 * 1024) {             // overlapping windows: separable, one token row per workgroup
-        static size_t attr_bytes[ICAF_MAX_DEVICES] = {};      // per device
+        static size_t attr_bytes[ICAF_MAX_DEVICES][3] = {};      // per device and instantiation
         int dev = 0;
         ICAF_HIP(hipGetDevice(&dev));
-        if (rows_lds > 64 * 1024 && dev >= 0 && dev < ICAF_MAX_DEVICES && rows_lds > attr_bytes[dev]) {
-            ICAF_HIP(hipFuncSetAttribute((const void*)pool_tokens_rows_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
-            attr_bytes[dev] = rows_lds;
+        const int rsel = kh <= 4 ? 0 : kh <= 8 ? 1 : 2;          // rows in flight per item: 4 / 8 / 12
+        const void* fn = rsel == 0 ? (const void*)pool_tokens_rows_kernel<DT, 4> : rsel == 1 ? (const void*)pool_tokens_rows_kernel<DT, 8>
+                                                                                             : (const void*)pool_tokens_rows_kernel<DT, 12>;
+        if (rows_lds > 64 * 1024 && dev >= 0 && dev < ICAF_MAX_DEVICES && rows_lds > attr_bytes[dev][rsel]) {
+            ICAF_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
+            attr_bytes[dev][rsel] = rows_lds;
         }
-        pool_tokens_rows_kernel<DT><<<dim3((unsigned)(2 * B * th)), dim3(256), rows_lds, s>>>((const T*)f0, ld0, (const T*)f1, ld1, p0, p1, (T*)tok,
-                                                                                             B, H, W, C, th, tw, kh, kw, sh, sw, a0, b0, a1, b1);
+        const dim3 grid((unsigned)(2 * B * th)), block(1024);
+#define ICAF_POOL_ROWS(RR)                                                                                                                  \
+    pool_tokens_rows_kernel<DT, RR><<<grid, block, rows_lds, s>>>((const T*)f0, ld0, (const T*)f1, ld1, p0, p1, (T*)tok, B, H, W, C, th, tw, kh, \
+                                                                  kw, sh, sw, a0, b0, a1, b1)
+        if (rsel == 0) ICAF_POOL_ROWS(4);
+        else if (rsel == 1) ICAF_POOL_ROWS(8);
+        else ICAF_POOL_ROWS(12);
+#undef ICAF_POOL_ROWS
         ICAF_LAUNCH_CHECK();
         return ICAF_OK;
     }

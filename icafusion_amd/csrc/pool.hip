@@ -321,8 +321,10 @@ extern "C" int icaf_sppf_pool(const void* x, int ldx, void* y1, void* y2, void* 
     const int vec = vec_of(dtype);
     if (C % vec || ldx % vec || ldy % vec || !(k & 1)) return fail(ICAF_ERR_ARG, "icaf_sppf_pool: C/ld must be multiples of %d and k odd", vec);
     const int nv = C / vec;
-    int vpb = 0, cap = 8;
-    if (const char* e = getenv("ICAF_SPPF_VPB")) cap = atoi(e) > 0 ? atoi(e) : cap;       // probe knob (tools/probes/sppf_vpb.py)
+    // channel vectors per workgroup: 2 measured best (tools/probes/sppf_vpb.py, MI355X, 64 x 20x20 x 256 bf16: 8 / 4 -> 32.7 us, 2 -> 29.3 us,
+    // 1 -> 46.9 us; x 512: 57 / 53 / 87 us) — twice the workgroups of 4 for latency hiding, still 32-byte runs per pixel
+    int vpb = 0, cap = 2;
+    if (const char* e = getenv("ICAF_SPPF_VPB")) cap = atoi(e) > 0 ? atoi(e) : cap;       // probe knob
     for (int c : {8, 4, 2, 1})
         if (c <= cap && nv % c == 0 && (size_t)H * W * c * 32 <= 60 * 1024) { vpb = c; break; }
     if (vpb) {

@@ -572,7 +572,9 @@ def test_sppf_upsample_copy(dt):
 
 POOL_CASES = [(2, 128, 40, 40, 20, 20), (1, 64, 40, 40, 16, 16), (1, 64, 64, 80, 20, 20), (2, 32, 10, 10, 10, 10),
               (1, 64, 68, 84, 20, 20),
-              (1, 32, 30, 33, 7, 9)]      # overlapping windows, token grid not a multiple of the 2x4 block per thread
+              (1, 32, 30, 33, 7, 9),      # overlapping windows, token grid not a multiple of the 2x4 block per thread
+              (1, 64, 32, 40, 16, 16),    # k (2, 10) s (2, 2): the separable kernel with 4 rows in flight (config 4's P4 level)
+              (1, 32, 31, 20, 16, 16)]    # k (16, 5) s (1, 1): window taller than the 12 rows in flight -> two chunks
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -666,8 +668,12 @@ def test_cross_attention_softmax_spike():
     close(out[0].cpu(), ref, torch.float32, "spiked softmax")
 
 
-@pytest.mark.parametrize("nc", [1, 9])
-def test_detect_decode(nc):
+@pytest.mark.parametrize("path", ["pixel", "element"])
+@pytest.mark.parametrize("nc", [1, 3, 9])
+def test_detect_decode(nc, path, monkeypatch):
+    """Both kernels behind icaf_detect_decode: one thread per pixel (3 anchors, no = 6 / 8 / 14) and the general one thread per element."""
+    if path == "element":
+        monkeypatch.setenv("ICAF_DETECT_ELEMENTWISE", "1")
     B, na, no = 2, 3, nc + 5
     anchors = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
     dims = [(12, 20), (6, 10), (3, 5)]
@@ -678,7 +684,7 @@ def test_detect_decode(nc):
     for l, (h, w) in enumerate(dims):
         p = rnd((B, na * no, h, w), 50 + l, 2.0)
         feats.append(p)
-        pa = torch.zeros((B, h, w, na * no + 2), dtype=torch.float32, device=DEV)
+        pa = torch.zeros((B, h, w, (na * no + 7) // 4 * 4), dtype=torch.float32, device=DEV)     # padded pixel stride, 16-byte multiple
         pa[..., :na * no] = p.permute(0, 2, 3, 1).to(DEV)
         raw = torch.zeros((B, na, h, w, no), dtype=torch.float32, device=DEV)
         run(ops.detect_decode(pa[..., :na * no], z, lg, raw, na, no, off, oracle.STRIDES[l], anchors[l]))

@@ -4,13 +4,12 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
 t0=$(date +%s)
-timeout 240 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py -q -m gpu -k "detect_decode or sppf_upsample or nearest_pre_term or pipeline_steps or batches_in_flight" --timeout=200 --tb=short -p no:cacheprovider > gpurun_out/ab_tests.log 2>&1
+timeout 240 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py -q -m gpu -k "detect_decode or sppf_upsample or dmff_pool_tokens or nearest_pre_term or pipeline_steps or batches_in_flight" --timeout=200 --tb=short -p no:cacheprovider > gpurun_out/ab_tests.log 2>&1
 echo "== tests: $(tail -1 gpurun_out/ab_tests.log) [$(( $(date +%s) - t0 )) s]"; grep -E "^(FAILED|ERROR)" gpurun_out/ab_tests.log | head
-timeout 200 python -m pytest tests/test_gpu_model.py -q -m gpu -x -k "golden or folded_upsample or graph_replay or other_shape or low_precision" --timeout=180 --tb=short -p no:cacheprovider > gpurun_out/ab_model.log 2>&1
+timeout 200 python -m pytest tests/test_gpu_model.py -q -m gpu -x -k "golden or graph_replay or other_shape or low_precision or map50" --timeout=180 --tb=short -p no:cacheprovider > gpurun_out/ab_model.log 2>&1
 echo "== model: $(tail -1 gpurun_out/ab_model.log) [$(( $(date +%s) - t0 )) s]"; grep -E "^(FAILED|ERROR)" gpurun_out/ab_model.log | head
-timeout 120 python tools/probes/sppf_vpb.py > gpurun_out/ab_sppf.txt 2>&1; cat gpurun_out/ab_sppf.txt | tail -14
 timeout 120 python tools/layer_profile.py --autotune > gpurun_out/ab_layers.txt 2>&1
-grep -E "total|detect_decode|upsample_nearest|sppf_pool" gpurun_out/ab_layers.txt
+grep -E "total|detect_decode|upsample_nearest|sppf_pool|dmff_pool_tokens" gpurun_out/ab_layers.txt
 echo "[$(( $(date +%s) - t0 )) s]"
 show() { python - "$1" <<'PY'
 import json, sys
@@ -22,7 +21,5 @@ except Exception as e:
 PY
 }
 timeout 150 python bench.py --no-cpu-baseline --repeats 5 > gpurun_out/ab_default.json 2> gpurun_out/ab_default.err; show gpurun_out/ab_default.json
-timeout 150 python bench.py --no-cpu-baseline --repeats 5 --fold-upsample > gpurun_out/ab_fold.json 2> gpurun_out/ab_fold.err; show gpurun_out/ab_fold.json
-ICAF_DMFF_FUSE_MAX_C=256 timeout 150 python bench.py --no-cpu-baseline --repeats 5 > gpurun_out/ab_fuse256.json 2> gpurun_out/ab_fuse256.err; show gpurun_out/ab_fuse256.json
 timeout 150 python bench.py --no-cpu-baseline --repeats 5 > gpurun_out/ab_default2.json 2> gpurun_out/ab_default2.err; show gpurun_out/ab_default2.json
 echo "[$(( $(date +%s) - t0 )) s]"
