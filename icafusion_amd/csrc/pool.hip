@@ -321,9 +321,9 @@ extern "C" int icaf_sppf_pool(const void* x, int ldx, void* y1, void* y2, void* 
     const int vec = vec_of(dtype);
     if (C % vec || ldx % vec || ldy % vec || !(k & 1)) return fail(ICAF_ERR_ARG, "icaf_sppf_pool: C/ld must be multiples of %d and k odd", vec);
     const int nv = C / vec;
-    // channel vectors per workgroup: 2 measured best (tools/probes/sppf_vpb.py, MI355X, 64 x 20x20 x 256 bf16: 8 / 4 -> 32.7 us, 2 -> 29.3 us,
-    // 1 -> 46.9 us; x 512: 57 / 53 / 87 us) — twice the workgroups of 4 for latency hiding, still 32-byte runs per pixel
-    int vpb = 0, cap = 2;
+    // channel vectors per workgroup: the largest group whose plane fits.  A cap of 2 (twice the workgroups) is faster in isolation
+    // (tools/probes/sppf_vpb.py, 64 x 20x20 x 256 bf16: 32.7 -> 29.3 us) and slower in the forward (35 -> 40 us, input not cache-resident)
+    int vpb = 0, cap = 8;
     if (const char* e = getenv("ICAF_SPPF_VPB")) cap = atoi(e) > 0 ? atoi(e) : cap;       // probe knob
     for (int c : {8, 4, 2, 1})
         if (c <= cap && nv % c == 0 && (size_t)H * W * c * 32 <= 60 * 1024) { vpb = c; break; }

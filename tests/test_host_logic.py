@@ -145,7 +145,10 @@ def test_pmc_summary_kernel_names_match_bench_names():
         "void icaf::bneck_kernel<1, 8, 32, 32, 1, false>(icaf::ConvP, int, int, int, int, int)": "bottleneck",
         "void icaf::stem2_kernel<1, false>(icaf::Stem2P)": "stem+conv3x3s2+1x1",
         "void icaf::stem_kernel<1, 32, false>(icaf::StemP)": "stem",
-        "void icaf::pool_tokens_rows_kernel<1>(icaf::Elem<1>::type const*, int)": "dmff_pool_tokens",
+        "void icaf::pool_tokens_rows_kernel<1, 12>(icaf::Elem<1>::type const*, int)": "dmff_pool_tokens",
+        "void icaf::detect_pixel_kernel<3, 6>(float const*, int, float*)": "detect_decode",
+        "void icaf::detect_decode_kernel<true>(float const*, int, float*)": "detect_decode",
+        "void icaf::upsample_kernel<true>(unsigned int __vector(4) const*, int)": "upsample_nearest",
         "void icaf::pool_tokens_kernel<1>(icaf::Elem<1>::type const*, int)": "dmff_pool_tokens",
         "void icaf::sppf_lds_kernel<1>(icaf::Elem<1>::type const*, int)": "sppf_pool",
         "void icaf::dmff_attn_mlp_kernel<1, 16, 1, 128>(icaf::DmffP)": "dmff_attn_mlp",

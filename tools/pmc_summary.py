@@ -37,7 +37,7 @@ def short(name):
     m = re.match(r"icaf::(\w+)(<[^>]*>)?", name)
     if m:
         return {"preprocess_kernel": "preprocess_s2d", "pool_tokens_kernel": "dmff_pool_tokens", "upsample_merge_kernel": "dmff_upsample_merge",
-                "cross_attn_kernel": "cross_attention", "detect_decode_kernel": "detect_decode", "sppf_lds_kernel": "sppf_pool",
+                "cross_attn_kernel": "cross_attention", "detect_decode_kernel": "detect_decode", "detect_pixel_kernel": "detect_decode", "sppf_lds_kernel": "sppf_pool",
                 "upsample_kernel": "upsample_nearest", "stem_kernel": "stem", "bneck_kernel": "bottleneck",
                 "stem2_kernel": "stem+conv3x3s2+1x1", "pool_tokens_rows_kernel": "dmff_pool_tokens",
                 "dmff_attn_mlp_kernel": "dmff_attn_mlp", "dmff_ln_qkv_kernel": "dmff_ln_qkv", "layernorm_kernel": "layernorm"}.get(m.group(1), m.group(1))
