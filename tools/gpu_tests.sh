@@ -13,8 +13,8 @@ timeout 900 python -m pytest tests/test_gpu_model.py tests/test_frontends.py tes
 echo "== model: $(tail -1 gpurun_out/model.log)"
 grep -E "^(FAILED|ERROR)" gpurun_out/model.log | head -20
 grep -E "AssertionError|Error:|error|assert " gpurun_out/model.log | sort | uniq -c | sort -rn | head -20
-timeout 1200 python -m pytest tests/test_attempt_load.py tests/test_gpu_pipeline.py tests/test_gpu_parity16.py -q -m gpu --timeout=600 --tb=short -p no:cacheprovider -s > gpurun_out/round2.log 2>&1
-echo "== attempt_load / pipeline / parity16: $(tail -1 gpurun_out/round2.log)"
+timeout 1200 python -m pytest tests/test_attempt_load.py tests/test_gpu_pipeline.py tests/test_gpu_parity16.py tests/test_gpu_dmff_fused.py -q -m gpu --timeout=600 --tb=short -p no:cacheprovider -s > gpurun_out/round2.log 2>&1
+echo "== attempt_load / pipeline / parity16 / fused DMFF: $(tail -1 gpurun_out/round2.log)"
 grep -E "^(FAILED|ERROR)" gpurun_out/round2.log | head -20
 grep -E "AssertionError|Error:|assert " gpurun_out/round2.log | sort | uniq -c | sort -rn | head -20
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; tail -3 gpurun_out/smoke.log
