@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restr
 }
 
 // One thread per PIXEL (b, y, x) for the common heads (3 anchors; no = 6 / 8 / 14): the NA * NO conv outputs of the pixel are one contiguous
-// run (16-byte loads), the index is taken apart once per pixel instead of once per element, and each anchor's z / raw row leaves as
+// run (8-byte loads), the index is taken apart once per pixel instead of once per element, and each anchor's z / raw row leaves as
 // 8-byte stores.  Same expressions, same rounding as the element kernel above (which remains the general path).
 template <int NA, int NO>
 __global__ __launch_bounds__(256) void detect_pixel_kernel(const float* __restrict__ p, int ldp, float* __restrict__ z,
@@ -83,13 +83,9 @@ __global__ __launch_bounds__(256) void detect_pixel_kernel(const float* __restri
         const float* src = p + (long long)pix * ldp;
         float v[NV];
 #pragma unroll
-        for (int i = 0; i + 4 <= NV; i += 4) {
-            const f32x4 q = *(const f32x4*)(src + i);
-            v[i] = q[0]; v[i + 1] = q[1]; v[i + 2] = q[2]; v[i + 3] = q[3];
-        }
-        if constexpr (NV % 4) {
-            const float2 q = *(const float2*)(src + NV - 2);
-            v[NV - 2] = q.x; v[NV - 1] = q.y;
+        for (int i = 0; i < NV; i += 2) {                 // 8-byte loads: the plan's conv output is dense (ldp = NV: 72 / 96 / 168-byte pixels)
+            const float2 q = *(const float2*)(src + i);
+            v[i] = q.x; v[i + 1] = q.y;
         }
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
@@ -151,8 +147,8 @@ extern "C" int icaf_detect_decode(const float* p, int ldp, float* z, float* logi
     long long blocks = (cells + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (B < 1 || ny < 1 || nx < 1) return fail(ICAF_ERR_ARG, "icaf_detect_decode: empty level");
-    // per-pixel kernel: 3 anchors, even `no` in use, 16-byte aligned pixel runs, row offsets that keep the 8-byte stores aligned
-    const bool aligned = ldp % 4 == 0 && ((uintptr_t)p & 15) == 0 && ((uintptr_t)z & 7) == 0 && (!raw || ((uintptr_t)raw & 7) == 0);
+    // per-pixel kernel: 3 anchors, even `no` in use, 8-byte aligned pixel runs and output rows
+    const bool aligned = ldp % 2 == 0 && ((uintptr_t)p & 7) == 0 && ((uintptr_t)z & 7) == 0 && (!raw || ((uintptr_t)raw & 7) == 0);
     if (na == 3 && aligned && (long long)B * ny * nx < (1ll << 31) && !getenv("ICAF_DETECT_ELEMENTWISE")) {
         if (no == 6) return launch_detect_pixel<3, 6>(p, ldp, z, logits, raw, B, ny, nx, rows_total, row_offset, stride, anc, S(s));
         if (no == 8) return launch_detect_pixel<3, 8>(p, ldp, z, logits, raw, B, ny, nx, rows_total, row_offset, stride, anc, S(s));

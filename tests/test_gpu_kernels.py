@@ -684,7 +684,7 @@ def test_detect_decode(nc, path, monkeypatch):
     for l, (h, w) in enumerate(dims):
         p = rnd((B, na * no, h, w), 50 + l, 2.0)
         feats.append(p)
-        pa = torch.zeros((B, h, w, (na * no + 7) // 4 * 4), dtype=torch.float32, device=DEV)     # padded pixel stride, 16-byte multiple
+        pa = torch.zeros((B, h, w, na * no + (2 if l else 0)), dtype=torch.float32, device=DEV)     # dense (as the plan allocates it) / padded pixel stride
         pa[..., :na * no] = p.permute(0, 2, 3, 1).to(DEV)
         raw = torch.zeros((B, na, h, w, no), dtype=torch.float32, device=DEV)
         run(ops.detect_decode(pa[..., :na * no], z, lg, raw, na, no, off, oracle.STRIDES[l], anchors[l]))
