@@ -905,7 +905,8 @@ class Detect(HipModule):
                 wp, kp = ops.pack_conv_weight(conv.weight.detach().float(), plan.dtype)
                 return wp, kp, ops.pack_bias(conv.bias.detach().float(), conv.out_channels)
             wp, kp, bp = self._cached(("det", l, plan.dtype, plan.device), make)
-            p = plan.act(B, ny, nx, nout, dtype=torch.float32)
+            # pixel stride padded to a 16-byte multiple (18 -> 20 floats): the conv epilogue then leaves 16-byte stores instead of scalar ones
+            p = plan.act(B, ny, nx, (nout + 3) // 4 * 4, dtype=torch.float32)[..., :nout]
             plan.add(ops.conv2d(x, wp, kp, bp, p, 1, 1, 1, 1, 0, 0, c, nout, ops.ACT_NONE, name="detect_conv"))
             raw = plan.empty((B, self.na, ny, nx, self.no), torch.float32)
             plan.add(ops.detect_decode(p, z, logits, raw, self.na, self.no, off, strides[l], ag[l].tolist()))
