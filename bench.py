@@ -257,14 +257,14 @@ def main():
             "config": {"workload": f"{yaml_name[:-5]} + DMFF(loops={args.loops}) {args.dtype}, batch {B}/GPU, "
                                    f"{H}x{W} synthetic RGB/IR pairs, seeded random weights, NMS conf {args.conf} iou {args.iou}",
                        "global_batch": B * world, "parallelism": f"dp{world} (pairs sharded, one all-gather of detections)",
-                       "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap, "batches_in_flight": args.depth},
+                       "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap, "batches_in_flight": pipe.depth},
             "forward_only_pairs_per_s": round(B / (fwd_tp_ms * 1e-3), 2),       # same batches-in-flight as `value`, no NMS
             "forward_ms_per_batch": round(fwd_ms, 3),                            # latency of ONE forward (one plan replayed back to back)
             "forward_only_pairs_per_s_one_in_flight": round(B / (fwd_ms * 1e-3), 2),
             "nms_ms_per_batch_standalone": round(nms_ms, 4),
             "model_tflops": round(gf * B / (fwd_tp_ms * 1e-3) / 1e3, 2) if gf else None,
             "forward_roofline": {      # whole forward: algorithmic FLOPs and leaf-op bytes of all launches over the forward-only time per batch
-                "basis": f"forward-only throughput with {args.depth} batch(es) in flight",
+                "basis": f"forward-only throughput with {pipe.depth} batch(es) in flight",
                 "tflops": round(sum(v[1] for v in per_kernel.values()) / reps / (fwd_tp_ms * 1e-3) / 1e12, 1),
                 "mfma_frac": round(sum(v[1] for v in per_kernel.values()) / reps / (fwd_tp_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
                 "gbs": round(sum(v[2] for v in per_kernel.values()) / reps / (fwd_tp_ms * 1e-3) / 1e9, 1),

@@ -616,6 +616,7 @@ extern "C" int icaf_nms(const float* pred, int B, long long rows, int nc, float 
     if (!pred || !det || !count || !workspace) return fail(ICAF_ERR_ARG, "icaf_nms: null pointer");
     if (max_det < 1 || max_det > MAX_KEEP) return fail(ICAF_ERR_ARG, "icaf_nms: max_det must be in [1, %d]", MAX_KEEP);
     if (max_nms < 1) return fail(ICAF_ERR_ARG, "icaf_nms: max_nms must be positive");
+    if (n_classes < 0 || (n_classes > 0 && !classes_host)) return fail(ICAF_ERR_ARG, "icaf_nms: class filter of %d ids without a list", n_classes);
     if (((uintptr_t)workspace & 255) != 0) return fail(ICAF_ERR_ARG, "icaf_nms: workspace must be 256-byte aligned");
     const int multi = multi_label && nc > 1;
     NmsWs ws;

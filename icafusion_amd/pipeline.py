@@ -34,7 +34,7 @@ class DetectionPipeline:
         model.static_outputs = True
         # depth > 1: that many batches in flight, each with its own plan (buffers, hipGraph) and forward stream — the tails of one
         # forward (20x20 layers, DMFF, Detect: launches that leave CUs idle) overlap the full-width layers of the next
-        self.depth = max(1, int(depth))
+        self.depth = max(1, int(depth)) if overlap else 1         # overlap=False is the strictly sequential baseline: one batch, one stream
         self.plans = [model.plan_for(batch, height, width, self.device, slot=s) for s in range(self.depth)]
         self.plan = self.plans[0]
         self.z = self.plan.outputs[0]
