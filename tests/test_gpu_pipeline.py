@@ -107,7 +107,9 @@ assert dist.get_backend() == "nccl"
 cfg = yaml.safe_load(open(os.path.join({repo!r}, "models", "transformer", "yolov5s_Transfusion_kaist.yaml")))
 m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 0)); m = m.to("cuda:0"); m.compute_dtype = torch.bfloat16; m.use_graph = True
 B, H, W = 4, 320, 320
-pipe = DetectionPipeline(m, B, H, W, "cuda:0", conf_thres=0.1, iou_thres=0.5, world=1, overlap=True, force_gather=True)
+pipe = DetectionPipeline(m, B, H, W, "cuda:0", conf_thres=0.1, iou_thres=0.5, world=1, overlap=True, force_gather=True, depth={depth})
+runners = pipe.deep_runners if pipe.depth > 1 else pipe.runners            # the slot step k used
+gathered = pipe.deep_gathered if pipe.depth > 1 else pipe.gathered
 outs = []
 for k in range(4):
     rgb, ir = synth_images(B, H, W, seed=70 + k)
@@ -115,22 +117,24 @@ for k in range(4):
     outs.append(pipe.step())
     pipe.synchronize()
     det_all, count_all = outs[-1]
-    det, count, _ = pipe.runners[k & 1].det, pipe.runners[k & 1].count, None
+    det, count = runners[k % len(runners)].det, runners[k % len(runners)].count
     assert det_all.shape == (B, 300, 6) and count_all.dtype == torch.int32
     assert torch.equal(det_all, det) and torch.equal(count_all, count), "all-gather of one rank must return that rank's block"
     assert int(count.sum()) > 0
-    assert det_all.data_ptr() == pipe.gathered[k & 1].data_ptr()            # the collective wrote the pipeline's gathered buffer
+    assert det_all.data_ptr() == gathered[k % len(gathered)].data_ptr()     # the collective wrote the pipeline's gathered buffer
 dist.barrier(); dist.destroy_process_group()
 print("RCCL_WORLD1_OK", [int(c.sum()) for _, c in outs])
 '''
 
 
-def test_rccl_all_gather_runs_on_the_nms_stream_with_one_rank():
+@pytest.mark.parametrize("depth", [1, 2])
+def test_rccl_all_gather_runs_on_the_nms_stream_with_one_rank(depth):
     """`nccl` (= RCCL) process group of world size 1: DetectionPipeline(force_gather=True) sends every step's detection block
     through dist.all_gather_into_tensor on the NMS stream — the collective, its stream ordering against the NMS kernels and
-    the gathered buffers run on hardware although no second GPU exists (a subprocess: it owns the process group)."""
+    the gathered buffers run on hardware although no second GPU exists (a subprocess: it owns the process group).  depth = 2 is
+    what `bench.py --gpus N` runs: two batches in flight, each with its own gathered block."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT.format(repo=REPO)], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT.format(repo=REPO, depth=depth)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
