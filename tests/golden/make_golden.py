@@ -252,6 +252,9 @@ def main():
     if "--n-only" in sys.argv:                        # yolov5n + DMFF (16-channel stem, C = 64 / 128 / 256 fusion blocks), added later
         model_case(yt, "model_n_flir_352x320_b2", "yolov5n_Transfusion_FLIR.yaml", 2, 352, 320, seed=14)
         return
+    if "--rect-only" in sys.argv:                     # the shape real KAIST validation batches have under the reference's rect protocol
+        model_case(yt, "model_s_kaist_544x672_b1", "yolov5s_Transfusion_kaist.yaml", 1, 544, 672, seed=15)     # (512x640 frames,
+        return                                                                                                 # pad 0.5 -> 544x672; DMFF windows (11,8) / (4,12) / (8,3))
     if "--fusion-variants-only" in sys.argv:          # the NiNfusion / Add fixtures, added later
         model_case(yt, "model_s_add_kaist_320_b1", "yolov5s_Add_kaist.yaml", 1, 320, 320, seed=11)
         model_case(yt, "model_n_ninfusion_flir_320_b2", "yolov5n_NiNfusion_FLIR.yaml", 2, 320, 320, seed=12)
@@ -276,6 +279,7 @@ def main():
     model_case(yt, "model_m_kaist_320_b1", "yolov5m_Transfusion_kaist.yaml", 1, 320, 320, seed=13)
     model_case(yt, "model_n_flir_352x320_b2", "yolov5n_Transfusion_FLIR.yaml", 2, 352, 320, seed=14)
     match_case(general, "match_predictions")
+    model_case(yt, "model_s_kaist_544x672_b1", "yolov5s_Transfusion_kaist.yaml", 1, 544, 672, seed=15)
 
 
 if __name__ == "__main__":

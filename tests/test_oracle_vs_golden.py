@@ -14,7 +14,8 @@ from oracle import icaf_oracle as oracle
 
 MODEL_CASES = ["model_s_kaist_320_b2", "model_s_kaist_384x320_loops3", "model_l_vedai_320_b1",
                "model_s_kaist_640_b1", "model_s_add_kaist_320_b1", "model_n_ninfusion_flir_320_b2", "model_m_kaist_320_b1",
-               "model_n_flir_352x320_b2"]
+               "model_n_flir_352x320_b2",
+               "model_s_kaist_544x672_b1"]     # the rect validation batch shape of KAIST (DMFF windows (11, 8) / (4, 12) / (8, 3))
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
