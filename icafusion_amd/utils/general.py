@@ -16,6 +16,41 @@ def make_divisible(x, divisor):
     return math.ceil(x / divisor) * divisor
 
 
+def check_img_size(img_size, s=32):
+    """Round --img-size up to a multiple of the model's largest stride (reference utils/general.py:142-147)."""
+    new_size = make_divisible(img_size, int(s))
+    if new_size != img_size:
+        print("WARNING: --img-size %g must be multiple of max stride %g, updating to %g" % (img_size, s, new_size))
+    return new_size
+
+
+def increment_path(path, exist_ok=False, sep="", mkdir=False):
+    """runs/exp -> runs/exp2, runs/exp3, ... when the path exists (reference utils/general.py:705-719): the next free
+    number after the highest `<name><sep><n>` sibling, 2 when there is none; a file keeps its suffix."""
+    import glob
+    import re
+    from pathlib import Path
+    path = Path(path)
+    if path.exists() and not exist_ok:
+        suffix = path.suffix
+        path = path.with_suffix("")
+        taken = [re.search(rf"%s{sep}(\d+)" % re.escape(path.stem), d) for d in glob.glob(f"{path}{sep}*")]
+        nums = [int(m.group(1)) for m in taken if m]
+        path = Path(f"{path}{sep}{max(nums) + 1 if nums else 2}{suffix}")
+    folder = path if path.suffix == "" else path.parent
+    if mkdir and not folder.exists():
+        folder.mkdir(parents=True, exist_ok=True)
+    return path
+
+
+def xyxy2xywh2(x):
+    """[x1, y1, x2, y2] -> [x1, y1, w, h] (top-left corner + size: the KAIST result-file layout, reference :312-319)."""
+    y = x.clone() if isinstance(x, torch.Tensor) else np.copy(x)
+    y[:, 2] = x[:, 2] - x[:, 0]
+    y[:, 3] = x[:, 3] - x[:, 1]
+    return y
+
+
 def xyxy2xywh(x):
     """[x1, y1, x2, y2] -> [cx, cy, w, h] (reference utils/general.py:322-329)."""
     y = x.clone() if isinstance(x, torch.Tensor) else np.copy(x)

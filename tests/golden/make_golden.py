@@ -240,6 +240,56 @@ def match_case(general, name):
     print(name, "TP flags per trial:", [int(rec[f"correct{t}"][:, 0].sum()) for t in range(T)])
 
 
+def results_case(general, name):
+    """Pin the result-file formats (--save-txt / --save-json): the reference writes them INLINE in its validation loop
+    (test.py:162-171 per-image text lines, :184-195 JSON rows, :248-258 result.txt), so those source lines are read from the reference
+    tree at generation time, dedented and exec'ed on the detections of tests/golden/match_predictions.npz (one trial = one image) in a
+    temporary directory, with the reference's own xyxy2xywh / xyxy2xywh2 in scope.  Only the produced file contents are stored."""
+    import json
+    import tempfile
+    import textwrap
+    from pathlib import Path
+    with open(os.path.join(REF, "test.py")) as f:
+        lines = f.read().splitlines()
+
+    def block(first, last_exclusive, want_range):
+        i0 = next(i for i, l in enumerate(lines) if first in l)
+        i1 = next(i for i, l in enumerate(lines) if i > i0 and last_exclusive in l)
+        assert (i0 + 1, i1) == want_range, (first, i0 + 1, i1)
+        return compile(textwrap.dedent("\n".join(lines[i0:i1])).rstrip(), f"reference test.py:{i0 + 1}-{i1}", "exec")
+    txt_code = block("# Append to text file", "# W&B logging - Media Panel Plots", (162, 171))
+    json_code = block("# Append to pycocotools JSON dictionary", "# Assign all predictions as incorrect", (184, 195))
+    i0 = next(i for i, l in enumerate(lines) if "temp = []" in l) - 1
+    assert lines[i0].strip() == "if save_txt:" and i0 + 1 == 248, (i0, lines[i0])
+    merge_code = compile(textwrap.dedent("\n".join(lines[i0:i0 + 11])).rstrip(), "reference test.py:248-258", "exec")
+    assert "ff.write(ii)" in lines[i0 + 10], lines[i0 + 10]
+    g = np.load(os.path.join(HERE, "match_predictions.npz"))
+    T = int(g["n"])
+    stems = [(f"set{t:02d}_V000_I{t * 37:05d}" if t % 2 == 0 else f"{1000 + t * 13}") for t in range(T)]
+    labels_list = sorted([s + ".txt" for s in stems] + ["0000.txt", "zz_extra.txt"])
+    out = {"stems": stems, "labels_list": labels_list, "runs": {}}
+    for save_conf in (True, False):
+        with tempfile.TemporaryDirectory() as d:
+            labels_dir = Path(d) / "labels"
+            labels_dir.mkdir()
+            jdict = []
+            for t in range(T):
+                pred, predn = torch.from_numpy(g[f"pred{t}"]), torch.from_numpy(g[f"predn{t}"])
+                geom = g[f"geom{t}"]
+                shapes = [((int(geom[2]), int(geom[3])), None)]
+                ns = dict(torch=torch, save_txt=True, save_json=True, save_conf=save_conf, labels_list=labels_list, path=Path("/data/visible/test") / (stems[t] + ".jpg"),
+                          shapes=shapes, si=0, predn=predn, pred=pred, labels_dir=labels_dir, jdict=jdict, is_coco=False, coco91class=None,
+                          xyxy2xywh=general.xyxy2xywh, xyxy2xywh2=general.xyxy2xywh2)
+                exec(txt_code, ns)
+                exec(json_code, ns)
+            exec(merge_code, dict(save_txt=True, os=os, labels_dir=labels_dir))
+            files = {n: open(labels_dir / n).read() for n in sorted(os.listdir(labels_dir))}
+            out["runs"]["conf" if save_conf else "noconf"] = {"files": files, "jdict": jdict}
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(out, f)
+    print(name, "files:", len(out["runs"]["conf"]["files"]), "json rows:", len(out["runs"]["conf"]["jdict"]))
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     yt, common, general, metrics = import_reference()
@@ -251,6 +301,9 @@ def main():
         return
     if "--n-only" in sys.argv:                        # yolov5n + DMFF (16-channel stem, C = 64 / 128 / 256 fusion blocks), added later
         model_case(yt, "model_n_flir_352x320_b2", "yolov5n_Transfusion_FLIR.yaml", 2, 352, 320, seed=14)
+        return
+    if "--results-only" in sys.argv:                  # the --save-txt / --save-json file formats (test.py:162-171, 184-195, 248-258)
+        results_case(general, "result_files")
         return
     if "--rect-only" in sys.argv:                     # the shape real KAIST validation batches have under the reference's rect protocol
         model_case(yt, "model_s_kaist_544x672_b1", "yolov5s_Transfusion_kaist.yaml", 1, 544, 672, seed=15)     # (512x640 frames,
@@ -280,6 +333,7 @@ def main():
     model_case(yt, "model_n_flir_352x320_b2", "yolov5n_Transfusion_FLIR.yaml", 2, 352, 320, seed=14)
     match_case(general, "match_predictions")
     model_case(yt, "model_s_kaist_544x672_b1", "yolov5s_Transfusion_kaist.yaml", 1, 544, 672, seed=15)
+    results_case(general, "result_files")
 
 
 if __name__ == "__main__":
