@@ -21,18 +21,8 @@ import torch
 from icafusion_amd.models.experimental import attempt_load
 from icafusion_amd.models.yolo import Model
 from icafusion_amd.utils.datasets import LoadImages, imwrite_bgr
-from icafusion_amd.utils.general import non_max_suppression, scale_coords, xyxy2xywh
+from icafusion_amd.utils.general import increment_path, non_max_suppression, scale_coords, xyxy2xywh
 from icafusion_amd.utils.torch_utils import select_device, time_synchronized
-
-
-def increment_path(path, exist_ok=False):
-    path = Path(path)
-    if not path.exists() or exist_ok:
-        return path
-    n = 2
-    while Path(f"{path}{n}").exists():
-        n += 1
-    return Path(f"{path}{n}")
 
 
 def draw_boxes(img_bgr, det, names, thickness=2, hide_labels=False):
@@ -64,6 +54,8 @@ def load_model(opt, device):
 
 @torch.no_grad()
 def detect(opt):
+    if getattr(opt, "augment", False):
+        raise NotImplementedError("test-time augmentation (models/yolo_test.py:116-132) is outside the inference hot path")
     device = select_device(opt.device)
     save_img = not opt.nosave
     save_dir = increment_path(Path(opt.project) / opt.name, exist_ok=opt.exist_ok)
@@ -133,6 +125,9 @@ def parse_opt(argv=None):
     ap.add_argument("--exist-ok", action="store_true")
     ap.add_argument("--line-thickness", default=2, type=int)
     ap.add_argument("--hide-labels", default=False, action="store_true")
+    ap.add_argument("--hide-conf", default=True, action="store_true", help="accepted for the reference's command lines: its default is True and "
+                    "cannot be switched off (:224), i.e. boxes carry the class name only — which is what is drawn here")
+    ap.add_argument("--augment", action="store_true", help="test-time augmentation: not built, raises")
     return ap.parse_args(argv)
 
 

@@ -226,3 +226,49 @@ def test_validation_loop_on_cpu_with_the_oracle_behind_it(tmp_path, monkeypatch)
     rows = json.load(open(run / "best_predictions.json"))
     assert len(rows) == total and {r["image_id"] for r in rows} == {s for s, d in per_image.items() if len(d)}
     assert all(set(r) == {"image_id", "category_id", "bbox", "score"} and r["category_id"] in (0, 1, 2) for r in rows)
+
+
+def test_detect_twostream_loop_on_cpu_with_the_oracle_behind_it(tmp_path, monkeypatch):
+    """detect_twostream.py's host side (paired loaders, letterbox, box scaling, label files, annotated images, run directory numbering)
+    with forward + NMS replaced by the CPU oracle."""
+    import sys
+    import torch
+    import yaml
+    sys.path.insert(0, HERE)
+    from test_frontends import make_dataset
+    from helpers import REPO
+    sys.path.insert(0, REPO)
+    import detect_twostream as dt
+    from icafusion_amd.models.yolo import Model
+    from icafusion_amd.synth import synth_state_dict
+    from oracle import icaf_oracle as oracle
+    rgb_dir, ir_dir = make_dataset(str(tmp_path / "set"), n=3, size=(120, 128), nc=3, seed=6)
+    cfg = yaml.safe_load(open(os.path.join(REPO, "models", "transformer", "yolov5s_Transfusion_FLIR.yaml")))
+    om = oracle.OracleModel(cfg, synth_state_dict(Model(cfg), seed=0))
+
+    class FakeModel:
+        stride = torch.tensor([8.0, 16.0, 32.0])
+        names = ["person", "car", "bicycle"]
+
+        def forward_u8(self, img6):
+            f = img6.float() / 255.0
+            return (om.forward(f[:, :3].contiguous(), f[:, 3:].contiguous())[0],)
+
+    def fake_nms(pred, conf_thres, iou_thres, classes=None, agnostic=False, **kw):
+        return [torch.from_numpy(d.copy()) for d in oracle.non_max_suppression(pred.numpy(), conf_thres, iou_thres, classes=classes, agnostic=agnostic)]
+
+    monkeypatch.setattr(dt, "load_model", lambda opt, device: FakeModel())
+    monkeypatch.setattr(dt, "non_max_suppression", fake_nms)
+    monkeypatch.setattr(dt, "select_device", lambda d: torch.device("cpu"))
+    args = ["--source1", rgb_dir, "--source2", ir_dir, "--img-size", "320", "--conf-thres", "0.3", "--save-txt", "--save-conf",
+            "--project", str(tmp_path / "runs"), "--name", "exp", "--hide-conf"]
+    out = dt.detect(dt.parse_opt(args))
+    assert out == tmp_path / "runs" / "exp" and len(list(out.glob("*_rgb.png"))) == 3 and len(list(out.glob("*_ir.png"))) == 3
+    txts = sorted((out / "labels").glob("*.txt"))
+    assert txts, "conf 0.3 leaves detections on the synthetic weights"
+    for t in txts:
+        rows = np.loadtxt(t, ndmin=2)                                    # cls cx cy w h conf, normalised to the native image
+        assert rows.shape[1] == 6 and (rows[:, 1:5] >= 0).all() and (rows[:, 1:5] <= 1).all() and (rows[:, 5] >= 0.3).all()
+        assert set(rows[:, 0].astype(int)) <= {0, 1, 2}
+    assert dt.detect(dt.parse_opt(args)) == tmp_path / "runs" / "exp2"                  # the run directory is numbered, not overwritten
+    assert dt.detect(dt.parse_opt(args + ["--exist-ok", "--nosave"])) == tmp_path / "runs" / "exp"
