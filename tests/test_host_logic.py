@@ -208,3 +208,26 @@ def test_fastdiv_matches_integer_division(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fastdiv ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_committed_tune_caches_only_name_configurations_the_tuner_would_time():
+    """Every (signature -> launch configuration) pair in profiles/tune_cache*.json is one conv_candidates() offers for that
+    signature: a cache edited by hand, or left behind by a change of the candidate rules, cannot pin a configuration the
+    library rejects or the bit-identity tests never see."""
+    import glob
+    import json
+    from types import SimpleNamespace
+
+    from icafusion_amd import ops
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "tune_cache*.json")))
+    assert files
+    n = 0
+    for f in files:
+        for key, tile in json.load(open(f)):
+            (M, cout, cin, kh, kw, sh, sw, H, W, ldx, ldy, groups, dtype, out_dtype, act, res, pre, cout2, chain_keep) = key
+            a = SimpleNamespace(Cout=cout, Cin=cin, kh=kh, kw=kw, sh=sh, sw=sw, ph=kh // 2, pw=kw // 2, dtype=dtype, out_dtype=out_dtype,
+                                act=act, pre=bool(pre), w2=bool(cout2), Cout2=cout2)
+            assert tile in ops.conv_candidates(a), (os.path.basename(f), key, tile)
+            assert ldy >= cout and ldx >= cin and M > 0 and groups in (1, 2)
+            n += 1
+    assert n > 150
