@@ -1,6 +1,6 @@
 #!/bin/bash
-# One short GPU call: tests of the kernels touched last (detect decode / upsample index math, pipeline __call__), the SPPF
-# workgroup-size probe, a per-launch profile, and three bench A/Bs (default, --fold-upsample, fused DMFF up to C = 256).
+# One short GPU call (about 40 s): tests of the kernels touched last (Detect decode, nearest up-sampling, DMFF pooling, pipeline), a per-launch
+# profile with the rows of those kernels printed, and the default bench twice (the spread of one box).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
 t0=$(date +%s)
