@@ -290,6 +290,31 @@ def results_case(general, name):
     print(name, "files:", len(out["runs"]["conf"]["files"]), "json rows:", len(out["runs"]["conf"]["jdict"]))
 
 
+def pool_window_case(common, name):
+    """Pin AdaptivePool2d's window rule (models/common.py:868-891) over a sweep of feature-map sizes, not just the four DMFF fixtures:
+    for the three anchor grids of the shipped yamls and ~1,200 (h, w) each — every height from the grid size to 170, eight scattered
+    widths per height, sizes below the grid in one dimension included where the reference still runs — the reference module's output
+    shape and the float64 sum of its avg / max outputs on a seeded tensor."""
+    rows = []
+    for va, ha in ((20, 20), (16, 16), (10, 10)):
+        avg, mx = common.AdaptivePool2d(va, ha, "avg"), common.AdaptivePool2d(va, ha, "max")
+        sizes = [(h, ha - 3 + ((h * 7 + j * 13) % (174 - ha))) for h in range(va - 3, 171) for j in range(8)]
+        sizes += [(va, ha), (va - 1, ha), (va, ha - 2), (va - 3, ha - 3), (va // 2, ha // 2)]     # at or below the grid on both sides: identity
+        for h, w in sizes:
+            g = np.random.default_rng([va, h, w])
+            x = torch.from_numpy(g.normal(0, 1, (1, 2, h, w)).astype(np.float32))
+            try:
+                a, m = avg(x), mx(x)
+            except Exception:                           # one side above the grid and the other below it: stride 0, torch raises
+                rows.append((va, ha, h, w, -1, -1, 0.0, 0.0))
+                continue
+            assert a.shape == m.shape
+            rows.append((va, ha, h, w, a.shape[2], a.shape[3], float(a.double().sum()), float(m.double().sum())))
+    rows = np.asarray(rows, np.float64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), rows=rows)
+    print(name, rows.shape, "raising:", int((rows[:, 4] < 0).sum()))
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     yt, common, general, metrics = import_reference()
@@ -301,6 +326,9 @@ def main():
         return
     if "--n-only" in sys.argv:                        # yolov5n + DMFF (16-channel stem, C = 64 / 128 / 256 fusion blocks), added later
         model_case(yt, "model_n_flir_352x320_b2", "yolov5n_Transfusion_FLIR.yaml", 2, 352, 320, seed=14)
+        return
+    if "--pool-only" in sys.argv:                     # AdaptivePool2d window rule over a sweep of sizes
+        pool_window_case(common, "adaptive_pool_windows")
         return
     if "--results-only" in sys.argv:                  # the --save-txt / --save-json file formats (test.py:162-171, 184-195, 248-258)
         results_case(general, "result_files")
@@ -334,6 +362,7 @@ def main():
     match_case(general, "match_predictions")
     model_case(yt, "model_s_kaist_544x672_b1", "yolov5s_Transfusion_kaist.yaml", 1, 544, 672, seed=15)
     results_case(general, "result_files")
+    pool_window_case(common, "adaptive_pool_windows")
 
 
 if __name__ == "__main__":
