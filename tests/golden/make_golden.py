@@ -315,6 +315,49 @@ def pool_window_case(common, name):
     print(name, rows.shape, "raising:", int((rows[:, 4] < 0).sum()))
 
 
+DATASET_CASES = [dict(n=7, size=(96, 128), nc=3, seed=9, img_size=160, batch=2, mixed=True),         # both orientations, ragged last batch
+                 dict(n=10, size=(100, 150), nc=2, seed=10, img_size=320, batch=4, mixed=True),
+                 dict(n=5, size=(128, 160), nc=1, seed=11, img_size=640, batch=8, mixed=False)]       # KAIST-like 4:5 frames, one batch: 544x672 rule
+
+
+def dataset_case(name):
+    """Pin the paired validation set's metadata path: the reference's LoadMultiModalImagesAndLabels.__init__ (utils/datasets.py:690-880:
+    file discovery, visible -> labels rule, label parsing, aspect-ratio sort, rectangular batch shapes with pad 0.5) is run on synthetic
+    paired folders written by tests/test_frontends.py::make_dataset; stored: file order, native shapes, batch shapes, labels.  Version
+    shims only (`np.int`, `torch.load(weights_only=False)` for the label cache the class writes next to the labels); __getitem__ needs
+    OpenCV and is not touched."""
+    import functools
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_frontends import make_dataset
+    import utils.datasets as rd
+    assert rd.__file__.startswith(REF)
+    if not hasattr(np, "int"):
+        np.int = int
+    real_load = torch.load
+    rd.torch.load = functools.partial(real_load, weights_only=False)
+    rec = {}
+    try:
+        for k, c in enumerate(DATASET_CASES):
+            with tempfile.TemporaryDirectory() as d:
+                rgb_dir, ir_dir = make_dataset(d, n=c["n"], size=c["size"], nc=c["nc"], seed=c["seed"], mixed=c["mixed"])
+                ds = rd.LoadMultiModalImagesAndLabels(rgb_dir, ir_dir, c["img_size"], c["batch"], augment=False, hyp=None, rect=True,
+                                                      cache_images=False, single_cls=False, stride=32, pad=0.5, image_weights=False, prefix="")
+                assert [os.path.basename(f) for f in ds.img_files_rgb] == [os.path.basename(f) for f in ds.img_files_ir]
+                rec[f"files{k}"] = np.asarray([os.path.basename(f) for f in ds.img_files_rgb])
+                rec[f"label_files{k}"] = np.asarray([os.path.relpath(f, d) for f in ds.label_files_rgb])
+                rec[f"shapes{k}"] = np.asarray(ds.shapes_rgb)                      # (w, h) per image, sorted order
+                rec[f"batch_shapes{k}"] = np.asarray(ds.batch_shapes_rgb)          # (h, w) per batch
+                rec[f"batch{k}"] = np.asarray(ds.batch_rgb)
+                rec[f"labels{k}"] = np.concatenate([np.concatenate((np.full((len(l), 1), i, np.float32), l), 1) for i, l in enumerate(ds.labels_rgb)])
+                print(name, k, rec[f"files{k}"].tolist(), rec[f"batch_shapes{k}"].tolist())
+    finally:
+        rd.torch.load = real_load
+    import json
+    rec["cases"] = np.asarray(json.dumps(DATASET_CASES))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     yt, common, general, metrics = import_reference()
@@ -326,6 +369,9 @@ def main():
         return
     if "--n-only" in sys.argv:                        # yolov5n + DMFF (16-channel stem, C = 64 / 128 / 256 fusion blocks), added later
         model_case(yt, "model_n_flir_352x320_b2", "yolov5n_Transfusion_FLIR.yaml", 2, 352, 320, seed=14)
+        return
+    if "--dataset-only" in sys.argv:                  # rect validation set metadata from the reference's dataset class
+        dataset_case("rect_dataset")
         return
     if "--pool-only" in sys.argv:                     # AdaptivePool2d window rule over a sweep of sizes
         pool_window_case(common, "adaptive_pool_windows")
@@ -363,6 +409,7 @@ def main():
     model_case(yt, "model_s_kaist_544x672_b1", "yolov5s_Transfusion_kaist.yaml", 1, 544, 672, seed=15)
     results_case(general, "result_files")
     pool_window_case(common, "adaptive_pool_windows")
+    dataset_case("rect_dataset")
 
 
 if __name__ == "__main__":

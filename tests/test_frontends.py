@@ -195,3 +195,26 @@ def test_detect_twostream_and_test_py_end_to_end(tmp_path):
             conf.append(d[:, 4]); pcls.append(d[:, 5]); tcls.append(lab[:, 0].numpy())
     ap, _ = oracle.ap_per_class(np.concatenate(tp), np.concatenate(conf), np.concatenate(pcls), np.concatenate(tcls))
     assert abs(100 * map50 - 100 * ap[:, 0].mean()) <= 0.1 and abs(100 * map_ - 100 * ap.mean()) <= 0.1
+
+
+def test_paired_validation_set_metadata_equals_the_reference_class(tmp_path):
+    """File discovery, the visible -> labels rule, label parsing, the aspect-ratio sort and the rectangular batch shapes of the
+    reference's LoadMultiModalImagesAndLabels (utils/datasets.py:690-880), recorded by tests/golden/make_golden.py --dataset-only
+    from the reference class itself on the same synthetic folders make_dataset() writes — including the KAIST-like case whose
+    single batch comes out as 544x672."""
+    import json
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rect_dataset.npz"))
+    cases = json.loads(str(g["cases"]))
+    assert len(cases) == 3
+    for k, c in enumerate(cases):
+        root = str(tmp_path / f"set{k}")
+        rgb_dir, ir_dir = make_dataset(root, n=c["n"], size=tuple(c["size"]), nc=c["nc"], seed=c["seed"], mixed=c["mixed"])
+        _, ds = D.create_dataloader_rgb_ir(rgb_dir, ir_dir, c["img_size"], c["batch"], 32, None, pad=0.5, rect=True)
+        assert [os.path.basename(f) for f in ds.rgb] == g[f"files{k}"].tolist(), k
+        assert [os.path.basename(f) for f in ds.ir] == g[f"files{k}"].tolist()
+        assert [os.path.relpath(f, root) for f in ds.label_files] == g[f"label_files{k}"].tolist()
+        assert ds.batch_shapes.tolist() == g[f"batch_shapes{k}"].tolist(), k
+        assert ds.batch.tolist() == g[f"batch{k}"].tolist()
+        mine = np.concatenate([np.concatenate((np.full((len(l), 1), i, np.float32), l), 1) for i, l in enumerate(ds.labels)])
+        np.testing.assert_array_equal(mine, g[f"labels{k}"])
+    assert g["batch_shapes2"].tolist() == [[544, 672]]
