@@ -358,6 +358,33 @@ def dataset_case(name):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
 
 
+def half_case(yt, name):
+    """The reference's own 16-bit behaviour (detect_twostream.py:33-40 / test.py:73-75: `.fuse()` then `.half()`): the real reference model,
+    fused, cast to bf16 / fp16 and run on the CPU on the seeded inputs of two fixtures, next to its fp32 output.  Stored: the 16-bit
+    outputs and their deviation from fp32 — the yardstick the 16-bit parity bounds of the HIP path are derived from (the 16-bit mode of
+    the oracle, `OracleModel(dtype=)`, is checked against these numbers in tests/test_oracle_vs_golden.py)."""
+    rec = {}
+    cases = [("s", "yolov5s_Transfusion_kaist.yaml", 1, 320, 320, 1), ("l", "yolov5l_Transfusion_VEDAI.yaml", 1, 320, 320, 3)]
+    for tag, yaml_name, batch, h, w, seed in cases:
+        ref_cfg = os.path.join(REF, "models", "transformer", yaml_name)
+        rgb, ir = synth_images(batch, h, w, seed)
+        for dn, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+            model = yt.Model(ref_cfg).eval()
+            model.load_state_dict(synth_state_dict(model, seed))
+            model = model.fuse().eval()
+            with torch.no_grad():
+                z32 = model(rgb, ir)[0]
+                z16 = model.to(dt)(rgb.to(dt), ir.to(dt))[0].float()
+            d = (z16 - z32).abs()
+            rec[f"{tag}_{dn}_z16"] = z16.numpy()
+            rec[f"{tag}_{dn}_dev"] = np.asarray([d[..., :4].max(), d[..., :4].mean(), d[..., 4:].max(), d[..., 4:].mean()], np.float64)
+            rec[f"{tag}_z32"] = z32.numpy()
+            print(name, tag, dn, "box max / mean, conf max / mean:", rec[f"{tag}_{dn}_dev"].tolist())
+        rec[f"{tag}_meta"] = np.asarray([batch, h, w, seed])
+        rec[f"{tag}_yaml"] = np.asarray(yaml_name)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     yt, common, general, metrics = import_reference()
@@ -369,6 +396,9 @@ def main():
         return
     if "--n-only" in sys.argv:                        # yolov5n + DMFF (16-channel stem, C = 64 / 128 / 256 fusion blocks), added later
         model_case(yt, "model_n_flir_352x320_b2", "yolov5n_Transfusion_FLIR.yaml", 2, 352, 320, seed=14)
+        return
+    if "--half-only" in sys.argv:                     # the real reference run in bf16 / fp16 on the CPU
+        half_case(yt, "reference_16bit")
         return
     if "--dataset-only" in sys.argv:                  # rect validation set metadata from the reference's dataset class
         dataset_case("rect_dataset")
@@ -410,6 +440,7 @@ def main():
     results_case(general, "result_files")
     pool_window_case(common, "adaptive_pool_windows")
     dataset_case("rect_dataset")
+    half_case(yt, "reference_16bit")
 
 
 if __name__ == "__main__":

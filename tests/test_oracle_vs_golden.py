@@ -185,3 +185,31 @@ def test_adaptive_pool_window_rule_over_a_sweep_of_sizes():
             assert (kh, kw, sh, sw) == (1, 1, 1, 1) and (th, tw) == (h, w)
             seen["identity"] += 1
     assert seen["pool"] > 3000 and seen["identity"] >= 15 and seen["raise"] > 100 and seen["overlap"] > 2000, seen
+
+
+@pytest.mark.parametrize("tag", ["s", "l"])
+def test_sixteen_bit_oracle_deviates_like_the_reference_in_sixteen_bit(tag):
+    """The yardstick of the 16-bit parity bounds (tests/test_gpu_parity16.py, profiles/parity_16bit.json) is the oracle evaluated in
+    bf16 / fp16 — `OracleModel(dtype=)`.  tests/golden/reference_16bit.npz holds the REAL reference, fused and cast with `.to(dtype)` as
+    detect_twostream.py:33-40 does, run on the CPU: the oracle's deviation from fp32 must be the reference's (mean within 20 %; the
+    maximum is a single element and varies with the summation order — the reference's own run moves by 10 % with the thread count)."""
+    g = load_golden("reference_16bit")
+    batch, h, w, seed = [int(v) for v in g[f"{tag}_meta"]]
+    cfg = load_cfg(str(g[f"{tag}_yaml"]))
+    m = Model(cfg).eval()
+    m.load_state_dict(synth_state_dict(m, seed))
+    fsd = m.fuse().state_dict()
+    rgb, ir = synth_images(batch, h, w, seed)
+    z32 = oracle.OracleModel(cfg, fsd).forward(rgb, ir)[0]
+    ref32 = torch.from_numpy(g[f"{tag}_z32"])
+    assert float((z32 - ref32).abs().max()) <= 2e-3                       # fp32: the oracle IS the reference (boxes are O(100 px))
+    for dn, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        o16 = oracle.OracleModel(cfg, fsd, dtype=dt).forward(rgb, ir)[0].float()
+        d = (o16 - z32).abs()
+        mine = np.array([float(d[..., :4].max()), float(d[..., :4].mean()), float(d[..., 4:].max()), float(d[..., 4:].mean())])
+        ratio = mine / g[f"{tag}_{dn}_dev"]
+        assert 0.8 <= ratio[1] <= 1.25 and 0.8 <= ratio[3] <= 1.25, (tag, dn, ratio)          # mean box / conf deviation
+        assert 0.4 <= ratio[0] <= 2.5 and 0.4 <= ratio[2] <= 2.5, (tag, dn, ratio)            # max box / conf deviation
+        # and the two 16-bit evaluations are closer to each other than either is to fp32 (same roundings, different summation order)
+        x = (o16 - torch.from_numpy(g[f"{tag}_{dn}_z16"])).abs()
+        assert float(x[..., :4].mean()) < g[f"{tag}_{dn}_dev"][1] and float(x[..., 4:].mean()) < g[f"{tag}_{dn}_dev"][3]
