@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Differential run: the CPU oracle against the LIVE reference (imported from /root/reference, build container only) on randomly drawn
+cases — the committed fixtures pin a fixed set, this sweeps around them.  Executed as a subprocess by
+tests/test_reference_differential.py (importing the reference re-binds the `models` / `utils` package names, which must not leak into
+the pytest process).  Prints one line per group and DIFFERENTIAL_OK at the end; any mismatch raises.
+
+    python tests/reference_differential.py [seed]
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.dont_write_bytecode = True
+
+import numpy as np      # noqa: E402
+import torch            # noqa: E402
+import yaml             # noqa: E402
+
+import make_golden as mg                                             # noqa: E402
+from icafusion_amd.synth import synth_images, synth_state_dict, synth_tensor   # noqa: E402
+from oracle import icaf_oracle as oracle                              # noqa: E402
+
+
+def nms_sweep(general, g, n_cases):
+    """utils.general.non_max_suppression (greedy core = the oracle's, injected for the absent torchvision) vs oracle.non_max_suppression:
+    random class counts, thresholds, multi-label / agnostic / class-filter switches, ties and empty images."""
+    for k in range(n_cases):
+        nc = int(g.choice([1, 1, 2, 3, 9]))
+        B, rows = int(g.integers(1, 4)), int(g.choice([7, 60, 400, 1500, 5000]))
+        xy, wh = g.uniform(0, 640, (B, rows, 2)), g.uniform(2, 260, (B, rows, 2))
+        obj, cls = g.uniform(0, 1, (B, rows, 1)), g.uniform(0, 1, (B, rows, nc))
+        pred = np.concatenate((xy, wh, obj, cls), 2).astype(np.float32)
+        if k % 5 == 0 and rows > 50:
+            pred[:, 10:40, 4:] = pred[:, 10:11, 4:]                     # equal scores: order falls back to the row index
+        if k % 7 == 0:
+            pred[0, :, 4] = 0.0                                          # an image without candidates
+        kw = dict(conf_thres=float(g.choice([0.001, 0.1, 0.25, 0.6])), iou_thres=float(g.choice([0.2, 0.45, 0.5, 0.7])),
+                  multi_label=bool(g.integers(0, 2)), agnostic=bool(g.integers(0, 2)))
+        if nc > 1 and g.integers(0, 3) == 0:
+            kw["classes"] = sorted(set(int(c) for c in g.integers(0, nc, 2)))
+        want = general.non_max_suppression(torch.from_numpy(pred.copy()), **kw)
+        got = oracle.non_max_suppression(pred, **kw)
+        assert len(want) == len(got) == B
+        for w_, g_ in zip(want, got):
+            assert tuple(w_.shape) == tuple(g_.shape), (k, kw, w_.shape, g_.shape)
+            np.testing.assert_array_equal(w_.numpy(), g_, err_msg=f"nms case {k} {kw}")
+    print(f"nms: {n_cases} random cases bit-equal")
+
+
+def dmff_sweep(common, g, n_cases):
+    """models.common.TransformerFusionBlock vs oracle.dmff: random widths, anchor grids, input sizes (disjoint / overlapping /
+    identity windows, rectangular maps) and iteration counts."""
+    worst = 0.0
+    for k in range(n_cases):
+        c = int(g.choice([32, 64, 96, 128]))
+        va, ha = [(20, 20), (16, 16), (10, 10), (8, 12)][int(g.integers(0, 4))]
+        h, w = int(g.integers(va - 2, 3 * va + 5)), int(g.integers(ha - 2, 3 * ha + 5))
+        if (h > va) != (w > ha) and not (h > va and w > ha):
+            if (h > va or w > ha) and (h // va == 0 or w // ha == 0):
+                h, w = max(h, va), max(w, ha)                              # the reference raises on a zero stride: not a parity case
+        loops, batch, seed = int(g.integers(1, 4)), int(g.integers(1, 3)), 100 + k
+        blk = common.TransformerFusionBlock(c, va, ha).eval()
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.eps = 1e-3
+        sd = {kk: (v if kk.endswith("num_batches_tracked") else synth_tensor("model.20." + kk, v.shape, seed=seed)) for kk, v in blk.state_dict().items()}
+        blk.load_state_dict(sd)
+        blk.crosstransformer[0].loops = loops
+        rgb = torch.from_numpy(g.normal(0, 1, (batch, c, h, w)).astype(np.float32))
+        ir = torch.from_numpy(g.normal(0, 1, (batch, c, h, w)).astype(np.float32))
+        with torch.no_grad():
+            want = blk([rgb, ir])
+        osd = {"model.20." + kk: v for kk, v in sd.items()}
+        got = oracle.dmff(rgb, ir, osd, "model.20", va, ha, 8, loops)
+        err = float((got - want).abs().max()) / max(1.0, float(want.abs().max()))
+        assert got.shape == want.shape and err <= 2e-4, (k, c, va, ha, h, w, loops, err)
+        worst = max(worst, err)
+    print(f"dmff: {n_cases} random blocks, worst relative error {worst:.2e}")
+
+
+def model_sweep(yt, g, n_cases):
+    """models.yolo_test.Model vs OracleModel at random rectangular input sizes / families / iteration counts."""
+    fams = ["yolov5n_Transfusion_FLIR.yaml", "yolov5s_Transfusion_kaist.yaml", "yolov5n_NiNfusion_FLIR.yaml", "yolov5s_Add_kaist.yaml",
+            "yolov5m_Transfusion_VEDAI.yaml", "yolov5n_Add_kaist.yaml", "yolov5s_Transfusion_FLIR.yaml"]
+    fams = [f for f in fams if os.path.isfile(os.path.join(mg.REF, "models", "transformer", f)) and
+            os.path.isfile(os.path.join(REPO, "models", "transformer", f))]
+    assert len(fams) >= 5
+    worst = 0.0
+    for k in range(n_cases):
+        name = fams[k % len(fams)]
+        h, w = 32 * int(g.integers(10, 14)), 32 * int(g.integers(10, 14))
+        loops = int(g.integers(1, 3)) if "Transfusion" in name else None
+        seed = 200 + k
+        ref_cfg = os.path.join(mg.REF, "models", "transformer", name)
+        model = yt.Model(ref_cfg).eval()
+        sd = synth_state_dict(model, seed)
+        model.load_state_dict(sd)
+        if loops is not None:
+            for i in (20, 21, 22):
+                model.model[i].crosstransformer[0].loops = loops
+        rgb, ir = synth_images(1, h, w, seed)
+        with torch.no_grad():
+            z, logits, raws = model(rgb, ir)
+        cfg = yaml.safe_load(open(os.path.join(REPO, "models", "transformer", name)))
+        oz, ologits, oraws = oracle.OracleModel(cfg, sd, loops=loops).forward(rgb, ir)
+        eb = float((oz[..., :4] - z[..., :4]).abs().max()) / max(1.0, float(z[..., :4].abs().max()))
+        es = float((oz[..., 4:] - z[..., 4:]).abs().max())
+        assert oz.shape == z.shape and eb <= 2e-4 and es <= 2e-4, (name, h, w, loops, eb, es)
+        assert all(tuple(a.shape) == tuple(b.shape) for a, b in zip(oraws, raws))
+        worst = max(worst, eb, es)
+    print(f"model: {n_cases} random (family, shape, iterations), worst error {worst:.2e}")
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    yt, common, general, metrics = mg.import_reference()
+    g = np.random.default_rng([2026, seed])
+    nms_sweep(general, g, 60)
+    dmff_sweep(common, g, 10)
+    model_sweep(yt, g, 7)
+    print("DIFFERENTIAL_OK")
+
+
+if __name__ == "__main__":
+    main()
