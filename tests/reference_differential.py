@@ -114,6 +114,87 @@ def model_sweep(yt, g, n_cases):
     print(f"model: {n_cases} random (family, shape, iterations), worst error {worst:.2e}")
 
 
+def metrics_sweep(general, metrics, g, n_cases):
+    """utils.metrics.ap_per_class, utils.general.box_iou / scale_coords / xyxy2xywh / xywh2xyxy vs the host mirror and the oracle."""
+    from icafusion_amd.utils import general as mine_g
+    from icafusion_amd.utils import metrics as mine_m
+    for k in range(n_cases):
+        n, nc, nt = int(g.integers(1, 600)), int(g.integers(1, 6)), int(g.integers(1, 200))
+        tp = np.logical_and.accumulate(g.random((n, 10)) < np.linspace(g.uniform(0.3, 0.9), 0.05, 10)[None], 1)
+        conf, pcls = g.random(n).astype(np.float32), g.integers(0, nc, n).astype(np.float32)
+        tcls = g.integers(0, nc, nt).astype(np.float32)
+        if k % 4 == 0:
+            tp[:] = False                                                   # no true positive at all
+        want = metrics.ap_per_class(tp, conf, pcls, tcls)
+        got = mine_m.ap_per_class(tp, conf, pcls, tcls)
+        for a, b, what in zip(want, got, ("tp", "fp", "fn", "p", "r", "ap", "f1", "classes")):
+            np.testing.assert_allclose(np.asarray(b, np.float64), np.asarray(a, np.float64), rtol=1e-9, atol=1e-12, err_msg=f"ap_per_class {what} case {k}")
+        oap, ocls = oracle.ap_per_class(tp, conf, pcls, tcls)
+        np.testing.assert_allclose(oap, want[5], rtol=1e-9, atol=1e-12)
+        a = torch.from_numpy(g.uniform(0, 600, (int(g.integers(1, 40)), 2)).astype(np.float32))
+        b = torch.from_numpy(g.uniform(0, 600, (int(g.integers(1, 40)), 2)).astype(np.float32))
+        b1 = torch.cat((a, a + torch.from_numpy(g.uniform(1, 200, a.shape).astype(np.float32))), 1)
+        b2 = torch.cat((b, b + torch.from_numpy(g.uniform(1, 200, b.shape).astype(np.float32))), 1)
+        assert torch.equal(general.box_iou(b1, b2), mine_g.box_iou(b1, b2))
+        assert torch.equal(general.xyxy2xywh(b1), mine_g.xyxy2xywh(b1)) and torch.equal(general.xywh2xyxy(b1), mine_g.xywh2xyxy(b1))
+        assert torch.equal(general.xyxy2xywh2(b1), mine_g.xyxy2xywh2(b1))
+        h0, w0 = int(g.integers(100, 900)), int(g.integers(100, 900))
+        H, W = 32 * int(g.integers(5, 25)), 32 * int(g.integers(5, 25))
+        c = torch.from_numpy(g.uniform(-30, 900, (25, 4)).astype(np.float32))
+        assert torch.equal(general.scale_coords((H, W), c.clone(), (h0, w0)), mine_g.scale_coords((H, W), c.clone(), (h0, w0)))
+        gain = min(H / h0, W / w0)
+        rp = ((gain, gain), ((W - w0 * gain) / 2, (H - h0 * gain) / 2))
+        assert torch.equal(general.scale_coords((H, W), c.clone(), (h0, w0), rp), mine_g.scale_coords((H, W), c.clone(), (h0, w0), rp))
+    print(f"metrics / box helpers: {n_cases} random cases equal")
+
+
+def match_sweep(general, g, n_cases):
+    """The INLINE TP-matching block of the reference's validation loop (test.py:196-230, exec'ed from its source lines as
+    make_golden.match_case does) vs the host statement and the oracle, on random detections / labels."""
+    import textwrap
+    from icafusion_amd.utils.metrics import match_predictions
+    with open(os.path.join(mg.REF, "test.py")) as f:
+        lines = f.read().splitlines()
+    i0 = next(i for i, l in enumerate(lines) if "# Assign all predictions as incorrect" in l)
+    i1 = next(i for i, l in enumerate(lines) if i > i0 and "# Append statistics (correct, conf, pcls, tcls)" in l)
+    code = compile(textwrap.dedent("\n".join(lines[i0:i1])).rstrip(), "reference test.py:196-230", "exec")
+    iouv = torch.linspace(0.5, 0.95, 10)
+    hits = 0
+    for k in range(n_cases):
+        H, W = 32 * int(g.integers(5, 22)), 32 * int(g.integers(5, 22))
+        h0, w0 = int(g.integers(80, 800)), int(g.integers(80, 800))
+        gain = min(H / h0, W / w0)
+        shapes = [((h0, w0), ((gain, gain), ((W - w0 * gain) / 2, (H - h0 * gain) / 2)))]
+        m, n, nc = int(g.integers(0, 9)), int(g.integers(0, 80)), int(g.integers(1, 4))
+        cls = g.integers(0, nc, (m, 1)).astype(np.float32)
+        labels = torch.from_numpy(np.concatenate((cls, g.uniform(0.2, 0.8, (m, 2)) * [W, H], g.uniform(0.04, 0.3, (m, 2)) * [W, H]), 1).astype(np.float32))
+        if m and n:
+            src = labels[g.integers(0, m, n)]
+            xyxy = general.xywh2xyxy(src[:, 1:5]) + torch.from_numpy(g.normal(0, 0.05, (n, 4)).astype(np.float32)) * src[:, [3, 4, 3, 4]]
+            pcls = torch.where(torch.from_numpy(g.random(n) < 0.75), src[:, 0], torch.from_numpy(g.integers(0, nc, n).astype(np.float32)))
+        else:
+            a = torch.from_numpy(g.uniform(0, 100, (n, 2)).astype(np.float32))
+            xyxy, pcls = torch.cat((a, a + 30), 1), torch.from_numpy(g.integers(0, nc, n).astype(np.float32))
+        conf = torch.from_numpy(np.sort(g.random(n).astype(np.float32))[::-1].copy())
+        pred = torch.cat((xyxy, conf[:, None], pcls[:, None]), 1)
+        img = torch.zeros(1, 6, H, W)
+        predn = pred.clone()
+        general.scale_coords(img[0].shape[1:], predn[:, :4], shapes[0][0], shapes[0][1])
+        ns = dict(torch=torch, pred=pred, predn=predn, labels=labels, nl=len(labels), niou=10, iouv=iouv, device="cpu", img=img, si=0,
+                  shapes=shapes, plots=False, scale_coords=general.scale_coords, xywh2xyxy=general.xywh2xyxy, box_iou=general.box_iou,
+                  confusion_matrix=None)
+        exec(code, ns)
+        want = ns["correct"].numpy()
+        tbox = general.xywh2xyxy(labels[:, 1:5])
+        general.scale_coords(img[0].shape[1:], tbox, shapes[0][0], shapes[0][1])
+        gt = torch.cat((labels[:, :1], tbox), 1).numpy()
+        np.testing.assert_array_equal(match_predictions(predn.numpy(), gt, iouv.numpy()), want, err_msg=f"host statement, case {k}")
+        np.testing.assert_array_equal(oracle.match_predictions(predn.numpy(), gt, iouv.numpy()), want, err_msg=f"oracle, case {k}")
+        hits += int(want[:, 0].sum())
+    assert hits > n_cases                                                    # the sweep does exercise matches
+    print(f"TP matching: {n_cases} random images equal ({hits} true positives at IoU 0.5)")
+
+
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -122,6 +203,8 @@ def main():
     nms_sweep(general, g, 60)
     dmff_sweep(common, g, 10)
     model_sweep(yt, g, 7)
+    metrics_sweep(general, metrics, g, 24)
+    match_sweep(general, g, 60)
     print("DIFFERENTIAL_OK")
 
 

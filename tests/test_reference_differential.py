@@ -1,6 +1,7 @@
 """Live differential test against the reference itself — runs only where /root/reference exists (the build container; the GPU box and
 any other checkout skip it).  The committed fixtures pin fixed cases; this draws random ones around them on every run:
-60 NMS configurations (bit-equal), 10 DMFF blocks and 7 whole models of random family / rectangular shape / iteration count."""
+60 NMS configurations (bit-equal), 10 DMFF blocks, 7 whole models of random family / rectangular shape / iteration count, 24 ap_per_class /
+box-helper cases and 60 images through the inline TP-matching block."""
 import os
 import subprocess
 import sys
