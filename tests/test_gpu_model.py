@@ -1,5 +1,7 @@
 """End-to-end parity on the MI355X: Model(cfg) built from the repo's yaml files, weights from icafusion_amd.synth,
 HIP forward vs (a) the committed outputs of the real reference (tests/golden) and (b) the CPU oracle at other sizes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -53,6 +55,13 @@ def test_fp32_forward_matches_reference_golden(name):
         assert tuple(r.shape) == tuple(g[f"raw{l}_shape"])
         got = r.cpu().reshape(-1)[torch.from_numpy(sample_idx(r.numel(), 100 + l))].numpy()
         assert np.abs(got - g[f"raw{l}"]).max() <= 1e-3 * max(1.0, np.abs(g[f"raw{l}"]).max())
+
+
+@pytest.mark.skipif(not os.environ.get("ICAF_TEST_NEXT"), reason="fixture generated after the round's GPU budget was spent: run once with "
+                    "ICAF_TEST_NEXT=1, then move the name into GOLDEN (DESIGN.md §6)")
+def test_fp32_forward_matches_reference_golden_rect_validation_shape():
+    """The 544x672 batch shape of the reference's rect validation protocol (DMFF windows (11, 8) / (4, 12) / (8, 3), 17x21 map at P5)."""
+    test_fp32_forward_matches_reference_golden("model_s_kaist_544x672_b1")
 
 
 def test_loops_yaml_argument_equals_attribute():
