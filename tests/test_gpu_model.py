@@ -1,5 +1,6 @@
 """End-to-end parity on the MI355X: Model(cfg) built from the repo's yaml files, weights from icafusion_amd.synth,
 HIP forward vs (a) the committed outputs of the real reference (tests/golden) and (b) the CPU oracle at other sizes."""
+import json
 import os
 
 import numpy as np
@@ -34,12 +35,37 @@ def build(yaml_name, seed, dtype=torch.float32, loops=None):
 GOLDEN = ["model_s_kaist_320_b2", "model_s_kaist_384x320_loops3", "model_l_vedai_320_b1", "model_s_kaist_640_b1",
           "model_s_add_kaist_320_b1", "model_n_ninfusion_flir_320_b2",      # Add / NiNfusion variants
           "model_m_kaist_320_b1",                                           # yolov5m widths: 48 / 96 / 192 / 384 / 768 channels
-          "model_n_flir_352x320_b2"]                                        # yolov5n + DMFF, rectangular input, FLIR classes
+          "model_n_flir_352x320_b2",                                        # yolov5n + DMFF, rectangular input, FLIR classes
+          "model_s_kaist_544x672_b1"]                                       # test.py's rect validation batch shape of KAIST frames: DMFF windows
+#                                                                             (11, 8) / (4, 12) / (8, 3), odd 17 x 21 map at P5 (utils/datasets.py:840-849)
+
+# Measured fp32 errors of every golden (absolute: box pixels, scores, logits, raw maps) are appended to gpurun_out/parity_fp32.jsonl;
+# profiles/parity_fp32.json is the committed copy of one run.  Bound = 10 x the committed measurement (never below the floor, which
+# is what a different summation order of one more layer would cost), absolute - not relative to max|z|: a regression of a few
+# hundredths of a pixel fails.  A golden without a committed measurement falls back to north_star's 1e-3 relative to the scale.
+_FLOOR = {"box_px": 2e-3, "score": 2e-5, "logit": 2e-4, "raw": 2e-4}
+
+
+def _fp32_bounds(name, scale):
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "parity_fp32.json")
+    try:
+        with open(path) as f:
+            rec = {r["golden"]: r for r in json.load(f)["goldens"]}[name]
+        return {k: max(10.0 * rec[k], _FLOOR[k]) for k in _FLOOR}
+    except (OSError, KeyError):
+        return {"box_px": 1e-3 * scale["box_px"], "score": 1e-3, "logit": 1e-3 * scale["logit"], "raw": 1e-3 * scale["raw"]}
+
+
+def _assert_abs(z, ref, what, box_px=2e-2, score=2e-4):
+    """Absolute fp32 bounds (pixels / probabilities): ~10 x what the goldens measure (profiles/parity_fp32.json)."""
+    e_box, e_sc = float(np.abs(z[..., :4] - ref[..., :4]).max()), float(np.abs(z[..., 4:] - ref[..., 4:]).max())
+    print(f"{what}: box error {e_box:.3g} px, score error {e_sc:.3g}")
+    assert e_box <= box_px and e_sc <= score, (what, e_box, e_sc)
 
 
 @pytest.mark.parametrize("name", GOLDEN)
 def test_fp32_forward_matches_reference_golden(name):
-    """fp32 HIP path vs the real reference's recorded output (north_star: fp32 1e-3)."""
+    """fp32 HIP path vs the real reference's recorded output (north_star: fp32 1e-3; asserted far tighter, see _fp32_bounds)."""
     g = load_golden(name)
     batch, h, w, seed, loops = [int(v) for v in g["meta"]]
     cfg, sd, m = build(str(g["yaml"]), seed, loops=None if loops < 0 else loops)
@@ -47,21 +73,26 @@ def test_fp32_forward_matches_reference_golden(name):
     z, logits, raws = m(rgb.to(DEV), ir.to(DEV))
     zc, ref = z.cpu().numpy(), g["z"]
     assert zc.shape == ref.shape
-    # boxes in pixels (values up to ~1e3): 1e-3 relative to the coordinate scale; scores: 1e-3 absolute
-    assert np.abs(zc[..., :4] - ref[..., :4]).max() <= 1e-3 * max(1.0, np.abs(ref[..., :4]).max())
-    assert np.abs(zc[..., 4:] - ref[..., 4:]).max() <= 1e-3
-    assert np.abs(logits.cpu().numpy() - g["logits"]).max() <= 1e-3 * max(1.0, np.abs(g["logits"]).max())
+    err = {"box_px": float(np.abs(zc[..., :4] - ref[..., :4]).max()), "score": float(np.abs(zc[..., 4:] - ref[..., 4:]).max()),
+           "logit": float(np.abs(logits.cpu().numpy() - g["logits"]).max()), "raw": 0.0}
+    scale = {"box_px": max(1.0, float(np.abs(ref[..., :4]).max())), "logit": max(1.0, float(np.abs(g["logits"]).max())), "raw": 1.0}
     for l, r in enumerate(raws):
         assert tuple(r.shape) == tuple(g[f"raw{l}_shape"])
         got = r.cpu().reshape(-1)[torch.from_numpy(sample_idx(r.numel(), 100 + l))].numpy()
-        assert np.abs(got - g[f"raw{l}"]).max() <= 1e-3 * max(1.0, np.abs(g[f"raw{l}"]).max())
-
-
-@pytest.mark.skipif(not os.environ.get("ICAF_TEST_NEXT"), reason="fixture generated after the round's GPU budget was spent: run once with "
-                    "ICAF_TEST_NEXT=1, then move the name into GOLDEN (DESIGN.md §6)")
-def test_fp32_forward_matches_reference_golden_rect_validation_shape():
-    """The 544x672 batch shape of the reference's rect validation protocol (DMFF windows (11, 8) / (4, 12) / (8, 3), 17x21 map at P5)."""
-    test_fp32_forward_matches_reference_golden("model_s_kaist_544x672_b1")
+        err["raw"] = max(err["raw"], float(np.abs(got - g[f"raw{l}"]).max()))
+        scale["raw"] = max(scale["raw"], float(np.abs(g[f"raw{l}"]).max()))
+    bound = _fp32_bounds(name, scale)
+    rec = dict(err, golden=name, yaml=str(g["yaml"]), batch=batch, height=h, width=w, box_px_scale=scale["box_px"], bound=bound)
+    print(json.dumps(rec))
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_fp32.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    for k in err:
+        assert err[k] <= bound[k], f"{name}: {k} error {err[k]:.3g} > {bound[k]:.3g}"
 
 
 def test_loops_yaml_argument_equals_attribute():
@@ -72,7 +103,7 @@ def test_loops_yaml_argument_equals_attribute():
     assert m.model[20].crosstransformer[0].loops == 3
     rgb, ir = synth_images(batch, h, w, seed)
     z = m(rgb.to(DEV), ir.to(DEV))[0].cpu().numpy()
-    assert np.abs(z - g["z"]).max() <= 1e-3 * max(1.0, np.abs(g["z"]).max())
+    _assert_abs(z, g["z"], "loops yaml")
 
 
 def test_fp32_forward_matches_oracle_other_shape():
@@ -81,7 +112,7 @@ def test_fp32_forward_matches_oracle_other_shape():
     rgb, ir = synth_images(3, 512, 640, seed=11)
     ref = oracle.OracleModel(cfg, sd).forward(rgb, ir)[0].numpy()
     z = m(rgb.to(DEV), ir.to(DEV))[0].cpu().numpy()
-    assert np.abs(z - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
+    _assert_abs(z, ref, "512x640 batch 3 vs oracle")
 
 
 def test_fused_model_same_output():

@@ -2,7 +2,7 @@
 of every full-size bf16 / fp16 batch against the fp32 CPU oracle, with the tolerance DERIVED from the reference's own 16-bit
 deviation on the same weights and inputs (tools/parity16.py: the oracle evaluated by torch in the same 16-bit type, which is
 what `model.half()` does in detect_twostream.py:40 / test.py:73-75), plus the bf16 / fp16 mAP@50 delta through the same
-ap_per_class on 16 images at 640x640 (north_star: within 0.1).  Every measured number is printed and appended to
+ap_per_class on 16 images at 640x640 of a detector with separated scores (north_star: within 0.1, asserted as stated).  Every measured number is printed and appended to
 gpurun_out/parity_16bit_tests.jsonl; profiles/parity_16bit.json is the committed copy of a full tools/parity16.py run.
 
 Why a multiple of the reference's deviation, and why 1.5: both pipelines keep activations in the 16-bit type between layers
@@ -53,23 +53,15 @@ def test_full_size_16bit_slice_vs_fp32_oracle(name):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_16bit_map50_delta_vs_fp32_oracle(dtype):
-    """mAP@50 (percent) of the 16-bit HIP detections vs the fp32 oracle's, 16 images 640x640, conf 0.001 / IoU 0.5 multi-label NMS
-    as test.py: on random synthetic labels and on pseudo ground truth cut from the oracle's own strongest detections."""
+def test_16bit_map50_within_a_tenth_of_the_fp32_oracle(dtype):
+    """north_star: mAP@50 within +-0.1 (percent) of the reference on identical inputs - asserted as stated, no multiplier.
+    16 images 640x640 through test.py's protocol (conf 0.001, IoU 0.5, the same ap_per_class) on the planted detector of
+    tools/parity16.py: scores separated the way a trained detector's are (background ~0.003, objects 0.3-0.85), mAP@50 ~ 80.
+    The recipe itself is checked first: the REFERENCE evaluated in the same 16-bit type must stay within 0.1 as well
+    (tests/test_oracle_vs_golden.py runs that half on the CPU for a smaller batch)."""
     rec = parity16.measure_map(dtype)
     _record(rec)
-    assert rec["images"] >= 16 and rec["labels_pseudo_gt"] >= 16
-    assert rec["pseudo_gt"]["map50_oracle_fp32"] > 50.0, "pseudo ground truth must give a non-trivial mAP"
-    r = rec["random_labels"]
-    assert abs(r["map50_delta"]) <= 0.1, f"{dtype} random labels: mAP@50 {r['map50_hip16']} vs {r['map50_oracle_fp32']}"
-    # Pseudo ground truth = the fp32 oracle's own top detections among thousands of near-equal random-weight scores: a stress
-    # test of rank stability.  16-bit score noise (5e-3 in bf16, 6e-4 in fp16) reorders true / false positives for ANY 16-bit
-    # implementation — the reference's own .half() / .bfloat16() modes move this mAP@50 by 14 / 17 points (profiles/parity_16bit.json;
-    # the HIP path, which decodes boxes and scores in fp32: 0.13 / 12) — so the bound is the reference's own 16-bit mode on the same
-    # inputs (x FACTOR), never less than 0.1.
-    g = rec["pseudo_gt"]
-    bound = max(0.1, FACTOR * abs(g["map50_delta_reference16"]))
-    assert abs(g["map50_delta"]) <= bound, (f"{dtype} pseudo ground truth: mAP@50 {g['map50_hip16']} vs fp32 {g['map50_oracle_fp32']}; the reference in "
-                                            f"{dtype} gives {g['map50_reference16']} (bound {bound:.3f})")
-    if dtype == "f16":
-        assert abs(g["map50_delta"]) <= 0.5      # measured 0.02 - 0.13: fp16 keeps the ranking almost intact
+    assert rec["images"] >= 16 and rec["objects"] >= 300
+    assert rec["map50_oracle_fp32"] > 50.0
+    assert abs(rec["map50_delta_reference16"]) <= 0.1, f"recipe not separated: the reference in {dtype} moves mAP@50 by {rec['map50_delta_reference16']}"
+    assert abs(rec["map50_delta"]) <= 0.1, f"{dtype}: mAP@50 {rec['map50_hip16']} vs fp32 oracle {rec['map50_oracle_fp32']}"

@@ -213,3 +213,20 @@ def test_sixteen_bit_oracle_deviates_like_the_reference_in_sixteen_bit(tag):
         # and the two 16-bit evaluations are closer to each other than either is to fp32 (same roundings, different summation order)
         x = (o16 - torch.from_numpy(g[f"{tag}_{dn}_z16"])).abs()
         assert float(x[..., :4].mean()) < g[f"{tag}_{dn}_dev"][1] and float(x[..., 4:].mean()) < g[f"{tag}_{dn}_dev"][3]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_planted_detector_recipe_is_separated(dtype):
+    """The weight recipe behind the 16-bit mAP test (tools/parity16.py: planted objects + a fitted objectness read-out) must itself
+    be insensitive to 16-bit arithmetic: the REFERENCE evaluated in bf16 / fp16 (the oracle by torch in that type) keeps mAP@50
+    within 0.1 of its fp32 value, at a non-trivial mAP.  (The GPU test asserts the same bound for the HIP path on 16 images.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity16
+    rec = parity16.measure_map(dtype, B=4, hip=False)
+    assert rec["objects"] >= 80 and rec["detections_oracle"] > 2 * rec["objects"]
+    assert 50.0 < rec["map50_oracle_fp32"] < 95.0
+    for st in rec["fit"][1:]:                              # P4 / P5: a clear gap between planted cells and background
+        assert st["planted_cells_min"] - st["background_max"] > 0.5
+    assert abs(rec["map50_delta_reference16"]) <= 0.1, rec

@@ -14,11 +14,9 @@ BASELINE.md quotes err_ref for the reference's default initialisation (bf16 2.3 
 yolov5s); the synthetic weights of icafusion_amd.synth spread the Detect logits much wider (their purpose: non-degenerate
 detections), which raises both errors alike — hence the yardstick is re-measured rather than quoted.
 
-Also: mAP@50 of the 16-bit HIP detections vs the fp32 oracle's detections through the same ap_per_class, on (a) random
-synthetic labels and (b) pseudo ground truth cut from the oracle's own strongest detections (mAP far from zero, sensitive
-to box shifts and score re-ordering) — next to the same two numbers for the reference evaluated in the 16-bit type.  With
-random weights thousands of candidates have nearly equal scores, so (b) is a stress test of RANK stability: a score change
-of 5e-3 (bf16) reorders true and false positives and moves AP by points, for the reference's own bf16 mode as for ours.
+Also: mAP@50 of the 16-bit HIP detections vs the fp32 oracle's detections through the same ap_per_class on a detector with
+SEPARATED scores (planted objects + a fitted objectness read-out, see planted_detector below), next to the same number for the
+reference evaluated in the 16-bit type: north_star's "mAP@50 within 0.1" is asserted without a yardstick multiplier.
 
     python tools/parity16.py [--out gpurun_out/parity_16bit.json] [--only c2,c4]      # on the GPU box
 
@@ -44,6 +42,9 @@ CONFIGS = {
     "c3_l_bf16_b32_640_shard": ("yolov5l_Transfusion_kaist.yaml", "bf16", 32, 640, 640, 1, (5, 30), 3),
     "c4_s_bf16_b64_512x640_loops3": ("yolov5s_Transfusion_kaist.yaml", "bf16", 64, 512, 640, 3, (0, 63), 4),
     "c5_l_vedai_f16_b16_1280_shard": ("yolov5l_Transfusion_VEDAI.yaml", "f16", 16, 1280, 1280, 1, (7,), 5),
+    # the batch shape real KAIST frames take under test.py's rect protocol (utils/datasets.py:840-849): DMFF windows (11, 8) / (4, 12) /
+    # (8, 3), odd 17 x 21 map at P5
+    "kaist_rect_s_bf16_b16_544x672": ("yolov5s_Transfusion_kaist.yaml", "bf16", 16, 544, 672, 1, (0, 15), 7),
 }
 
 
@@ -127,41 +128,140 @@ def map_metrics(dets, gts, iouv):
     return 100.0 * float(ap[:, 0].mean()), 100.0 * float(ap.mean())
 
 
-def measure_map(dtype, B=16, H=640, W=640, seed=6, yaml_name="yolov5s_Transfusion_FLIR.yaml"):
-    """mAP@50 / mAP@50:95 (percent) of HIP-16-bit detections vs fp32-oracle detections, same labels, same ap_per_class
-    (test.py's protocol: conf 0.001, IoU 0.5, multi-label)."""
-    from icafusion_amd.synth import synth_images, synth_labels
-    from icafusion_amd.utils.general import non_max_suppression
+# ---- mAP@50 on a detection set with SEPARATED scores ---------------------------------------------------------------
+# Random synthetic weights give thousands of near-equal scores per image (and, with i.i.d. noise images, features that barely
+# depend on the image at all): mAP on such a set measures rank noise, not the implementation.  No trained checkpoint exists in
+# the container, so the separation is PLANTED in the weights, the way a trained detector has it:
+#   * "objects": a fixed +-A pattern added to the P4 DMFF position embedding (a learned (1, N, C) parameter of the reference,
+#     models/common.py:773-774) at six token positions - a localised, image-independent cause that travels through the
+#     cross-attention block, the bilinear merge and the whole PANet head;
+#   * an objectness read-out FITTED to it: ridge regression of Detect's objectness row (one anchor per level; the other anchors
+#     are switched off by their bias) on the fp32 oracle's head features, target +1 at the planted cells / -1 elsewhere, times a
+#     gain - background cells end near conf 0.003, planted cells at 0.3-0.85, a gap of ~20x the bf16 noise of the logit;
+#   * box regression rows damped (x 0.25) so that boxes stay near their anchors (the synthetic rows otherwise give 3 x 2 pixel
+#     boxes, for which the 4-pixel grid of a bf16 coordinate near 640 already breaks IoU 0.5 in the REFERENCE's own bf16 mode).
+# Ground truth = the fp32 oracle's detections above conf 0.25 plus 25 % labels that nothing detects (so that AP is not pinned
+# at 100): every implementation that finds the same objects with boxes within IoU 0.5 and keeps them ranked above the
+# background scores the same AP; a lost object costs 1 / (#objects) ~ 0.2 points.
+PLANT_TOKENS = ((3, 4), (3, 11), (8, 8), (12, 3), (12, 12), (6, 14))     # of the 16 x 16 P4 token grid
+PLANT_AMPLITUDE, PLANT_RIDGE, PLANT_GAIN, PLANT_ANCHOR, PLANT_REG_SCALE, PLANT_FIT_IMAGES = 2.0, 1e-3, 8.0, 2, 0.25, 4
+
+
+def planted_detector(cfg, fsd, rgb, ir, seed):
+    """Modify the fused state_dict `fsd` in place (see above); rgb / ir are the evaluation inputs, the first few of them
+    are used for the fit.  Returns the fitted read-out's separation statistics."""
+    from oracle import icaf_oracle as oracle
+    nc = cfg["nc"]
+    no = nc + 5
+    rows = cfg["backbone"] + cfg["head"]
+    det_i = len(rows) - 1
+    det_from = rows[-1][0]
+    p4 = [i for i, r in enumerate(rows) if r[2] == "TransformerFusionBlock"][1]
+    va, ha = rows[p4][3][1], rows[p4][3][2]
+    g = np.random.default_rng([seed, 0x91A47])
+    C = fsd[f"model.{p4}.pos_emb_vis"].shape[2]
+    u = torch.from_numpy(g.choice([-1.0, 1.0], C).astype(np.float32)) * PLANT_AMPLITUDE
+    for k in (f"model.{p4}.pos_emb_vis", f"model.{p4}.pos_emb_ir"):
+        for ty, tx in PLANT_TOKENS:
+            fsd[k][0, ty * ha + tx] += u
+    n = min(PLANT_FIT_IMAGES, rgb.shape[0])
+    _, outs = oracle.OracleModel(cfg, fsd).forward(rgb[:n], ir[:n], keep_layers=True)
+    stats = []
+    for l, f in enumerate(det_from):
+        feat = outs[f].numpy()
+        bn, cc, ny, nx = feat.shape
+        lab = -np.ones((ny, nx), np.int8)
+        yy, xx = np.mgrid[0:ny, 0:nx]
+        for ty, tx in PLANT_TOKENS:
+            cy, cx = (ty + 0.5) * ny / va - 0.5, (tx + 0.5) * nx / ha - 0.5
+            d = np.maximum(np.abs(yy - cy) * va / ny, np.abs(xx - cx) * ha / nx)       # distance in token units
+            lab[d < 1.2] = 0                                                            # transition band: not fitted
+            lab[d < 0.24 + 0.3 * va / ny] = 1
+        y = np.tile(lab[None], (bn, 1, 1)).reshape(-1)
+        a = np.concatenate((feat.transpose(0, 2, 3, 1).reshape(-1, cc), np.ones((y.size, 1), np.float32)), 1).astype(np.float64)
+        sel = y != 0
+        w = np.linalg.solve(a[sel].T @ a[sel] + PLANT_RIDGE * sel.sum() * np.eye(cc + 1), a[sel].T @ y[sel].astype(np.float64))
+        sc = a @ w
+        stats.append({"level": l, "planted_cells_min": float(sc[y == 1].min()), "background_max": float(sc[y == -1].max())})
+        wt, bt = fsd[f"model.{det_i}.m.{l}.weight"], fsd[f"model.{det_i}.m.{l}.bias"]
+        for an in range(3):
+            c = an * no + 4
+            if an == PLANT_ANCHOR:
+                wt[c, :, 0, 0] = torch.from_numpy((PLANT_GAIN * w[:-1]).astype(np.float32))
+                bt[c] = float(PLANT_GAIN * w[-1])
+            else:
+                wt[c] = 0.0
+                bt[c] = -30.0
+            wt[an * no:an * no + 4] *= PLANT_REG_SCALE
+            bt[an * no:an * no + 4] *= PLANT_REG_SCALE
+            bt[an * no + 5:an * no + no] += 2.0
+    return stats
+
+
+def planted_case(yaml_name, B, H, W, seed):
+    """(cfg, fused planted state_dict, rgb, ir, fit statistics) - CPU only."""
+    from icafusion_amd.models.yolo import Model
+    from icafusion_amd.synth import synth_images, synth_state_dict
+    cfg = load_cfg(yaml_name)
+    m = Model(cfg).eval()
+    m.load_state_dict(synth_state_dict(m, seed))
+    m.fuse()
+    fsd = {k: v.clone() for k, v in m.state_dict().items()}
+    rgb, ir = synth_images(B, H, W, seed=seed)
+    stats = planted_detector(cfg, fsd, rgb, ir, seed)
+    return cfg, fsd, rgb, ir, stats
+
+
+def planted_ground_truth(zr, nc):
+    """Labels (cls, x1, y1, x2, y2) per image: the fp32 oracle's detections above conf 0.25 (NMS at the evaluation's IoU 0.5, so that
+    the conf-0.001 detection list contains exactly these boxes) + one undetectable 2-pixel label per four objects."""
+    from oracle import icaf_oracle as oracle
+    strong = oracle.non_max_suppression(zr, 0.25, 0.5, multi_label=nc > 1)
+    ghost = np.array([[0, 1, 1, 3, 3]], np.float32)
+    objects = [np.concatenate((d[:, 5:6], d[:, :4]), 1).astype(np.float32) for d in strong]
+    return objects, [np.concatenate((o, np.tile(ghost, (max(1, len(o) // 4), 1)))) for o in objects]
+
+
+def measure_map(dtype, B=16, H=640, W=640, seed=6, yaml_name="yolov5s_Transfusion_kaist.yaml", hip=True):
+    """mAP@50 / mAP@50:95 (percent; test.py's protocol: conf 0.001, IoU 0.5, multi-label when nc > 1, same ap_per_class) of the
+    fp32 oracle, of the reference evaluated in `dtype` (the oracle by torch in that type) and - hip=True, GPU box - of the HIP
+    path in `dtype`, on the planted detector above.  north_star: |delta mAP@50| <= 0.1."""
     from oracle import icaf_oracle as oracle
     _cpu_threads()
-    cfg, fsd, m = build(yaml_name, dtype, 1, seed)
+    cfg, fsd, rgb, ir, stats = planted_case(yaml_name, B, H, W, seed)
     nc = cfg["nc"]
-    rgb, ir = synth_images(B, H, W, seed=seed)
+    ml = nc > 1
     zr = oracle.OracleModel(cfg, fsd).forward(rgb, ir)[0].numpy()
     z16 = oracle.OracleModel(cfg, fsd, dtype=DT[dtype]).forward(rgb, ir)[0].float().numpy()      # the reference in the same 16-bit type
-    zg = m(rgb.cuda(), ir.cuda())[0].float()
-    dets_g = [d.cpu().numpy() for d in non_max_suppression(zg, 0.001, 0.5, multi_label=True)]
-    dets_r = oracle.non_max_suppression(zr, 0.001, 0.5, multi_label=True)
-    dets_16 = oracle.non_max_suppression(z16, 0.001, 0.5, multi_label=True)
+    objects, gts = planted_ground_truth(zr, nc)
     iouv = np.linspace(0.5, 0.95, 10)
-    lab = synth_labels(B, nc, seed=seed).numpy()
-    gt_rand = [_xyxy(lab[lab[:, 0] == b][:, 1:].copy(), W, H) for b in range(B)]
-    # pseudo ground truth: the fp32 oracle's 8 strongest single-label detections per image (conf 0.25, as detect_twostream.py)
-    strong = oracle.non_max_suppression(zr, 0.25, 0.45)
-    gt_pseudo = [np.concatenate((d[:8, 5:6], d[:8, :4]), 1).astype(np.float32) for d in strong]
-    out = {"dtype": dtype, "yaml": yaml_name, "images": B, "height": H, "width": W, "labels_random": int(sum(len(g) for g in gt_rand)),
-           "labels_pseudo_gt": int(sum(len(g) for g in gt_pseudo)), "detections_hip": int(sum(len(d) for d in dets_g)),
-           "detections_oracle": int(sum(len(d) for d in dets_r))}
-    for tag, gts in (("random_labels", gt_rand), ("pseudo_gt", gt_pseudo)):
+    dets_r = oracle.non_max_suppression(zr, 0.001, 0.5, multi_label=ml)
+    dets_16 = oracle.non_max_suppression(z16, 0.001, 0.5, multi_label=ml)
+    conf = zr[..., 4] * zr[..., 5:].max(-1)
+    b50, b = map_metrics(dets_r, gts, iouv)
+    c50, c = map_metrics(dets_16, gts, iouv)
+    out = {"dtype": dtype, "yaml": yaml_name, "images": B, "height": H, "width": W, "recipe": "planted objects + fitted objectness read-out (tools/parity16.py)",
+           "fit": stats, "objects": int(sum(len(g) for g in objects)), "labels": int(sum(len(g) for g in gts)),
+           "detections_oracle": int(sum(len(d) for d in dets_r)),
+           "rows_conf_above_0.25": int((conf > 0.25).sum()), "rows_conf_0.05_to_0.25": int(((conf > 0.05) & (conf <= 0.25)).sum()),
+           "rows_conf_0.001_to_0.05": int(((conf > 0.001) & (conf <= 0.05)).sum()),
+           "map50_oracle_fp32": round(b50, 4), "map_oracle_fp32": round(b, 4),
+           "map50_reference16": round(c50, 4), "map50_delta_reference16": round(c50 - b50, 4),
+           "map_reference16": round(c, 4), "map_delta_reference16": round(c - b, 4)}
+    if hip:
+        from icafusion_amd.models.yolo import Model
+        from icafusion_amd.utils.general import non_max_suppression
+        m = Model(cfg).eval().fuse()
+        m.load_state_dict(fsd)
+        m = m.to("cuda:0")
+        m.compute_dtype = DT[dtype]
+        zg = m(rgb.cuda(), ir.cuda())[0].float()
+        dets_g = [d.cpu().numpy() for d in non_max_suppression(zg, 0.001, 0.5, multi_label=ml)]
         a50, a = map_metrics(dets_g, gts, iouv)
-        b50, b = map_metrics(dets_r, gts, iouv)
-        c50, c = map_metrics(dets_16, gts, iouv)
-        out[tag] = {"map50_hip16": round(a50, 4), "map50_oracle_fp32": round(b50, 4), "map50_delta": round(a50 - b50, 4),
-                    "map_hip16": round(a, 4), "map_oracle_fp32": round(b, 4), "map_delta": round(a - b, 4),
-                    "map50_reference16": round(c50, 4), "map50_delta_reference16": round(c50 - b50, 4),
-                    "map_reference16": round(c, 4), "map_delta_reference16": round(c - b, 4)}
-    del m
-    torch.cuda.empty_cache()
+        out.update({"detections_hip": int(sum(len(d) for d in dets_g)), "map50_hip16": round(a50, 4), "map50_delta": round(a50 - b50, 4),
+                    "map_hip16": round(a, 4), "map_delta": round(a - b, 4)})
+        del m
+        torch.cuda.empty_cache()
     return out
 
 
