@@ -56,7 +56,52 @@ def parse():
                     "low-occupancy tail of one forward (20x20 layers, DMFF, Detect) overlaps the full-width layers of the next; 1 = one batch at a time")
     ap.add_argument("--fold-upsample", action="store_true", help="head rows Upsample -> Concat -> C3: run the up-sampled half of the 1x1 at low resolution")
     ap.add_argument("--tune-cache", default=None, help="json file: load igemm tile choices if present, save after tuning")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement (latency_ms_b1)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher check: start the ranks, initialise the process group (RCCL with GPUs, gloo "
+                    "without), all-gather one detection block, print {n_gpus, backend} and exit - no model, no timing")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no torchrun environment: start the N ranks ourselves (one process per GPU through
+    torch.distributed.run, rendezvous on 127.0.0.1) and pass rank 0's JSON line through.  The driver's own
+    `python -m torch.distributed.run ... bench.py --gpus N` form sets WORLD_SIZE and never comes here."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print(f"[bench] --gpus {args.gpus} without a torchrun environment: launching {args.gpus} ranks ({' '.join(cmd[1:9])} ...)", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """Rank start-up, rank -> GPU binding, process group and the one collective of the path, without the model."""
+    from icafusion_amd import dist as D
+    import torch.distributed as tdist
+    rank, world, local = D.init_from_env()
+    cuda = torch.cuda.is_available()
+    dev = torch.device("cuda", local) if cuda else torch.device("cpu")
+    if cuda:
+        torch.cuda.set_device(local)
+    B, max_det = 4, 300
+    block, det, count = D.detection_block(B, max_det, dev)
+    det.fill_(float(rank + 1))
+    count.fill_(rank + 1)
+    det_all, count_all = D.gather_detections(det, count, block=block)
+    ok = det_all.shape[0] == world and all(int(count_all[r, 0]) == r + 1 and float(det_all[r, 0, 0, 0]) == r + 1 for r in range(world))
+    if world > 1:
+        tdist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "requested_gpus": args.gpus, "gather_ok": bool(ok),
+                          "backend": tdist.get_backend() if world > 1 else None, "device": str(dev)}))
+    if world > 1:
+        tdist.destroy_process_group()
+    return 0 if ok and world == args.gpus else 1
 
 
 def cpu_baseline(cfg, sd, args, loops):
@@ -106,6 +151,10 @@ def cpu_baseline(cfg, sd, args, loops):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.dry_run:
+        sys.exit(dry_run(args))
     from icafusion_amd import dist as D
     from icafusion_amd import ops
     from icafusion_amd.models.yolo import Model
@@ -114,7 +163,7 @@ def main():
     import torch.distributed as tdist
 
     rank, world, local = D.init_from_env()
-    if world != args.gpus:
+    if world != args.gpus:             # (a launcher's WORLD_SIZE wins; n_gpus in the JSON line is the world size that ran)
         if rank == 0:
             print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -275,8 +324,34 @@ def main():
                 "mfma_frac_of_dense_peak": round(att[1] / (att[0] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4)},
             "kernels": kernels,
             "plan_buffer_MB": round(plan.nbytes / 2 ** 20, 1),
-            "detections_first_image": int(count[0]),
+            "detections_first_image": int(count.reshape(-1)[0]),
         }
+        if world == 1 and not args.no_latency:
+            # batch-1 latency (detect_twostream.py:83-88 runs forward -> sync -> NMS -> sync per frame pair): one pair, one plan, the
+            # hipGraph replay followed by NMS on the same stream, host-synchronised every step; median of 100
+            lp = DetectionPipeline(model, 1, H, W, dev, conf_thres=args.conf, iou_thres=args.iou, world=1, overlap=False, depth=1)
+            r1, i1 = synth_images(1, H, W, seed=7)
+            lp.inputs[0].copy_(r1.to(dev)); lp.inputs[1].copy_(i1.to(dev))
+            lat, lat_f = [], []
+            for k in range(120):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                lp.step()
+                lp.synchronize()
+                if k >= 20:
+                    lat.append(1e3 * (time.perf_counter() - t0))
+            l0, l1 = ops.Event(), ops.Event()
+            lsp = lp.fwd_stream.cuda_stream
+            l0.record(lsp)
+            for _ in range(50):
+                lp.plan.run(lsp)
+            l1.record(lsp)
+            torch.cuda.synchronize()
+            lat.sort()
+            out["latency_ms_b1"] = round(lat[len(lat) // 2], 4)                        # forward + NMS, host clock around one step
+            out["latency_b1"] = {"forward_plus_nms_ms_median": round(lat[len(lat) // 2], 4), "p90_ms": round(lat[int(len(lat) * 0.9)], 4),
+                                 "forward_graph_ms_device": round(l0.elapsed_ms(l1) / 50, 4), "launches_per_forward": len(lp.plan.launches),
+                                 "note": "batch 1, depth 1, hipGraph replay + device NMS on one stream, synchronised per step"}
         # PMC counters cannot be read from inside this process: the committed summaries of tools/gpu_pmc.sh (same command line, one
         # file per workload: profiles/pmc_traffic*.json) supply the dominant kernel's HBM bytes
         import glob

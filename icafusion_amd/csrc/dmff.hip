@@ -472,7 +472,7 @@ static int launch_attn(const void* qkv, void* out, int B, int N, int C, int DK, 
     const int NP = (N + 31) & ~31;
     const size_t lds = (size_t)NP * (DKP * EB + 16) + (size_t)DKP * ((size_t)NP * EB + 16);
     if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "icaf_cross_attention: %zu bytes of LDS needed (N=%d, dk=%d) exceed 160 KiB", lds, N, DK);
-    static bool attr_set[ICAF_MAX_DEVICES] = {};          // per instantiation and per device
+    static std::atomic<bool> attr_set[ICAF_MAX_DEVICES];          // per instantiation and per device
     int dev = 0;
     ICAF_HIP(hipGetDevice(&dev));
     if (lds > 64 * 1024 && dev >= 0 && dev < ICAF_MAX_DEVICES && !attr_set[dev]) {

@@ -647,7 +647,7 @@ template <int DT, int DKP, int NP2, int SLB>
 static int launch_attn_mlp(const DmffP& p, hipStream_t s) {
     const size_t lds = attn_mlp_lds(p.C, p.N, DKP, Elem<DT>::BYTES);
     if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_attn_mlp: %zu bytes of LDS (C=%d, N=%d, dk=%d) exceed 160 KiB", lds, p.C, p.N, p.dk);
-    static bool attr_set[ICAF_MAX_DEVICES] = {};
+    static std::atomic<bool> attr_set[ICAF_MAX_DEVICES];
     int dev = 0;
     ICAF_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= ICAF_MAX_DEVICES) return fail(ICAF_ERR_UNSUPPORTED, "device ordinal %d", dev);
@@ -692,7 +692,7 @@ template <int DT, int SLB>
 static int launch_ln_qkv_t(const DmffP& p, hipStream_t s) {
     const size_t lds = (size_t)TMROWS * (p.C * Elem<DT>::BYTES + 16) + Ring<SLB>::BYTES;
     if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_ln_qkv: C=%d too wide", p.C);
-    static bool attr_set[ICAF_MAX_DEVICES] = {};
+    static std::atomic<bool> attr_set[ICAF_MAX_DEVICES];
     int dev = 0;
     ICAF_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= ICAF_MAX_DEVICES) return fail(ICAF_ERR_UNSUPPORTED, "device ordinal %d", dev);

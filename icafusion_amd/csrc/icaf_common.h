@@ -5,6 +5,7 @@
 #include <string>
 #include <cstdio>
 #include <cstdarg>
+#include <atomic>
 #include "../../include/icaf.h"
 
 namespace icaf {

@@ -496,7 +496,7 @@ static int launch_dma_mode(const ConvP& q, dim3 grid, hipStream_t s) {
     constexpr int ring0 = ring_only > stage_out ? ring_only : stage_out;
     constexpr int ring = CHAIN ? (ring0 + 1023) / 1024 * 1024 + BN * BN * 2 : ring0;      // + the chained layer's weights
     static_assert(ring <= 160 * 1024, "LDS capacity");
-    static bool attr_done = false;                 // one flag per instantiation
+    static std::atomic<bool> attr_done{false};     // one flag per instantiation (one process drives one GPU)
     if (!attr_done) {
         int st = set_lds_attr(igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE, PRE, CHAIN>, ring);
         if (st) return st;

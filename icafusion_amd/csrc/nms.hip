@@ -4,19 +4,21 @@
 // (300) survivors are returned.  The walk therefore reaches at most a few hundred to a few thousand of the (up to 25 200 x nc)
 // candidates, so nothing here sorts more than it walks:
 //   0. hipMemsetAsync          clears the per-image score histograms and candidate counters.
-//   1. nms_keys_kernel         every prediction row in parallel (B x rows / 1024 workgroups — the whole chip, not one
+//   1. nms_keys_kernel         every prediction row in parallel (B x rows / 4096 workgroups — the whole chip, not one
 //                              workgroup per image): obj > conf, conf = obj * cls > conf, class filter; writes ONE 32-bit word
 //                              per candidate slot (order-preserving score bits, 0 = not a candidate), the class of
 //                              single-label rows, a 2178-bin histogram of the score's upper 16 bits per image (LDS
-//                              atomics, flushed once per workgroup) and the candidate count of every 1024-row chunk.
+//                              atomics, flushed once per workgroup) and the candidate count of every 4096-row chunk.
 //   2. nms_walk_kernel         one 1024-thread workgroup per image, rounds of
 //                                select   the highest-score histogram bins that are still unvisited and hold <= 1024 (first
 //                                         round) / 4096 keys — one LDS prefix scan over the histogram;
 //                                gather   those candidates into LDS as unique 64-bit keys (score bits << 32 | ~slot);
-//                                sort     rank sort in LDS (every thread counts the keys greater than its own, broadcast
-//                                         16-byte LDS reads; unique keys -> unique ranks);
-//                                walk     greedy suppression, 64 candidates per step: 16 wavefronts test the step against
-//                                         the kept boxes (<= max_det, in LDS), wave 0 resolves the step internally;
+//                                sort     bitonic network in LDS, descending (unique keys: the order is total; a rank sort — every
+//                                         thread counting the keys above its own — was 5x slower: n^2 64-bit compares);
+//                                walk     greedy suppression, 64 candidates per step: all 16 wavefronts test the step against
+//                                         the kept boxes (<= max_det, in LDS) AND build the step's own 64 x 64 suppression
+//                                         relation (one ballot per candidate); wave 0 then resolves the step with scalar mask
+//                                         arithmetic only — no IoU in the serial part — and the kept lanes write at once;
 //                              until max_det boxes are kept or the candidates (capped at max_nms, by score) are exhausted.
 //                              Rounds visit disjoint, descending score ranges, each sorted by the full key, so the visiting
 //                              order equals a stable descending sort of all candidates — ties fall back to the slot index,
@@ -632,7 +634,7 @@ extern "C" int icaf_nms(const float* pred, int B, long long rows, int nc, float 
     }
     const long long cap = rows * (multi ? nc : 1);
     hipStream_t hs = S(s);
-    static bool attr_set[ICAF_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
+    static std::atomic<bool> attr_set[ICAF_MAX_DEVICES];      // hipFuncSetAttribute is per device
     int dev = 0;
     ICAF_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= ICAF_MAX_DEVICES) return fail(ICAF_ERR_UNSUPPORTED, "icaf_nms: device ordinal %d", dev);

@@ -34,33 +34,44 @@ def shard_range(global_batch, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def pack_detections(det, count):
-    """(B, max_det, 6) fp32 + (B,) int32 -> one (B, max_det*6 + 1) fp32 block (count stored exactly as a float)."""
-    B = det.shape[0]
-    return torch.cat((det.reshape(B, -1), count.to(torch.float32).reshape(B, 1)), 1).contiguous()
+def detection_block(B, max_det, device):
+    """ONE allocation holding a rank's NMS output: [B][max_det][6] fp32 detections followed by [B] int32 counts (stored in the
+    same fp32 storage, bit for bit).  The NMS kernels write straight into the two views, and the block is what travels through the
+    collective: no packing kernel, no allocation per step.  Returns (block, det view, count view)."""
+    n = B * max_det * 6
+    block = torch.zeros((n + B,), dtype=torch.float32, device=device)
+    return block, block[:n].view(B, max_det, 6), block[n:].view(torch.int32)
 
 
-def unpack_detections(block, max_det):
-    B = block.shape[0]
-    det = block[:, :max_det * 6].reshape(B, max_det, 6)
-    count = block[:, max_det * 6].round().to(torch.int32)
-    return det, count
+def split_block(flat, world, B, max_det):
+    """Views into `world` concatenated detection blocks: det (world, B, max_det, 6) fp32, count (world, B) int32 - rank-major,
+    i.e. global batch order for contiguous shards (flatten_gathered gives the (world * B, ...) tensors, allocating)."""
+    n = B * max_det * 6
+    blocks = flat.view(world, n + B)
+    return blocks[:, :n].view(world, B, max_det, 6), blocks[:, n:].view(torch.int32)
 
 
-def gather_detections(det, count, out=None, force_collective=False):
-    """All-gather every rank's detections (equal B_local on all ranks).  Returns (det_all, count_all) on every rank,
-    ordered by rank, i.e. in global batch order for a contiguous shard.  With one rank nothing needs exchanging and the
-    inputs are returned — unless force_collective is set, which sends the block through the collective anyway (a
-    1-GPU box can then exercise the RCCL call, its stream ordering and the gathered buffer: tests/test_gpu_model.py)."""
-    if not (dist.is_available() and dist.is_initialized()):
-        if force_collective:
-            raise RuntimeError("gather_detections(force_collective=True) needs an initialised process group")
-        return det, count
-    if dist.get_world_size() == 1 and not force_collective:
-        return det, count
+def flatten_gathered(det, count):
+    return det.reshape(-1, det.shape[-2], 6), count.reshape(-1)
+
+
+def gather_detections(det, count, out=None, force_collective=False, block=None):
+    """All-gather every rank's detections (equal B_local on all ranks): ONE `all_gather_into_tensor` of the rank's detection block.
+    Returns (det_all (world, B_local, max_det, 6), count_all (world, B_local)) on every rank - views of `out`, rank-major.
+    `block` = the rank's detection_block (det / count are its views: nothing is packed, nothing allocated when `out` is given);
+    without it the two tensors are packed first (tests, ad-hoc callers).  With one rank nothing needs exchanging and the inputs
+    come back as (1, B, ...) views - unless force_collective is set, which sends the block through the collective anyway (a 1-GPU
+    box can then exercise the RCCL call, its stream ordering and the gathered buffer: tests/test_gpu_pipeline.py)."""
+    B, max_det = det.shape[0], det.shape[1]
+    active = dist.is_available() and dist.is_initialized()
+    if not active and force_collective:
+        raise RuntimeError("gather_detections(force_collective=True) needs an initialised process group")
+    if not active or (dist.get_world_size() == 1 and not force_collective):
+        return det.view(1, B, max_det, 6), count.view(1, B)
     world = dist.get_world_size()
-    block = pack_detections(det, count)
+    if block is None:
+        block = torch.cat((det.reshape(-1), count.to(torch.int32).view(torch.float32).reshape(-1)))
     if out is None:
-        out = torch.empty((world * block.shape[0], block.shape[1]), dtype=block.dtype, device=block.device)
-    dist.all_gather_into_tensor(out, block)
-    return unpack_detections(out, det.shape[1])
+        out = torch.empty((world * block.numel(),), dtype=torch.float32, device=block.device)
+    dist.all_gather_into_tensor(out.view(-1), block)
+    return split_block(out.view(-1), world, B, max_det)

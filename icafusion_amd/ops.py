@@ -557,8 +557,8 @@ class NmsRunner:
         sz = C.c_size_t(0)
         check(lib().icaf_nms_workspace_bytes(B, rows, nc, int(self.multi_label), C.byref(sz)), "nms_workspace")
         self.ws = torch.empty((max(sz.value, 16),), dtype=torch.uint8, device=device)
-        self.det = torch.zeros((B, max_det, 6), dtype=torch.float32, device=device)
-        self.count = torch.zeros((B,), dtype=torch.int32, device=device)
+        from .dist import detection_block            # det + count in ONE allocation: the block the all-gather sends as it is
+        self.block, self.det, self.count = detection_block(B, max_det, device)
         self.keep = torch.zeros((B, max_det), dtype=torch.int32, device=device) if want_keep else None
 
     def launch(self, pred, conf_thres, iou_thres, agnostic=False, classes=None, max_nms=30000, max_wh=4096.0,

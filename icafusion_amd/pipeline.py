@@ -50,21 +50,36 @@ class DetectionPipeline:
         rows, no = self.z.shape[1], self.z.shape[2]
         ml = bool(multi_label) and no - 5 > 1
         self.runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False) for _ in range(nslots)]
-        self.gathered = [torch.empty((world * batch, max_det * 6 + 1), dtype=torch.float32, device=self.device)
+        self.gathered = [torch.empty((world * (batch * max_det * 6 + batch),), dtype=torch.float32, device=self.device)
                          for _ in range(nslots)] if self.gather else None
         if self.depth > 1:
             self.nms_stream = torch.cuda.Stream(device=self.device)
             self.deep_runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False) for _ in range(self.depth)]
             self.nms_done_deep = [torch.cuda.Event() for _ in range(self.depth)]
-            self.deep_gathered = [torch.empty((world * batch, max_det * 6 + 1), dtype=torch.float32, device=self.device)
+            self.deep_gathered = [torch.empty((world * (batch * max_det * 6 + batch),), dtype=torch.float32, device=self.device)
                                   for _ in range(self.depth)] if self.gather else None
         self.n = 0
         self.last = None
 
     @property
     def inputs(self):
-        """Static RGB / IR staging tensors (NCHW fp32) of the NEXT step's plan; fill them, then call step()."""
+        """Static RGB / IR staging tensors (NCHW fp32) of the NEXT step's plan.  With depth > 1 every in-flight slot has its OWN
+        staging tensors: they must be refilled before EVERY step (filling them once and stepping repeatedly would run every
+        other batch on another slot's stale inputs), and the caller's copy must be ordered against the slot's forward stream —
+        `submit()` does both."""
         return self.plans[self.n % self.depth].inputs
+
+    def submit(self, rgb, ir):
+        """Copy one batch into the next step's staging tensors ON that slot's forward stream (after the slot's previous forward —
+        same stream — so a forward still reading them is never overwritten), then enqueue the step."""
+        d = self.n % self.depth
+        fs = self.fwd_streams[d]
+        ins = self.plans[d].inputs
+        fs.wait_stream(torch.cuda.current_stream(self.device))     # rgb / ir may have been produced on the caller's stream
+        with torch.cuda.stream(fs):
+            ins[0].copy_(rgb, non_blocking=True)
+            ins[1].copy_(ir, non_blocking=True)
+        return self.step()
 
     def step(self):
         """Enqueue one batch: forward replay, then NMS (+ gather) on the second stream.  Returns (det, count[, all])
@@ -85,7 +100,7 @@ class DetectionPipeline:
         out = (det, count)
         if self.gather:
             with torch.cuda.stream(ns):
-                out = D.gather_detections(det, count, out=self.gathered[i], force_collective=True)
+                out = D.gather_detections(det, count, out=self.gathered[i], force_collective=True, block=self.runners[i].block)
         if self.overlap:
             self.nms_done[i].record(ns)
         self.n += 1
@@ -106,7 +121,7 @@ class DetectionPipeline:
         out = (det, count)
         if self.gather:
             with torch.cuda.stream(ns):
-                out = D.gather_detections(det, count, out=self.deep_gathered[d], force_collective=True)
+                out = D.gather_detections(det, count, out=self.deep_gathered[d], force_collective=True, block=self.deep_runners[d].block)
         self.nms_done_deep[d].record(ns)
         self.n += 1
         self.last = out
@@ -119,10 +134,7 @@ class DetectionPipeline:
 
     def __call__(self, rgb, ir):
         """Convenience: copy one batch in, run it, wait, return list of (n, 6) detections per image."""
-        ins = self.inputs                       # the staging tensors of the plan the next step replays
-        ins[0].copy_(rgb)
-        ins[1].copy_(ir)
-        torch.cuda.current_stream(self.device).synchronize()
-        det, count = self.step()[:2]
+        det, count = self.submit(rgb, ir)[:2]
         self.synchronize()
+        det, count = det.reshape(-1, det.shape[-2], 6), count.reshape(-1)
         return [det[k, :n].clone() for k, n in enumerate(count.tolist())]

@@ -89,7 +89,9 @@ def test(data, weights=None, batch_size=32, imgsz=640, conf_thres=0.001, iou_thr
     dev = next(model.parameters()).device
     if dataloader is None:
         gs = int(max(float(model.stride.max()), 32))                      # grid size = max stride (test.py:68)
-        dataloader = create_dataloader_rgb_ir(data["val_rgb"], data["val_ir"], imgsz, batch_size, gs, None, pad=0.5, rect=True)[0]
+        # the reference passes `opt` (test.py:100), whose single_cls makes the dataset zero the label classes (utils/datasets.py:465-466)
+        dataloader = create_dataloader_rgb_ir(data["val_rgb"], data["val_ir"], imgsz, batch_size, gs, argparse.Namespace(single_cls=single_cls),
+                                              pad=0.5, rect=True)[0]
     writer = None
     if save_txt or save_json:                                           # result files of the reference (utils/results.py)
         listing = label_listing(os.path.dirname(dataloader.dataset.label_files[0])) if save_txt else None

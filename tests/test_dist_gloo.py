@@ -26,7 +26,14 @@ def _worker(rank, world, port, q):
     det_all = torch.rand((gb, max_det, 6), generator=g)
     cnt_all = torch.tensor([0, 5, 2, 3, 1, 4], dtype=torch.int32)
     det, cnt = D.gather_detections(det_all[a:b].clone(), cnt_all[a:b].clone())
-    ok = torch.equal(det, det_all) and torch.equal(cnt, cnt_all)
+    assert det.shape == (world, gb // world, max_det, 6) and cnt.shape == (world, gb // world) and cnt.dtype == torch.int32
+    ok = all(torch.equal(x, y) for x, y in zip(D.flatten_gathered(det, cnt), (det_all, cnt_all)))
+    # the serving path: NMS output lives in ONE pre-allocated block, which is what the collective sends (no cat, no cast)
+    block, d, c = D.detection_block(b - a, max_det, "cpu")
+    d.copy_(det_all[a:b]); c.copy_(cnt_all[a:b])
+    out = torch.empty((world * block.numel(),))
+    det2, cnt2 = D.gather_detections(d, c, out=out, block=block)
+    ok = ok and det2.data_ptr() == out.data_ptr() and all(torch.equal(x, y) for x, y in zip(D.flatten_gathered(det2, cnt2), (det_all, cnt_all)))
     q.put((rank, ok, (a, b)))
     torch.distributed.destroy_process_group()
 
@@ -45,3 +52,18 @@ def test_shard_and_gather_world2():
     for p in procs:
         p.join(60)
     assert res == [(0, True, (0, 3)), (1, True, (3, 6))]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must start two ranks itself (it silently ran one and reported
+    n_gpus 1).  --dry-run stops after the process group + one detection-block all-gather (gloo here, RCCL on a GPU node)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["requested_gpus"] == 2 and rec["gather_ok"] and rec["backend"] == "gloo"

@@ -74,12 +74,7 @@ def test_pipeline_with_several_batches_in_flight(depth):
     batches = [synth_images(B, H, W, seed=60 + k) for k in range(6)]
     outs = []
     for rgb, ir in batches:
-        ins = pipe.inputs                                                         # staging tensors of the NEXT step's plan
-        ins[0].copy_(rgb.to(DEV)); ins[1].copy_(ir.to(DEV))
-        torch.cuda.current_stream().synchronize()
-        outs.append(pipe.step()[:2])
-        if len(outs) > depth:                                                     # the slot about to be reused next: consume it first
-            pass
+        outs.append(pipe.submit(rgb.to(DEV), ir.to(DEV))[:2])                     # copies on the slot's forward stream, no host sync
     pipe.synchronize()
     m.static_outputs = False
     ref = build("yolov5s_Transfusion_FLIR.yaml", torch.bfloat16)                  # an independent model instance, one batch at a time
@@ -118,8 +113,9 @@ for k in range(4):
     pipe.synchronize()
     det_all, count_all = outs[-1]
     det, count = runners[k % len(runners)].det, runners[k % len(runners)].count
-    assert det_all.shape == (B, 300, 6) and count_all.dtype == torch.int32
-    assert torch.equal(det_all, det) and torch.equal(count_all, count), "all-gather of one rank must return that rank's block"
+    assert det_all.shape == (1, B, 300, 6) and count_all.shape == (1, B) and count_all.dtype == torch.int32
+    assert torch.equal(det_all[0], det) and torch.equal(count_all[0], count), "all-gather of one rank must return that rank's block"
+    assert det.data_ptr() == runners[k % len(runners)].block.data_ptr()     # NMS wrote into the block that travelled: no packing step
     assert int(count.sum()) > 0
     assert det_all.data_ptr() == gathered[k % len(gathered)].data_ptr()     # the collective wrote the pipeline's gathered buffer
 dist.barrier(); dist.destroy_process_group()

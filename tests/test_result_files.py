@@ -272,3 +272,70 @@ def test_detect_twostream_loop_on_cpu_with_the_oracle_behind_it(tmp_path, monkey
         assert set(rows[:, 0].astype(int)) <= {0, 1, 2}
     assert dt.detect(dt.parse_opt(args)) == tmp_path / "runs" / "exp2"                  # the run directory is numbered, not overwritten
     assert dt.detect(dt.parse_opt(args + ["--exist-ok", "--nosave"])) == tmp_path / "runs" / "exp"
+
+
+def test_single_cls_reaches_the_dataset(tmp_path, monkeypatch):
+    """`test(..., single_cls=True)` on a multi-class label set: the reference hands `opt` to the dataloader, whose dataset zeroes the label
+    classes (utils/datasets.py:465-466, test.py:100) while the loop zeroes the detections' (test.py:141-142) - with the flag stopping at
+    the loop, labels 1..n never match class-0 detections and P / R / mAP are silently wrong."""
+    import sys
+    import torch
+    import yaml
+    sys.path.insert(0, HERE)
+    from test_frontends import make_dataset
+    from helpers import REPO
+    from icafusion_amd.models.yolo import Model
+    from icafusion_amd.synth import synth_state_dict
+    from icafusion_amd.utils.general import scale_coords
+    from icafusion_amd.utils.metrics import match_predictions
+    from oracle import icaf_oracle as oracle
+    val = _root_test_module()
+    rgb_dir, ir_dir = make_dataset(str(tmp_path / "set"), n=2, size=(120, 128), nc=3, seed=8)
+    cfg = yaml.safe_load(open(os.path.join(REPO, "models", "transformer", "yolov5s_Transfusion_kaist.yaml")))       # nc = 1 head
+    om = oracle.OracleModel(cfg, synth_state_dict(Model(cfg), seed=0))
+    seen = {}
+    real = val.create_dataloader_rgb_ir
+
+    def spy(*a, **kw):
+        loader, ds = real(*a, **kw)
+        seen["opt"] = a[5]
+        seen["classes"] = sorted({float(c) for lab in ds.labels for c in lab[:, 0]})
+        return loader, ds
+
+    class FakeModel:
+        stride = torch.tensor([8.0, 16.0, 32.0])
+
+        def parameters(self):
+            yield torch.zeros(1)
+
+        def forward_u8(self, img6):
+            f = img6.float() / 255.0
+            return (om.forward(f[:, :3].contiguous(), f[:, 3:].contiguous())[0],)
+
+    def fake_nms(out, conf_thres, iou_thres, multi_label=False, agnostic=False, **kw):
+        assert agnostic
+        dets = oracle.non_max_suppression(out.numpy(), conf_thres, iou_thres, multi_label=multi_label, agnostic=agnostic)
+        det = torch.zeros((len(dets), 300, 6))
+        for i, d in enumerate(dets):
+            det[i, :len(d)] = torch.from_numpy(d)
+        return det, torch.tensor([len(d) for d in dets], dtype=torch.int32), None
+
+    def fake_match(det, count, labels, label_off, iouv, scale=None, predn=None, stream_ptr=None):
+        assert float(labels[:, 0].abs().max()) == 0.0                  # every label arrives as class 0
+        correct = torch.zeros((det.shape[0], 300, iouv.numel()), dtype=torch.uint8)
+        for b in range(det.shape[0]):
+            n = int(count[b])
+            d = det[b, :n].clone()
+            gain, px, py, w0, h0 = scale[b].tolist()
+            scale_coords(None, d[:, :4], (h0, w0), ((gain, gain), (px, py)))
+            lab = labels[int(label_off[b]):int(label_off[b + 1])]
+            correct[b, :n] = torch.from_numpy(match_predictions(d.numpy(), lab.numpy(), iouv.numpy()).astype(np.uint8))
+        return correct
+
+    monkeypatch.setattr(val, "create_dataloader_rgb_ir", spy)
+    monkeypatch.setattr(val, "nms_device", fake_nms)
+    monkeypatch.setattr(val.ops, "match_predictions", fake_match)
+    data = {"val_rgb": rgb_dir, "val_ir": ir_dir, "nc": 3, "names": ["person", "car", "bicycle"]}
+    (mp, mr, map50, map_, *_), maps, _ = val.test(data, batch_size=2, imgsz=320, conf_thres=0.3, single_cls=True, model=FakeModel())
+    assert seen["opt"].single_cls is True and seen["classes"] == [0.0]
+    assert maps.shape == (1,)
