@@ -18,7 +18,9 @@
 // 32x32x16 with the weights as the A operand so that a lane owns 4 consecutive channels of ONE token row — LayerNorm
 // statistics, bias, GELU, the coefficient mixes and the residual are per-lane register work.
 // Rounding points are those of the unfused launches (activations rounded to the storage type between layers, fp32 accumulate).
-// fp32 tokens do not fit this LDS plan; the fp32 parity build keeps the per-layer launches (dmff.hip + igemm.hip).
+// An fp32 instantiation (v_mfma_f32_32x32x2_f32, erff GELU, fp32 tiles) exists for C <= 128 — where the LDS plan still fits — so
+// that the SAME template the 16-bit bench path runs is checked against the reference's fp32 goldens at 1e-3
+// (tests/test_gpu_dmff_fused.py); the fp32 model path uses the per-layer launches unless CrossTransformerBlock.fuse_fp32 is set.
 #include "icaf_common.h"
 #include "conv_common.h"
 
@@ -118,14 +120,21 @@ template <int DT, int SLB> struct WS {
     }
 };
 
-template <int DT> __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
-    u32x2 v;
-    if constexpr (DT == ICAF_BF16) { v[0] = pack2_bf16(a, b); v[1] = pack2_bf16(c, d); }
+// Four consecutive channels of one token row (what a lane's accumulator quad holds) in the storage type: 8 bytes for the 16-bit
+// types, 16 bytes for fp32.
+template <int DT> struct Quad { using type = u32x2; };
+template <> struct Quad<ICAF_F32> { using type = u32x4; };
+template <int DT> __device__ __forceinline__ typename Quad<DT>::type pack4(float a, float b, float c, float d) {
+    typename Quad<DT>::type v;
+    if constexpr (DT == ICAF_F32) { v[0] = __float_as_uint(a); v[1] = __float_as_uint(b); v[2] = __float_as_uint(c); v[3] = __float_as_uint(d); }
+    else if constexpr (DT == ICAF_BF16) { v[0] = pack2_bf16(a, b); v[1] = pack2_bf16(c, d); }
     else { v[0] = pack2_f16(a, b); v[1] = pack2_f16(c, d); }
     return v;
 }
-template <int DT> __device__ __forceinline__ void unpack4(const u32x2& v, float* f) {
-    if constexpr (DT == ICAF_BF16) {
+template <int DT> __device__ __forceinline__ void unpack4(const typename Quad<DT>::type& v, float* f) {
+    if constexpr (DT == ICAF_F32) {
+        f[0] = __uint_as_float(v[0]); f[1] = __uint_as_float(v[1]); f[2] = __uint_as_float(v[2]); f[3] = __uint_as_float(v[3]);
+    } else if constexpr (DT == ICAF_BF16) {
         f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xffff0000u);
         f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xffff0000u);
     } else {
@@ -227,8 +236,8 @@ __global__ __launch_bounds__(FT) void dmff_ln_qkv_kernel(const DmffP p) {
                     const int n = n0 + wn * 64 + t * 32 + 8 * q + 4 * hi;
                     if (n < nout) {
                         const f32x4 b = *(const f32x4*)(bias + n);
-                        *(u32x2*)(out + row * nout + n) = pack4<DT>(acc[t][4 * q] + b[0], acc[t][4 * q + 1] + b[1], acc[t][4 * q + 2] + b[2],
-                                                                    acc[t][4 * q + 3] + b[3]);
+                        *(typename Quad<DT>::type*)(out + row * nout + n) = pack4<DT>(acc[t][4 * q] + b[0], acc[t][4 * q + 1] + b[1], acc[t][4 * q + 2] + b[2],
+                                                                                      acc[t][4 * q + 3] + b[3]);
                     }
                 }
         }
@@ -238,22 +247,38 @@ __global__ __launch_bounds__(FT) void dmff_ln_qkv_kernel(const DmffP p) {
 // ---------------------------------------------------------------------------------------------------------------
 // attention + out-projection + LayerNorm + MLP.  grid = (ceil(N / 64), B, 2 directions)
 // ---------------------------------------------------------------------------------------------------------------
+// (fp32: identity key order and P taken register-for-register, as cross_attn_kernel's fp32 build — dmff.hip)
 template <int DT> __device__ __forceinline__ int vt_phys16(int key) {
-    const int k16 = key & 15;
-    return (key & ~15) + (((k16 >> 2) & 1) << 3) + (k16 & 3) + ((k16 >> 3) << 2);
+    if constexpr (DT == ICAF_F32) return key;
+    else {
+        const int k16 = key & 15;
+        return (key & ~15) + (((k16 >> 2) & 1) << 3) + (k16 & 3) + ((k16 >> 3) << 2);
+    }
 }
 template <int DT> __device__ __forceinline__ u32x4 pack_p16(const f32x16& s, int st) {
     u32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        if constexpr (DT == ICAF_BF16) v[e] = pack2_bf16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
+        if constexpr (DT == ICAF_F32) v[e] = __float_as_uint(s[4 * st + e]);
+        else if constexpr (DT == ICAF_BF16) v[e] = pack2_bf16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
         else v[e] = pack2_f16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
     }
     return v;
 }
+// one 16-byte vector of a V row (channels v * VEC ...) -> VEC rows of V^T at (permuted) key column pk
+template <int DT> __device__ __forceinline__ void scatter_vt(unsigned char* Vt, int VS, int v, int pk, const u32x4& vvv) {
+    if constexpr (DT == ICAF_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(unsigned int*)(Vt + (size_t)(v * 4 + j) * VS + pk * 4) = vvv[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            *(unsigned short*)(Vt + (size_t)(v * 8 + j) * VS + pk * 2) = (unsigned short)((vvv[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+    }
+}
 
 template <int DT, int DKP, int NP2, int SLB>
-__global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32) ? 2 : 1) void dmff_attn_mlp_kernel(const DmffP p) {      // C <= 128: two workgroups per CU (<= 256 registers)
+__global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32 && DT != ICAF_F32) ? 2 : 1) void dmff_attn_mlp_kernel(const DmffP p) {      // C <= 128: two workgroups per CU (<= 256 registers)
     using E = Elem<DT>;
     using T = typename E::type;
     using S = WS<DT, SLB>;
@@ -330,10 +355,7 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32) ? 2 : 1) void dmff_attn
                     const int idx = tid + i * FT, key = idx / NVK, v = idx - key * NVK;
                     if (idx < items) {
                         *(u32x4*)(Ks + (size_t)key * KS + v * 16) = kreg[hh][i];
-                        const int pk = vt_phys16<DT>(key);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            *(unsigned short*)(Vt + (size_t)(v * 8 + j) * VS + pk * 2) = (unsigned short)((vreg[hh][i][j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+                        scatter_vt<DT>(Vt, VS, v, vt_phys16<DT>(key), vreg[hh][i]);
                     }
                 }
             }
@@ -355,10 +377,7 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32) ? 2 : 1) void dmff_attn
                             vvv = *(const u32x4*)(base + key * row3 + 2 * C + v * VEC);
                         }
                         *(u32x4*)(Ks + (size_t)key * KS + v * 16) = kvv;
-                        const int pk = vt_phys16<DT>(key);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            *(unsigned short*)(Vt + (size_t)(v * 8 + j) * VS + pk * 2) = (unsigned short)((vvv[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+                        scatter_vt<DT>(Vt, VS, v, vt_phys16<DT>(key), vvv);
                     }
                 }
             }
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32) ? 2 : 1) void dmff_attn
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int d0 = td * 32 + 8 * g4 + 4 * hi;
                         if (d0 < DK)
-                            *(u32x2*)(orow + d0 * EB) = pack4<DT>(o[td][4 * g4] * inv, o[td][4 * g4 + 1] * inv, o[td][4 * g4 + 2] * inv,
+                            *(typename Quad<DT>::type*)(orow + d0 * EB) = pack4<DT>(o[td][4 * g4] * inv, o[td][4 * g4 + 1] * inv, o[td][4 * g4 + 2] * inv,
                                                                    o[td][4 * g4 + 3] * inv);
                     }
             }
@@ -471,7 +490,7 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32) ? 2 : 1) void dmff_attn
     T* yrow = (T*)p.y + dir * p.y_gs + ((long long)b * N + (rok ? tok : 0)) * p.ldy;
     u32x4 r0v[S::NV], r1v[S::NV];
     S::start(r0v, r1v, Wo, p.Kp, ring);
-    u32x2 xatt[NP2][2][4];
+    typename Quad<DT>::type xatt[NP2][2][4];
     {
         const float* bias = p.bo + dir * p.bo_gs;
         const float ca = p.c_acc_a[dir], cr = p.c_res_a[dir];
@@ -490,11 +509,11 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32) ? 2 : 1) void dmff_attn
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int n = i * 128 + wn * 64 + t * 32 + 8 * q + 4 * hi;
-                        u32x2 pk = {0u, 0u};
+                        typename Quad<DT>::type pk = pack4<DT>(0.f, 0.f, 0.f, 0.f);
                         if (n < C) {
                             const f32x4 bv = *(const f32x4*)(bias + n);
                             float rv[4];
-                            unpack4<DT>(*(const u32x2*)(xres + n), rv);
+                            unpack4<DT>(*(const typename Quad<DT>::type*)(xres + n), rv);
                             float v[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (acc[t][4 * q + j] + bv[j]) * ca);
@@ -558,10 +577,10 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32) ? 2 : 1) void dmff_attn
                         unpack4<DT>(xatt[i][t][q], v);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean) * rstd * gv[j] + bv[j];
-                        *(u32x2*)(T0 + (size_t)lrow * SA + n * EB) = pack4<DT>(o[0], o[1], o[2], o[3]);
+                        *(typename Quad<DT>::type*)(T0 + (size_t)lrow * SA + n * EB) = pack4<DT>(o[0], o[1], o[2], o[3]);
                         // x_att is needed once more, as the residual of the MLP mix: park it in this workgroup's own rows of the
                         // output tensor (read back by the same lane at the end) instead of holding 16 * NP2 registers through the MLP
-                        if (rok) *(u32x2*)(yrow + n) = xatt[i][t][q];
+                        if (rok) *(typename Quad<DT>::type*)(yrow + n) = xatt[i][t][q];
                     }
                 }
         lds_barrier();
@@ -590,8 +609,9 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32) ? 2 : 1) void dmff_attn
                 for (int q = 0; q < 4; ++q) {
                     const int nl = wn * 64 + t * 32 + 8 * q + 4 * hi;          // column inside the chunk
                     const f32x4 bv = *(const f32x4*)(b1 + hc + nl);
-                    *(u32x2*)(Hb + (size_t)lrow * SH + nl * EB) = pack4<DT>(gelu_fast_f(acc[t][4 * q] + bv[0]), gelu_fast_f(acc[t][4 * q + 1] + bv[1]),
-                                                                            gelu_fast_f(acc[t][4 * q + 2] + bv[2]), gelu_fast_f(acc[t][4 * q + 3] + bv[3]));
+                    *(typename Quad<DT>::type*)(Hb + (size_t)lrow * SH + nl * EB) =      // (fp32: erff; 16-bit: the 1.5e-7 polynomial — apply_act)
+                        pack4<DT>(apply_act<ICAF_ACT_GELU, DT>(acc[t][4 * q] + bv[0]), apply_act<ICAF_ACT_GELU, DT>(acc[t][4 * q + 1] + bv[1]),
+                                  apply_act<ICAF_ACT_GELU, DT>(acc[t][4 * q + 2] + bv[2]), apply_act<ICAF_ACT_GELU, DT>(acc[t][4 * q + 3] + bv[3]));
                 }
             lds_barrier();
 #pragma unroll
@@ -620,11 +640,11 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32) ? 2 : 1) void dmff_attn
                     if (n < C) {
                         const f32x4 bv = *(const f32x4*)(b2 + n);
                         float rv[4];
-                        unpack4<DT>(*(const u32x2*)(yrow + n), rv);              // x_att, parked here after the LayerNorm
+                        unpack4<DT>(*(const typename Quad<DT>::type*)(yrow + n), rv);   // x_att, parked here after the LayerNorm
                         float v[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (acc2[i][t][4 * q + j] + bv[j]) * ca);
-                        *(u32x2*)(yrow + n) = pack4<DT>(v[0], v[1], v[2], v[3]);
+                        *(typename Quad<DT>::type*)(yrow + n) = pack4<DT>(v[0], v[1], v[2], v[3]);
                     }
                 }
     }
@@ -633,12 +653,12 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32) ? 2 : 1) void dmff_attn
 
 static inline int slice_bytes(int C) { return C % 128 == 0 ? 128 : 64; }     // every pass needs an even number of slices
 
-static size_t attn_mlp_lds(int C, int N, int dkp, int eb) {
+static size_t attn_mlp_lds(int C, int N, int dkp, int eb) {      // (eb = 4: always 128-byte slices)
     const int NP = (N + 31) & ~31;
     const size_t tile = (size_t)TMROWS * (C * eb + 16), hb = (size_t)TMROWS * (128 * eb + 16);
     const size_t ks = dkp * eb == 32 ? 32 : dkp * eb + 16;
     const size_t kv2 = 2 * ((size_t)NP * ks + (size_t)dkp * (NP * eb + 16));
-    const size_t ring = slice_bytes(C) == 128 ? Ring<128>::BYTES : Ring<64>::BYTES;
+    const size_t ring = (eb == 4 || slice_bytes(C) == 128) ? Ring<128>::BYTES : Ring<64>::BYTES;
     const size_t chain = hb + ring + 2 * 64 * sizeof(float);
     return tile + (kv2 > chain ? kv2 : chain);
 }
@@ -677,6 +697,13 @@ static int dispatch_np2(const DmffP& p, hipStream_t s) {
     return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_attn_mlp: C=%d > 512 (the [64 x C] token tile and K / V^T of two heads exceed the LDS)", p.C);
 }
 
+// fp32 (parity build of the same template): C <= 128, head dims 8 .. 32 — what fits the LDS plan with 4-byte tiles
+static int dispatch_attn_mlp_f32(const DmffP& p, hipStream_t s) {
+    if (p.C > 128 || p.dk > 32) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_attn_mlp: the fp32 instantiation covers C <= 128, head dim <= 32 (C=%d, dk=%d)", p.C, p.dk);
+    if (p.dk <= 16) return launch_attn_mlp<ICAF_F32, 16, 1, 128>(p, s);
+    return launch_attn_mlp<ICAF_F32, 32, 1, 128>(p, s);
+}
+
 template <int DT>
 static int dispatch_attn_mlp(const DmffP& p, hipStream_t s) {
     if (p.dk <= 16) return dispatch_np2<DT, 16>(p, s);
@@ -708,16 +735,18 @@ static int launch_ln_qkv_t(const DmffP& p, hipStream_t s) {
 }
 template <int DT>
 static int launch_ln_qkv(const DmffP& p, hipStream_t s) {
-    return slice_bytes(p.C) == 128 ? launch_ln_qkv_t<DT, 128>(p, s) : launch_ln_qkv_t<DT, 64>(p, s);
+    if constexpr (DT == ICAF_F32) return launch_ln_qkv_t<DT, 128>(p, s);                  // (32 K elements per slice: C % 64 == 0 gives an even count)
+    else return slice_bytes(p.C) == 128 ? launch_ln_qkv_t<DT, 128>(p, s) : launch_ln_qkv_t<DT, 64>(p, s);
 }
 
 static int fill(const icaf_dmff_args* a, DmffP& p, const char* who) {
     if (!a || !a->x || !a->qkv || !a->wqkv || !a->bqkv) return fail(ICAF_ERR_ARG, "%s: null pointer", who);
-    if (a->dtype != ICAF_BF16 && a->dtype != ICAF_F16) return fail(ICAF_ERR_UNSUPPORTED, "%s: 16-bit token types only (the fp32 build uses the per-layer launches)", who);
+    if (a->dtype != ICAF_BF16 && a->dtype != ICAF_F16 && a->dtype != ICAF_F32) return fail(ICAF_ERR_ARG, "%s: bad dtype %d", who, a->dtype);
+    if (a->dtype == ICAF_F32 && a->C > 128) return fail(ICAF_ERR_UNSUPPORTED, "%s: the fp32 instantiation covers C <= 128 (wider fp32 blocks use the per-layer launches)", who);
     if (a->B < 1 || a->N < 1 || a->heads < 1 || a->C % a->heads || a->B > 65535) return fail(ICAF_ERR_ARG, "%s: bad B/N/heads", who);
     if (a->C % 64 || a->C > 1024) return fail(ICAF_ERR_UNSUPPORTED, "%s: C=%d must be a multiple of 64 and <= 1024", who, a->C);
     if ((a->C / a->heads) % 8) return fail(ICAF_ERR_UNSUPPORTED, "%s: head dim %d must be a multiple of 8", who, a->C / a->heads);
-    if (a->Kp < a->C || a->Kp % 64) return fail(ICAF_ERR_ARG, "%s: Kp=%d", who, a->Kp);
+    if (a->Kp < a->C || a->Kp % (a->dtype == ICAF_F32 ? 32 : 64)) return fail(ICAF_ERR_ARG, "%s: Kp=%d", who, a->Kp);
     p.x = a->x; p.qkv = a->qkv; p.y = a->y;
     p.wqkv = a->wqkv; p.bqkv = a->bqkv; p.wo = a->wo; p.bo = a->bo; p.w1 = a->w1; p.b1 = a->b1; p.w2 = a->w2; p.b2 = a->b2;
     p.ln_a_g[0] = a->ln_attn_gamma[0]; p.ln_a_g[1] = a->ln_attn_gamma[1]; p.ln_a_b[0] = a->ln_attn_beta[0]; p.ln_a_b[1] = a->ln_attn_beta[1];
@@ -743,6 +772,11 @@ extern "C" int icaf_dmff_attn_mlp_lds_bytes(int C, int N, int heads, int dtype, 
     if (!bytes || heads < 1 || C % heads) return fail(ICAF_ERR_ARG, "icaf_dmff_attn_mlp_lds_bytes: bad arguments");
     const int dk = C / heads;
     const int dkp = dk <= 16 ? 16 : dk <= 32 ? 32 : dk <= 48 ? 48 : dk <= 64 ? 64 : dk <= 96 ? 96 : 128;
+    if (dtype == ICAF_F32) {
+        const size_t need = C % 64 == 0 && C <= 128 && dk % 8 == 0 && dk <= 32 ? attn_mlp_lds(C, N, dkp, 4) : (size_t)-1;
+        *bytes = need <= 160 * 1024 ? need : (size_t)-1;
+        return ICAF_OK;
+    }
     *bytes = (dtype == ICAF_BF16 || dtype == ICAF_F16) && C % 64 == 0 && C <= 512 && dk % 8 == 0 && dk <= 128 ? attn_mlp_lds(C, N, dkp, 2) : (size_t)-1;
     return ICAF_OK;
 }
@@ -752,6 +786,7 @@ extern "C" int icaf_dmff_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s) {
     int st = fill(a, p, "icaf_dmff_ln_qkv");
     if (st) return st;
     if (!a->ln_attn_gamma[0] || !a->ln_attn_gamma[1] || !a->ln_attn_beta[0] || !a->ln_attn_beta[1]) return fail(ICAF_ERR_ARG, "icaf_dmff_ln_qkv: LayerNorm parameters missing");
+    if (a->dtype == ICAF_F32) return launch_ln_qkv<ICAF_F32>(p, S(s));
     return a->dtype == ICAF_BF16 ? launch_ln_qkv<ICAF_BF16>(p, S(s)) : launch_ln_qkv<ICAF_F16>(p, S(s));
 }
 
@@ -760,7 +795,8 @@ extern "C" int icaf_dmff_attn_mlp(const icaf_dmff_args* a, icaf_stream_t s) {
     int st = fill(a, p, "icaf_dmff_attn_mlp");
     if (st) return st;
     if (!a->y || !a->wo || !a->bo || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ln_mlp_gamma || !a->ln_mlp_beta) return fail(ICAF_ERR_ARG, "icaf_dmff_attn_mlp: null pointer");
-    if (a->hidden % 128 || a->hidden < 128 || a->Kp4 < a->hidden || a->Kp4 % 64) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_attn_mlp: hidden width %d must be a multiple of 128", a->hidden);
+    if (a->hidden % 128 || a->hidden < 128 || a->Kp4 < a->hidden || a->Kp4 % (a->dtype == ICAF_F32 ? 32 : 64)) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_attn_mlp: hidden width %d must be a multiple of 128", a->hidden);
     if (a->ldy < a->C || a->ldy % 4) return fail(ICAF_ERR_ARG, "icaf_dmff_attn_mlp: ldy=%d", a->ldy);
+    if (a->dtype == ICAF_F32) return dispatch_attn_mlp_f32(p, S(s));
     return a->dtype == ICAF_BF16 ? dispatch_attn_mlp<ICAF_BF16>(p, S(s)) : dispatch_attn_mlp<ICAF_F16>(p, S(s));
 }

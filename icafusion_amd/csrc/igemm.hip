@@ -197,15 +197,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(c
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) foff[s] = l31 * RB + (((2 * s + hi) ^ fkey) << 4);
 
+    // Prologue: ALL NS stages are empty, so the first NS slices go out at once (the steady-state loop below keeps NS - 1 in flight:
+    // it can only refill the stage consumed one barrier earlier).  A 1x1 layer's K loop is 2-4 slices long; with the first two
+    // round trips to HBM overlapped instead of chained, a K = 128 tile waits for memory once, not twice.
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) {
+    for (int s = 0; s < NS; ++s) {
 #pragma unroll
         for (int part = 0; part < NSTEP; ++part) issue_part(s, s, part);
         advance();
     }
 
     for (int c = 0; c < p.nchunks; ++c) {
-        // slice c has landed once at most the (NS-2) younger slices of this wave are still outstanding
+        // slice c has landed once at most the (NS-2) younger slices of this wave are still outstanding (c = 0: NS - 1 younger slices
+        // are outstanding; the same count then also waits for slice 1, which costs nothing extra: both were issued together)
         if (nb_mine == NBF) wait_vmcnt<(NS - 2) * (NA + NBF)>();
         else wait_vmcnt<(NS - 2) * (NA + NBF + 1)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -226,9 +230,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(c
             for (int a = 0; a < TN; ++a)
 #pragma unroll
                 for (int b = 0; b < TM; ++b) mma_step<DT>(acc[a][b], fw[s][a], fp[s][b]);
-            issue_part(c + NS - 1, (c + NS - 1) % NS, s);
+            if (c > 0) issue_part(c + NS - 1, (c + NS - 1) % NS, s);          // (slice NS - 1 left with the prologue)
         }
-        advance();
+        if (c > 0) advance();
     }
     wait_vmcnt<0>();                               // drain the zero-fill slices issued past the end
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

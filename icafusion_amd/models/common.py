@@ -730,10 +730,14 @@ class CrossTransformerBlock(HipModule):
     # the pair of launches beats the seven (MI355X, batch 32, N = 400: 111 vs 145 us); at C = 256 / 512 one workgroup per CU cannot
     # hide its own latencies and each 64-row tile re-streams all 9 C^2 weights (166 vs 141 us, 430 vs 153 us) — DESIGN.md §11.
     fuse_max_c = int(os.environ.get("ICAF_DMFF_FUSE_MAX_C", "128"))
+    # fp32 plans keep the per-layer launches (the goldens then cover them); True runs the fp32 INSTANTIATION of the fused kernels where
+    # it exists (C <= 128): the same template the 16-bit path runs, held to the reference's fp32 goldens (tests/test_gpu_dmff_fused.py)
+    fuse_fp32 = os.environ.get("ICAF_DMFF_FUSE_FP32", "0") == "1"
 
     def fusable(self, plan, C, N):
         hid, h = self.mlp_vis[0].out_features, self.crossatt.h
-        return (self.fuse_block and C <= self.fuse_max_c and plan.dtype in (torch.bfloat16, torch.float16) and C % 64 == 0 and (C // h) % 8 == 0
+        types = (torch.bfloat16, torch.float16, torch.float32) if (self.fuse_fp32 and C <= 128) else (torch.bfloat16, torch.float16)
+        return (self.fuse_block and C <= self.fuse_max_c and plan.dtype in types and C % 64 == 0 and (C // h) % 8 == 0
                 and hid % 128 == 0 and self.mlp_vis[2].in_features == hid
                 and (plan.device.type != "cuda" or ops.dmff_fused_lds_bytes(C, N, h, plan.dtype) is not None)
                 and (plan.device.type == "cuda" or C <= 512))

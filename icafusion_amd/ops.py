@@ -464,7 +464,7 @@ def cross_attention(qkv, out, B, N, heads, name="cross_attention"):
 
 def dmff_fused_lds_bytes(C_, N, heads, dt):
     """LDS bytes one icaf_dmff_attn_mlp workgroup needs for this shape, or None when the fused block kernels do not cover it."""
-    if dt not in (torch.bfloat16, torch.float16):
+    if dt not in (torch.bfloat16, torch.float16, torch.float32):      # (fp32: the parity instantiation, C <= 128)
         return None
     sz = C.c_size_t(0)
     check(lib().icaf_dmff_attn_mlp_lds_bytes(int(C_), int(N), int(heads), dtype_code(dt), C.byref(sz)), "dmff_attn_mlp_lds_bytes")

@@ -79,6 +79,9 @@ class DetectionPipeline:
         with torch.cuda.stream(fs):
             ins[0].copy_(rgb, non_blocking=True)
             ins[1].copy_(ir, non_blocking=True)
+        for t in (rgb, ir):                                        # the copies run on `fs`, possibly long after this call returns: tell the
+            if t.is_cuda:                                          # caching allocator, or a temporary's memory is handed out (and overwritten
+                t.record_stream(fs)                                # on the caller's stream) before the copy has read it
         return self.step()
 
     def step(self):
