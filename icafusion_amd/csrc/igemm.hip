@@ -450,12 +450,17 @@ int ctile_check(const icaf_conv_args* a, const ConvP& p, int shape);
 int launch_ctile(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
 int launch_bneck(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
 const char* ctile_tag(int shape);
+// igemm_stream.hip
+int stream_check(const icaf_conv_args* a, const ConvP& p, int shape);
+int launch_stream(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
+const char* stream_tag(int shape);
 
-//   40 + shape: 3x3 direct convolution from an LDS halo tile (ctile.hip); an explicit request that the layer cannot
-//   satisfy is an error (the autotuner skips it), it is never chosen silently.
+//   40 + shape: 3x3 direct convolution from an LDS halo tile (ctile.hip); 50 + shape: persistent streaming GEMM for 1x1 layers
+//   (igemm_stream.hip); an explicit request that the layer cannot satisfy is an error (the autotuner skips it), it is never
+//   chosen silently.
 static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
     const bool dma_ok = p.x_bytes != 0;
-    if (a->tile > 40 && a->tile < 50) return a->tile;
+    if (a->tile > 40 && a->tile < 60) return a->tile;
     if (a->tile >= 1 && a->tile <= 34 && a->tile % 10 >= 1 && a->tile % 10 <= 4) {
         const int pipe = a->tile / 10;
         return (pipe != 1 && !dma_ok) ? a->tile % 10 + 10 : a->tile;
@@ -681,6 +686,7 @@ extern "C" int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s) {
     fill(a, p);
     const int tile = pick_tile(a, p);
     hipStream_t hs = S(s);
+    if (tile > 50) return launch_stream(a, p, tile - 50, hs);
     if (tile > 40) return launch_ctile(a, p, tile - 40, hs);
     if (a->dtype == ICAF_BF16)
         return a->out_dtype == ICAF_F32 ? launch_tile<ICAF_BF16, ICAF_F32>(p, a->groups, tile, hs)
@@ -715,6 +721,12 @@ extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int b
     fill(a, p);
     const int tile = pick_tile(a, p);
     static const char* dn[] = {"f32", "bf16", "f16"};
+    if (tile > 50) {
+        st = stream_check(a, p, tile - 50);
+        if (st) return st;
+        snprintf(buf, buf_len, "igemm_stream_%s_%s", dn[a->dtype], stream_tag(tile - 50));
+        return ICAF_OK;
+    }
     if (tile > 40) {
         st = ctile_check(a, p, tile - 40);
         if (st) return st;

@@ -6,6 +6,7 @@ one kernel on a stream or returns a `Launch` record that does so later (used by 
 PyTorch only provides device memory and streams here — none of its operators run on the hot path.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -204,6 +205,7 @@ def bottleneck(x, w1_packed, kp1, bias1, w2_packed, kp2, bias2, y, c, add, shape
 
 _TUNE_CACHE = {}
 CTILE_SHAPES = {1: (32, 1), 2: (64, 1), 3: (64, 1), 4: (64, 2), 5: (128, 1)}     # shape id -> (BN, stride), ctile.hip
+STREAM_GEMM = os.environ.get("ICAF_STREAM_GEMM", "1") != "0"      # A/B switch for the persistent 1x1 kernel as a tuner candidate
 CONV_PIPELINES = (0, 1, 2)        # LDS-DMA 64 B x3, register-staged, LDS-DMA 128 B x2 (3 = 128 B x3: never won)
 
 
@@ -236,6 +238,11 @@ def conv_candidates(a):
             cands.append(28)
         if a.Cout >= 256:
             cands.append(26)
+    if ((a.kh, a.kw, a.sh, a.sw, a.ph, a.pw) == (1, 1, 1, 1, 0, 0) and a.dtype != F32 and a.out_dtype == a.dtype and not a.pre and not a.w2
+            and not a.res and (a.Cin * 2) % 128 == 0 and a.Cout % 8 == 0 and STREAM_GEMM):
+        cands.append(52)                     # persistent streaming GEMM (igemm_stream.hip): 128 x 64 tile ...
+        if a.Cout > 64:
+            cands.append(51)                 # ... and 128 x 128; a launch the shape rules out returns an error and is skipped
     if (a.kh, a.kw, a.ph, a.pw) == (3, 3, 1, 1) and a.act == ACT_SILU and a.out_dtype == a.dtype and not a.pre and not a.w2:
         for shape, (bn, stride) in CTILE_SHAPES.items():       # 3x3 direct convolution from an LDS halo patch
             if a.sh == stride and a.sw == stride and a.Cout <= bn and (bn < 64 or a.Cout > bn // 2):

@@ -125,6 +125,62 @@ def test_conv2d(case, dt):
     assert float(ybuf[..., cout:].abs().max()) == 0.0, "conv wrote outside its channel slice"
 
 
+STREAM_CASES = [
+    # B, H, W, cin, cout, act, groups, shape (tile id 50 + shape): persistent streaming GEMM for 1x1 layers (igemm_stream.hip)
+    (8, 80, 80, 128, 128, ops.ACT_SILU, 2, 1),      # C3 cv3 at 80x80, both backbones side by side: 6 tiles per workgroup
+    (8, 80, 80, 64, 64, ops.ACT_SILU, 2, 2),        # ONE 128-byte slice per tile, 128 x 64 tile
+    (12, 37, 41, 256, 256, ops.ACT_SILU, 1, 1),     # two channel tiles per pixel tile, 143 pixel tiles (1-2 per workgroup), ragged last one
+    (4, 40, 40, 512, 256, ops.ACT_NONE, 1, 1),      # K = 8 slices
+    (2, 64, 72, 128, 512, ops.ACT_GELU, 2, 1),      # four channel tiles, GELU (DMFF fc1)
+    (5, 33, 29, 192, 64, ops.ACT_SILU, 1, 2),       # K = 3 slices (odd), Cout = one 64-wide tile
+    (9, 40, 40, 1024, 512, ops.ACT_SILU, 1, 1),     # SPPF cv2: K = 16 slices
+    (6, 52, 52, 64, 136, ops.ACT_NONE, 1, 2),       # ragged N on the 128 x 64 tile (three channel tiles: rejected when they do not
+]                                                   # divide an XCD's workgroups - the test then expects the error)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", STREAM_CASES)
+def test_conv1x1_streaming_kernel(case, dt):
+    """igemm_stream.hip vs torch, and BIT-EXACT vs the implicit-GEMM kernel (same K order, MFMA step and epilogue expressions):
+    a persistent workgroup walks several tiles through one DMA ring, so the cases cover several tiles per workgroup, ragged last
+    tiles, one to sixteen K slices per tile, one to four channel tiles, and the paired (groups = 2) launch."""
+    B, H, W, cin, cout, act, G, shape = case
+    xs = [rnd((B, cin, H, W), 51 + g) for g in range(G)]
+    ws = [rnd((cout, cin, 1, 1), 53 + g, 1.0 / math.sqrt(cin)) for g in range(G)]
+    bs = [rnd((cout,), 55 + g, 0.2) for g in range(G)]
+    stk = (lambda t: torch.stack(t).contiguous()) if G == 2 else (lambda t: t[0])
+    xa = stk([to_act(x, dt, pad_to=cin + 16) for x in xs])
+    packs = [ops.pack_conv_weight(w.to(DEV), dt) for w in ws]
+    wp, kp = stk([p_[0] for p_ in packs]), packs[0][1]
+    bp = stk([ops.pack_bias(b.to(DEV), cout) for b in bs])
+    ldy = -(-cout // 8) * 8 + 8
+    outs = []
+    for tile in (50 + shape, 2):
+        ybuf = torch.full((G, B, H, W, ldy) if G == 2 else (B, H, W, ldy), 7.0, dtype=dt, device=DEV)
+        y = ybuf[..., :cout]
+        try:
+            run(ops.conv2d(xa, wp, kp, bp, y, 1, 1, 1, 1, 0, 0, cin, cout, act, alpha_acc=0.75, tile=tile))
+        except ops._lib.IcafError as e:
+            assert tile > 50 and "channel tiles do not divide" in str(e) and cout == 136, e
+            return
+        assert float((ybuf[..., cout:] - 7.0).abs().max()) == 0.0, "conv wrote outside its channel slice"
+        outs.append(y.clone())
+    assert torch.equal(outs[0], outs[1]), f"streaming kernel != igemm, max diff {(outs[0].float() - outs[1].float()).abs().max().item()}"
+    for g in range(G):
+        ref = F.conv2d(q(xs[g], dt), q(ws[g], dt), bs[g])
+        ref = {ops.ACT_NONE: lambda t: t, ops.ACT_SILU: F.silu, ops.ACT_GELU: F.gelu}[act](ref) * 0.75
+        close(from_act(outs[0][g] if G == 2 else outs[0]), ref, dt, f"stream {case} group {g}")
+
+
+def test_conv1x1_streaming_kernel_rejects_other_layers():
+    x = torch.zeros((1, 32, 32, 64), dtype=torch.bfloat16, device=DEV)
+    w3 = rnd((64, 64, 3, 3), 1)
+    wp, kp = ops.pack_conv_weight(w3.to(DEV), torch.bfloat16)
+    y = torch.zeros((1, 32, 32, 64), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ops._lib.IcafError):
+        run(ops.conv2d(x, wp, kp, None, y, 3, 3, 1, 1, 1, 1, 64, 64, ops.ACT_SILU, tile=52))
+
+
 CTILE_CASES = [
     # B, H, W, cin, cout, stride, use_res, ctile shape (tile id 40 + shape)
     (2, 40, 70, 16, 32, 1, False, 1),     # stem-like: 16 channels = 32 bytes per pixel, one tap per MFMA step

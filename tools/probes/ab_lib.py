@@ -14,8 +14,16 @@ from icafusion_amd.synth import synth_state_dict   # noqa: E402
 cfg = yaml.safe_load(open(f"{R}/models/transformer/yolov5s_Transfusion_kaist.yaml"))
 m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 0)); m = m.to("cuda:0"); m.compute_dtype = torch.bfloat16
 m.autotune = True; m.use_graph = True
-ops.load_tune_cache(f"{R}/profiles/tune_cache.json")
+# ICAF_AB_TUNE: unset = the committed tile choices; "fresh" = tune every layer on the spot (new candidates get their chance);
+# a path = load it if it exists, tune the rest, save it there
+tune = os.environ.get("ICAF_AB_TUNE", "")
+if not tune:
+    ops.load_tune_cache(f"{R}/profiles/tune_cache.json")
+elif tune != "fresh" and os.path.exists(tune):
+    ops.load_tune_cache(tune)
 plan = m.plan_for(32, 640, 640, "cuda:0")
+if tune and tune != "fresh":
+    ops.save_tune_cache(tune)
 st = torch.cuda.Stream(); sp = st.cuda_stream
 fw = []
 for rep in range(3):
