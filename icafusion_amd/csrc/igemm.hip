@@ -26,8 +26,8 @@
 //     buffer-descriptor range and kept selectable for A/B measurements (configuration ids 11..14).
 #include "conv_common.h"
 
-static_assert(sizeof(icaf_conv_args) == 272, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
-static_assert(sizeof(icaf_bneck_args) == 336, "icaf_bneck_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
+static_assert(sizeof(icaf_conv_args) == 288, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
+static_assert(sizeof(icaf_bneck_args) == 352, "icaf_bneck_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
 
 namespace icaf {
 
@@ -454,13 +454,17 @@ const char* ctile_tag(int shape);
 int stream_check(const icaf_conv_args* a, const ConvP& p, int shape);
 int launch_stream(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
 const char* stream_tag(int shape);
+// igemm_wreg.hip
+int wreg_check(const icaf_conv_args* a, const ConvP& p, int shape);
+int launch_wreg(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
+const char* wreg_tag(int shape);
 
 //   40 + shape: 3x3 direct convolution from an LDS halo tile (ctile.hip); 50 + shape: persistent streaming GEMM for 1x1 layers
-//   (igemm_stream.hip); an explicit request that the layer cannot satisfy is an error (the autotuner skips it), it is never
-//   chosen silently.
+//   (igemm_stream.hip); 60 + shape: weight operand fed from registers (igemm_wreg.hip); an explicit request that the layer cannot
+//   satisfy is an error (the autotuner skips it), it is never chosen silently.
 static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
     const bool dma_ok = p.x_bytes != 0;
-    if (a->tile > 40 && a->tile < 60) return a->tile;
+    if (a->tile > 40 && a->tile < 70) return a->tile;
     if (a->tile >= 1 && a->tile <= 34 && a->tile % 10 >= 1 && a->tile % 10 <= 4) {
         const int pipe = a->tile / 10;
         return (pipe != 1 && !dma_ok) ? a->tile % 10 + 10 : a->tile;
@@ -686,6 +690,7 @@ extern "C" int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s) {
     fill(a, p);
     const int tile = pick_tile(a, p);
     hipStream_t hs = S(s);
+    if (tile > 60) return launch_wreg(a, p, tile - 60, hs);
     if (tile > 50) return launch_stream(a, p, tile - 50, hs);
     if (tile > 40) return launch_ctile(a, p, tile - 40, hs);
     if (a->dtype == ICAF_BF16)
@@ -721,6 +726,12 @@ extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int b
     fill(a, p);
     const int tile = pick_tile(a, p);
     static const char* dn[] = {"f32", "bf16", "f16"};
+    if (tile > 60) {
+        st = wreg_check(a, p, tile - 60);
+        if (st) return st;
+        snprintf(buf, buf_len, "igemm_wreg_%s_%s", dn[a->dtype], wreg_tag(tile - 60));
+        return ICAF_OK;
+    }
     if (tile > 50) {
         st = stream_check(a, p, tile - 50);
         if (st) return st;

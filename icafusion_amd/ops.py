@@ -99,6 +99,29 @@ def pack_conv_weight(w4d, dt, cin_pad=None):
     return pack_matrix(w.reshape(co, -1).contiguous(), dt)
 
 
+_FRAG_CACHE = {}
+WREG_GEMM = os.environ.get("ICAF_WREG_GEMM", "1") != "0"       # A/B switch: weights-from-registers kernels as tuner candidates
+
+
+def frag_weights(w_packed):
+    """Second copy of packed 16-bit weights ([Np][Kp] or stacked [G][Np][Kp]) in FRAGMENT-MAJOR order for the kernels that feed
+    the weight operand from registers (igemm_wreg.hip; icaf.h: icaf_conv_args.wf): [G][Np / 32][Kp / 16][64][8], lane (hi * 32 + r) of
+    block (nb, ks) = w[nb * 32 + r][ks * 16 + hi * 8 : + 8].  Built once per packed tensor (plan-build time), cached by storage."""
+    key = (w_packed.data_ptr(), tuple(w_packed.shape), w_packed.dtype)
+    hit = _FRAG_CACHE.get(key)
+    if hit is not None:
+        return hit[1]
+    w = w_packed if w_packed.dim() == 3 else w_packed[None]
+    G, np_, kp = w.shape
+    assert np_ % 32 == 0 and kp % 16 == 0 and w.element_size() == 2
+    f = w.reshape(G, np_ // 32, 32, kp // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()      # g, nb, ks, hi, r, e
+    f = f.reshape(G, np_ // 32, kp // 16, 64, 8)
+    if w_packed.dim() == 2:
+        f = f[0]
+    _FRAG_CACHE[key] = (w_packed, f)                 # (the packed tensor is kept alive with its copy: the key is its address)
+    return f
+
+
 def s2d_conv_weight(w4d):
     """6x6/s2/p2 kernel over C channels -> equivalent 3x3/s1/p1 kernel over the 4C space-to-depth channels
     ordered (dy, dx, c):  W3[co][(dy*2+dx)*C + c][ty][tx] = W[co][c][2ty+dy][2tx+dx]."""
@@ -144,6 +167,11 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
     a.alpha_acc[0], a.alpha_acc[1] = float(aa[0]), float(aa[1])
     a.alpha_res[0], a.alpha_res[1] = float(ar[0]), float(ar[1])
     a.tile = tile
+    wf = None
+    if (WREG_GEMM and x.dtype != torch.float32 and y.dtype == x.dtype and (cin * 2) % 128 == 0 and kp % 64 == 0 and pre is None
+            and chain is None and cout > 64):
+        wf = frag_weights(w_packed)                   # igemm_wreg.hip: weight operand from registers (tile ids 61 / 62)
+        a.wf, a.wf_gs = wf.data_ptr(), (wf.stride(0) if w_packed.dim() == 3 else 0)
     if pre is not None:               # fp32 coarse map (B, h, w, >= cout) added, bilinearly resized, before the activation
         Bp, hp, wp_, cp, ldp = _act_geom(pre)
         assert pre.dtype == torch.float32 and Bp == B and cp >= cout and groups == 1
@@ -168,7 +196,7 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
     if chain is not None:
         flops += 2.0 * m * cout * chain["cout"] * groups
         nbytes += groups * (m * chain["cout"] - (0 if chain.get("keep") else m * cout)) * eo      # y2 is written instead of / besides y
-    return Launch(lib().icaf_conv2d, (C.byref(a),), keep=(a, x, w_packed, bias, y, res, pre, chain), name=name, flops=flops,
+    return Launch(lib().icaf_conv2d, (C.byref(a),), keep=(a, x, w_packed, bias, y, res, pre, chain, wf), name=name, flops=flops,
                   nbytes=nbytes)
 
 
@@ -243,6 +271,10 @@ def conv_candidates(a):
         cands.append(52)                     # persistent streaming GEMM (igemm_stream.hip): 128 x 64 tile ...
         if a.Cout > 64:
             cands.append(51)                 # ... and 128 x 128; a launch the shape rules out returns an error and is skipped
+    if a.wf and not a.pre and not a.w2:
+        cands.append(61)                     # weights fed from registers (igemm_wreg.hip): 128 x 128 ...
+        if a.Cout > 128:
+            cands.append(62)                 # ... and 128 x 256
     if (a.kh, a.kw, a.ph, a.pw) == (3, 3, 1, 1) and a.act == ACT_SILU and a.out_dtype == a.dtype and not a.pre and not a.w2:
         for shape, (bn, stride) in CTILE_SHAPES.items():       # 3x3 direct convolution from an LDS halo patch
             if a.sh == stride and a.sw == stride and a.Cout <= bn and (bn < 64 or a.Cout > bn // 2):

@@ -136,6 +136,12 @@ typedef struct icaf_conv_args {
     int Kp2, Cout2, ldy2;
     int chain_keep; /* != 0: y IS written as well; only then may `res` be set: the chained 1x1 consumes y as stored, residual
                      * included (a Bottleneck's 3x3 + shortcut followed by the next Bottleneck's 1x1, models/common.py:193-194) */
+    /* Optional second copy of the packed weights in FRAGMENT-MAJOR order (NULL = none), read by the launch configurations that feed
+     * the weight operand from registers (igemm_wreg.hip, tile ids 61 / 62): [Np / 32][Kp / 16][64 lanes][8 elements], lane
+     * (hi * 32 + r) of block (nb, ks) holding w[nb * 32 + r][ks * 16 + hi * 8 .. + 8] of the K-major matrix above; wf_gs = group
+     * stride in elements.  16-bit types (icafusion_amd.ops.frag_weights builds it once per layer). */
+    const void* wf;
+    long long wf_gs;
 } icaf_conv_args;
 
 int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s);

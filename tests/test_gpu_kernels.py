@@ -181,6 +181,74 @@ def test_conv1x1_streaming_kernel_rejects_other_layers():
         run(ops.conv2d(x, wp, kp, None, y, 3, 3, 1, 1, 1, 1, 64, 64, ops.ACT_SILU, tile=52))
 
 
+WREG_CASES = [
+    # B, H, W, cin, cout, k, stride, act, use_res, groups, shape (tile id 60 + shape): weight operand fed from registers (igemm_wreg.hip)
+    (4, 40, 40, 128, 128, 3, 1, ops.ACT_SILU, True, 2, 1),      # Bottleneck 3x3 + shortcut, both backbones: 18 K slices
+    (3, 20, 20, 256, 256, 3, 1, ops.ACT_SILU, False, 1, 2),     # 128 x 256 tile, K = 36 slices
+    (2, 40, 40, 128, 256, 3, 2, ops.ACT_SILU, False, 2, 2),     # stride 2
+    (2, 23, 29, 64, 136, 3, 1, ops.ACT_GELU, True, 1, 1),       # ragged M and N (N tile 2 half empty), K = 9 slices (9 % 3 == 0)
+    (1, 17, 19, 64, 192, 1, 1, ops.ACT_NONE, False, 1, 1),      # ONE K slice (tail path only), 1x1
+    (2, 33, 31, 128, 384, 1, 1, ops.ACT_SILU, True, 1, 1),      # two K slices, three channel tiles
+    (5, 20, 20, 512, 512, 1, 1, ops.ACT_SILU, False, 1, 2),     # 1x1, K = 8 slices (8 % 3 == 2), two 256-wide tiles
+    (2, 20, 20, 1024, 512, 1, 1, ops.ACT_SILU, False, 2, 1),    # SPPF cv2, paired: K = 16 slices (16 % 3 == 1)
+    (1, 13, 13, 64, 384, 3, 2, ops.ACT_SILU, False, 1, 2),      # 128 x 256 tile reaching beyond Cout: rejected (checked below)
+]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", WREG_CASES)
+def test_conv_weights_from_registers_kernel(case, dt):
+    """igemm_wreg.hip vs torch, and BIT-EXACT vs the implicit-GEMM kernel.  The K loop is unrolled by three with a tail of 0-2
+    steps, the pixel ring is four stages deep, the weights come fragment-major straight from memory: the cases cover every tail
+    length, 1x1 / 3x3 / stride 2, residuals, ragged tiles, both tile widths and the paired (groups = 2) launch."""
+    B, H, W, cin, cout, k, st, act, use_res, G, shape = case
+    p_ = k // 2
+    Ho, Wo = (H + 2 * p_ - k) // st + 1, (W + 2 * p_ - k) // st + 1
+    xs = [rnd((B, cin, H, W), 61 + g) for g in range(G)]
+    ws = [rnd((cout, cin, k, k), 63 + g, 1.0 / math.sqrt(cin * k * k)) for g in range(G)]
+    bs = [rnd((cout,), 65 + g, 0.2) for g in range(G)]
+    rs = [rnd((B, cout, Ho, Wo), 67 + g) for g in range(G)] if use_res else None
+    stk = (lambda t: torch.stack(t).contiguous()) if G == 2 else (lambda t: t[0])
+    xa = stk([to_act(x, dt) for x in xs])
+    packs = [ops.pack_conv_weight(w.to(DEV), dt) for w in ws]
+    wp, kp = stk([p0[0] for p0 in packs]), packs[0][1]
+    bp = stk([ops.pack_bias(b.to(DEV), cout) for b in bs])
+    ra = stk([to_act(r, dt) for r in rs]) if use_res else None
+    ldy = -(-cout // 8) * 8 + 8
+    outs = []
+    for tile in (60 + shape, 2):
+        ybuf = torch.full((G, B, Ho, Wo, ldy) if G == 2 else (B, Ho, Wo, ldy), 7.0, dtype=dt, device=DEV)
+        y = ybuf[..., :cout]
+        try:
+            run(ops.conv2d(xa, wp, kp, bp, y, k, k, st, st, p_, p_, cin, cout, act, res=ra, alpha_acc=0.75, alpha_res=1.25, tile=tile))
+        except ops._lib.IcafError as e:
+            assert tile > 60 and "beyond the packed weights" in str(e) and cout == 384 and shape == 2, e
+            return
+        assert float((ybuf[..., cout:] - 7.0).abs().max()) == 0.0, "conv wrote outside its channel slice"
+        outs.append(y.clone())
+    assert not (cout == 384 and shape == 2 and cin == 64), "the 128 x 256 tile must reject Cout = 384 (Np = 384)"
+    assert torch.equal(outs[0], outs[1]), f"wreg kernel != igemm, max diff {(outs[0].float() - outs[1].float()).abs().max().item()}"
+    for g in range(G):
+        ref = F.conv2d(q(xs[g], dt), q(ws[g], dt), bs[g], st, p_)
+        ref = {ops.ACT_NONE: lambda t: t, ops.ACT_SILU: F.silu, ops.ACT_GELU: F.gelu}[act](ref) * 0.75
+        if use_res:
+            ref = ref + 1.25 * q(rs[g], dt)
+        close(from_act(outs[0][g] if G == 2 else outs[0]), ref, dt, f"wreg {case} group {g}")
+
+
+def test_frag_weights_layout():
+    """ops.frag_weights: lane (hi * 32 + r) of block (nb, ks) holds w[nb * 32 + r][ks * 16 + hi * 8 : + 8] (icaf.h: icaf_conv_args.wf)."""
+    w = torch.arange(128 * 64, dtype=torch.float32).reshape(128, 64).to(torch.bfloat16).to(DEV)
+    f = ops.frag_weights(w)
+    assert f.shape == (4, 4, 64, 8)
+    for nb, ks, lane in ((0, 0, 0), (1, 2, 37), (3, 3, 63), (2, 1, 31)):
+        hi, r = lane // 32, lane % 32
+        assert torch.equal(f[nb, ks, lane], w[nb * 32 + r, ks * 16 + hi * 8: ks * 16 + hi * 8 + 8])
+    w2 = torch.stack((w, w + 1)).contiguous()
+    f2 = ops.frag_weights(w2)
+    assert f2.shape == (2, 4, 4, 64, 8) and torch.equal(f2[1, 1, 2, 37], w2[1, 32 + 5, 32 + 8: 32 + 16])
+
+
 CTILE_CASES = [
     # B, H, W, cin, cout, stride, use_res, ctile shape (tile id 40 + shape)
     (2, 40, 70, 16, 32, 1, False, 1),     # stem-like: 16 channels = 32 bytes per pixel, one tap per MFMA step

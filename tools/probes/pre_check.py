@@ -25,7 +25,7 @@ for i, l in enumerate(plan.launches):
     l(sp); torch.cuda.synchronize()
     if l.fn is not ops.lib().icaf_conv2d or not l.keep[0].pre:
         continue
-    a, x, wp, bias, y, res, pre, chain = l.keep
+    a, x, wp, bias, y, res, pre, chain = l.keep[:8]
     N, K = a.Cout, a.Cin
     W = wp[:N, :K].float()
     ref = x.float().reshape(-1, x.shape[-1])[:, :K] @ W.t() + bias[:N]
@@ -48,7 +48,7 @@ for i, l in enumerate(plan.launches):
 for i, l in enumerate(plan.launches):
     if l.fn is not ops.lib().icaf_conv2d or not l.keep[0].pre or l.keep[0].pre_mode == 1:
         continue
-    a, x, wp, bias, y, res, pre, chain = l.keep
+    a, x, wp, bias, y, res, pre, chain = l.keep[:8]
     outs = []
     for c in (2, 2, 22):
         a.tile = c
