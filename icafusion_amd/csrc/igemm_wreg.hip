@@ -17,6 +17,12 @@
 // Workgroup = NWV wavefronts = 128 pixels x 32 * NWV channels (NWV = 4: 128 x 128, NWV = 8: 128 x 256).
 #include "conv_common.h"
 
+// Ablation switches for timing studies (tools/quick_variant.py -DICAF_WREG_ABL=n; results are then meaningless):
+//   1 = no weight loads, 2 = no pixel DMA, 4 = no LDS fragment reads
+#ifndef ICAF_WREG_ABL
+#define ICAF_WREG_ABL 0
+#endif
+
 namespace icaf {
 
 // MODE 1: 1x1 / stride 1 / pad 0 (plain row-major pixel matrix); MODE 2: any filter with Cin * bytes a multiple of 128 (a K slice
@@ -86,7 +92,8 @@ __global__ __launch_bounds__(NWV * 64) void igemm_wreg_kernel(const ConvP p, con
                 const bool ok = a_ok[i] && kvalid && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
                 voff = ok ? a_off[i] + tap_delta : OOB;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + (wave + NWV * i) * 1024), 16, voff, 0, 0, 0);
+            if constexpr (!(ICAF_WREG_ABL & 2))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + (wave + NWV * i) * 1024), 16, voff, 0, 0, 0);
         }
     };
     auto advance_a = [&]() {
@@ -107,7 +114,8 @@ __global__ __launch_bounds__(NWV * 64) void igemm_wreg_kernel(const ConvP p, con
         for (int s = 0; s < NSTEP; ++s) {
             int ks = chunk * NSTEP + s;
             ks = ks < last_step ? ks : last_step;
-            dst[s] = wf[(long long)ks * 64];
+            if constexpr (ICAF_WREG_ABL & 1) dst[s] = u32x4{(unsigned)ks, (unsigned)lane, 0x3f803f80u, 0x3f803f80u};
+            else dst[s] = wf[(long long)ks * 64];
         }
     };
 
@@ -150,7 +158,10 @@ __global__ __launch_bounds__(NWV * 64) void igemm_wreg_kernel(const ConvP p, con
         for (int s = 0; s < NSTEP; ++s) {
             u32x4 fp[TM];
 #pragma unroll
-            for (int b = 0; b < TM; ++b) fp[b] = *(const u32x4*)(a_s + (b * 32) * RB + foff[s]);
+            for (int b = 0; b < TM; ++b) {
+                if constexpr (ICAF_WREG_ABL & 4) fp[b] = u32x4{(unsigned)(c + b), (unsigned)foff[s], 0x3f803f80u, 0x3f803f80u};
+                else fp[b] = *(const u32x4*)(a_s + (b * 32) * RB + foff[s]);
+            }
 #pragma unroll
             for (int b = 0; b < TM; ++b) mma_step<DT>(acc[0][b], fw[P][s], fp[b]);
             issue_a(sfree, s, NSTEP);
