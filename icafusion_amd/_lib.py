@@ -93,6 +93,7 @@ SIGNATURES = {
     "icaf_dmff_attn_mlp_lds_bytes": (_i, [_i, _i, _i, _i, C.POINTER(_sz)]),
     "icaf_dmff_upsample_merge": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_detect_decode": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _ll, _ll, _f, C.POINTER(_f), _p]),
+    "icaf_detect_conv": (_i, [C.POINTER(ConvArgs), _p, _p, _p, _i, _i, _ll, _ll, _f, C.POINTER(_f), _p]),
     "icaf_match_predictions": (_i, [_p, _p, _i, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p]),
     "icaf_nms_workspace_bytes": (_i, [_i, _ll, _i, _i, C.POINTER(_sz)]),
     "icaf_nms": (_i, [_p, _i, _ll, _i, _f, _f, _i, _i, C.POINTER(_i), _i, _i, _i, _f, _p, _p, _p, _p, _sz, _p]),

@@ -2,11 +2,13 @@
 // Built with fp contraction off so every expression rounds exactly like the reference's separate torch ops.
 #pragma clang fp contract(off)
 #include "icaf_common.h"
+#include "stream_core.h"
 #include <cstdlib>
 
 namespace icaf {
 
 struct Anchors { float v[16]; };   // up to 8 anchors (w, h) in pixels
+int conv_prepare(const icaf_conv_args* a, ConvP& p);      // igemm.hip
 
 // One thread per OUTPUT ELEMENT (b, anchor, y, x, o), o fastest: z, logits and raw are written fully coalesced (their
 // rows are contiguous over (x, o)); the conv output is read in `no`-float runs at pixel stride ldp, each 128-byte line
@@ -132,6 +134,101 @@ static int launch_detect_pixel(const float* p, int ldp, float* z, float* logits,
     return ICAF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Detect level in ONE launch: the 1x1 output conv (models/yolo_test.py:50) as the persistent streaming GEMM of stream_core.h with
+// the decode (:52-63) as its epilogue.  The conv's fp32 map never reaches HBM (it was written and read back: 2 x 14.7 MB at P3,
+// batch 32) and a level is one launch instead of two.  The accumulator tile (+ bias) is staged as fp32 in the workgroup's LDS
+// buffer — exactly the values the two-launch form stores — and one thread per (pixel, anchor) decodes its NO values with the
+// expressions of detect_pixel_kernel above (this file is built with fp contraction off): z, logits and raw are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NA, int NO>
+struct DetectEpi {
+    static constexpr int SO = 64 * 4 + 16;                 // fp32 staging rows of the 128 x 64 tile
+    float* z; float* logits; float* raw;
+    int M, ny, nx; long long rows_total, row_offset; float stride; Anchors anc; FastDiv dnx, dny;
+    template <int TM>
+    __device__ __forceinline__ void stage(const f32x16 (&acc)[TM], const f32x4 (&bq)[4], unsigned char* stg, int row0, int col0, int l31, int hi) const {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int nl = col0 + 8 * qd + 4 * hi;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int ml = row0 + b * 32 + l31;
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[b][4 * qd + j] + bq[qd][j];          // (igemm's epilogue with ACT_NONE, alpha 1)
+                *(f32x4*)(stg + ml * SO + nl * 4) = v;
+            }
+        }
+    }
+    __device__ __forceinline__ void flush(const unsigned char* stg, int m0, int n0, int tid) const {
+        if (tid >= 128 * NA) return;                        // one thread per (pixel of the tile, anchor)
+        const int row = tid / NA, a = tid - row * NA;
+        const unsigned int pix = (unsigned int)(m0 + row);
+        if ((int)pix >= M) return;
+        unsigned int t, x, b, y;
+        fd_divmod(pix, dnx, t, x);
+        fd_divmod(t, dny, b, y);
+        const float* src = (const float*)(stg + row * SO) + a * NO;
+        float v[NO];
+#pragma unroll
+        for (int k = 0; k < NO; k += 2) { const float2 q2 = *(const float2*)(src + k); v[k] = q2.x; v[k + 1] = q2.y; }
+        const long long cell = ((long long)a * ny + y) * nx + x;
+        const long long zrow = (long long)b * rows_total + row_offset + cell;
+        float o[NO];
+#pragma unroll
+        for (int k = 0; k < NO; ++k) {
+            const float sg = 1.0f / (1.0f + expf(-v[k]));
+            float out = sg;
+            if (k == 0) out = ((sg * 2.0f - 0.5f) + (float)x) * stride;
+            else if (k == 1) out = ((sg * 2.0f - 0.5f) + (float)y) * stride;
+            else if (k == 2 || k == 3) {
+                const float d = sg * 2.0f;
+                out = (d * d) * anc.v[2 * a + (k - 2)];
+            }
+            o[k] = out;
+        }
+        float* zr = z + zrow * NO;
+#pragma unroll
+        for (int k = 0; k < NO; k += 2) *(float2*)(zr + k) = float2{o[k], o[k + 1]};
+        if (raw) {
+            float* rr = raw + (((long long)b * NA) * ny * nx + cell) * NO;
+#pragma unroll
+            for (int k = 0; k < NO; k += 2) *(float2*)(rr + k) = float2{v[k], v[k + 1]};
+        }
+        if (logits) {
+#pragma unroll
+            for (int k = 5; k < NO; ++k) logits[zrow * (NO - 5) + (k - 5)] = v[k];
+        }
+    }
+};
+
+template <int DT, int NA, int NO>
+__global__ __launch_bounds__(512) void detect_conv_kernel(const ConvP p, const DetectEpi<NA, NO> epi) {
+    stream_gemm<DT, 64>(p, epi);
+}
+
+template <int DT, int NA, int NO>
+static int launch_detect_conv(const ConvP& p, const DetectEpi<NA, NO>& epi, hipStream_t s) {
+    constexpr int LDS = 3 * (128 + 64) * 128 + 128 * DetectEpi<NA, NO>::SO;
+    ConvP q = p;
+    q.mtiles = (p.M + 127) / 128;
+    q.ntiles = 1;
+    q.nchunks = p.K / 64;
+    int dev = 0, cus = 256;
+    ICAF_HIP(hipGetDevice(&dev));
+    ICAF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int grid = cus & ~7;                     // one workgroup per CU, 8 XCDs; workgroups beyond the pixel tiles exit at once
+    static std::atomic<bool> attr{false};
+    if (!attr) {
+        ICAF_HIP(hipFuncSetAttribute((const void*)detect_conv_kernel<DT, NA, NO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    detect_conv_kernel<DT, NA, NO><<<dim3((unsigned)grid, 1, 1), dim3(512), LDS, s>>>(q, epi);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
 }  // namespace icaf
 
 using namespace icaf;
@@ -163,4 +260,32 @@ extern "C" int icaf_detect_decode(const float* p, int ldp, float* z, float* logi
                            no, rows_total, row_offset, stride, anc, dv);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
+}
+
+extern "C" int icaf_detect_conv(const icaf_conv_args* a, float* z, float* logits, float* raw, int na, int no, long long rows_total,
+                                long long row_offset, float stride, const float* anchors_px, icaf_stream_t s) {
+    if (!a || !z || !anchors_px) return fail(ICAF_ERR_ARG, "icaf_detect_conv: null pointer");
+    ConvP p;
+    int st = conv_prepare(a, p);
+    if (st) return st;
+    if (a->dtype == ICAF_F32) return fail(ICAF_ERR_UNSUPPORTED, "icaf_detect_conv: 16-bit feature maps (the fp32 build runs icaf_conv2d + icaf_detect_decode)");
+    if (a->kh != 1 || a->kw != 1 || a->sh != 1 || a->sw != 1 || a->ph || a->pw || a->groups != 1 || a->res || a->pre || a->w2 || a->act != ICAF_ACT_NONE)
+        return fail(ICAF_ERR_ARG, "icaf_detect_conv: a plain 1x1 convolution without activation is expected");
+    if ((a->Cin * 2) % 128 || p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "icaf_detect_conv: Cin * 2 bytes must be a multiple of 128 (Cin = %d)", a->Cin);
+    if (na != 3 || (no != 6 && no != 8 && no != 14) || a->Cout != na * no) return fail(ICAF_ERR_UNSUPPORTED, "icaf_detect_conv: built for 3 anchors, no in {6, 8, 14} (na = %d, no = %d, Cout = %d)", na, no, a->Cout);
+    if (row_offset + (long long)na * a->Ho * a->Wo > rows_total) return fail(ICAF_ERR_ARG, "icaf_detect_conv: level does not fit in z");
+    if (((uintptr_t)z & 7) || (raw && ((uintptr_t)raw & 7))) return fail(ICAF_ERR_ARG, "icaf_detect_conv: z / raw must be 8-byte aligned");
+    if ((long long)a->B * a->Ho * a->Wo >= (1ll << 31)) return fail(ICAF_ERR_UNSUPPORTED, "icaf_detect_conv: too many pixels");
+    Anchors anc;
+    for (int i = 0; i < 16; ++i) anc.v[i] = i < 2 * na ? anchors_px[i] : 0.0f;
+    const FastDiv dnx = make_fastdiv((unsigned)a->Wo), dny = make_fastdiv((unsigned)a->Ho);
+#define ICAF_DETECT_CONV(NO_)                                                                                                              \
+    {                                                                                                                                      \
+        DetectEpi<3, NO_> epi{z, logits, raw, p.M, a->Ho, a->Wo, rows_total, row_offset, stride, anc, dnx, dny};                           \
+        return a->dtype == ICAF_BF16 ? launch_detect_conv<ICAF_BF16, 3, NO_>(p, epi, S(s)) : launch_detect_conv<ICAF_F16, 3, NO_>(p, epi, S(s)); \
+    }
+    if (no == 6) ICAF_DETECT_CONV(6)
+    if (no == 8) ICAF_DETECT_CONV(8)
+    ICAF_DETECT_CONV(14)
+#undef ICAF_DETECT_CONV
 }

@@ -679,6 +679,14 @@ static void fill(const icaf_conv_args* a, ConvP& p) {
     p.w2_bytes = a->w2 ? (unsigned)((((long long)a->Cout2 + 127) / 128 * 128) * a->Kp2 * eb) : 0;
 }
 
+// validate + fill for the other translation units that run a convolution through their own kernel (detect.hip)
+int conv_prepare(const icaf_conv_args* a, ConvP& p) {
+    int st = validate(a);
+    if (st) return st;
+    fill(a, p);
+    return ICAF_OK;
+}
+
 }  // namespace icaf
 
 using namespace icaf;

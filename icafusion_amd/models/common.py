@@ -870,6 +870,9 @@ class Detect(HipModule):
     kernel that writes z / logits / the permuted raw map directly in their final layouts."""
     stride = None
     export = False
+    # 16-bit plans: a level's 1x1 conv and its decode run as ONE launch (icaf_detect_conv; ICAF_DETECT_FUSE=0: A/B switch).  A class
+    # default: un-pickled reference checkpoints never run this constructor (DESIGN.md section 1).
+    fuse_decode = os.environ.get("ICAF_DETECT_FUSE", "1") != "0"
 
     def __init__(self, nc=80, anchors=(), ch=()):
         super().__init__()
@@ -909,10 +912,16 @@ class Detect(HipModule):
                 wp, kp = ops.pack_conv_weight(conv.weight.detach().float(), plan.dtype)
                 return wp, kp, ops.pack_bias(conv.bias.detach().float(), conv.out_channels)
             wp, kp, bp = self._cached(("det", l, plan.dtype, plan.device), make)
+            raw = plan.empty((B, self.na, ny, nx, self.no), torch.float32)
+            if self.fuse_decode and ops.detect_conv_ok(x, self.na, self.no, c):
+                # 16-bit maps: conv + decode in ONE launch (icaf_detect_conv) - the fp32 conv map never reaches HBM
+                plan.add(ops.detect_conv(x, wp, kp, bp, z, logits, raw, self.na, self.no, off, strides[l], ag[l].tolist(), c))
+                raws.append(raw)
+                off += self.na * ny * nx
+                continue
             # pixel stride padded to a 16-byte multiple (18 -> 20 floats): the conv epilogue then leaves 16-byte stores instead of scalar ones
             p = plan.act(B, ny, nx, (nout + 3) // 4 * 4, dtype=torch.float32)[..., :nout]
             plan.add(ops.conv2d(x, wp, kp, bp, p, 1, 1, 1, 1, 0, 0, c, nout, ops.ACT_NONE, name="detect_conv"))
-            raw = plan.empty((B, self.na, ny, nx, self.no), torch.float32)
             plan.add(ops.detect_decode(p, z, logits, raw, self.na, self.no, off, strides[l], ag[l].tolist()))
             raws.append(raw)
             off += self.na * ny * nx

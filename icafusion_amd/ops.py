@@ -585,6 +585,35 @@ def detect_decode(p, z, logits, raw, na, no, row_offset, stride, anchors_px, nam
                    float(stride), arr), keep=(p, z, logits, raw, arr), name=name, nbytes=nb)
 
 
+def detect_conv_ok(x, na, no, cin):
+    """Can icaf_detect_conv (Detect level in one launch) take this level?  16-bit maps, 3 anchors, no in {6, 8, 14}, Cin * 2 % 128 == 0."""
+    return x.dtype in (torch.bfloat16, torch.float16) and na == 3 and no in (6, 8, 14) and (cin * 2) % 128 == 0 and x.dim() == 4
+
+
+def detect_conv(x, w_packed, kp, bias, z, logits, raw, na, no, row_offset, stride, anchors_px, cin, name="detect_conv+decode"):
+    """One Detect level in ONE launch (icaf_detect_conv): x (B, ny, nx, >= cin) 16-bit act -> z (B, rows_total, no), logits, raw; the
+    1x1 output conv (packed weights / bias as for conv2d) runs as the persistent streaming GEMM with the decode as its epilogue."""
+    B, ny, nx, cx, ldx = _act_geom(x)
+    assert cx >= cin and z.dtype == torch.float32 and z.is_contiguous() and w_packed.dtype == x.dtype
+    a = ConvArgs()
+    a.x, a.w, a.bias = x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None
+    a.y = z.data_ptr()                                   # (never written: icaf_conv_args wants a non-null y)
+    a.groups = 1
+    a.B, a.H, a.W, a.Cin, a.ldx = B, ny, nx, cin, ldx
+    a.Ho, a.Wo, a.Cout, a.ldy = ny, nx, na * no, na * no
+    a.kh = a.kw = a.sh = a.sw = 1
+    a.Kp, a.act = kp, ACT_NONE
+    a.dtype, a.out_dtype = dtype_code(x.dtype), F32
+    a.alpha_acc[0] = a.alpha_acc[1] = 1.0
+    arr = (C.c_float * (2 * na))(*[float(v) for v in anchors_px])
+    m = B * ny * nx
+    nb = m * cin * x.element_size() + 3 * m * na * no * 4
+    return Launch(lib().icaf_detect_conv,
+                  (C.byref(a), z.data_ptr(), logits.data_ptr() if logits is not None else None, raw.data_ptr() if raw is not None else None,
+                   na, no, z.shape[1], row_offset, float(stride), arr), keep=(a, x, w_packed, bias, z, logits, raw, arr), name=name,
+                  flops=2.0 * m * na * no * cin, nbytes=nb)
+
+
 class NmsRunner:
     """Pre-allocated NMS launch for a fixed (B, rows, nc) — graph-capturable; results stay on the device."""
 

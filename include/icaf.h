@@ -222,6 +222,12 @@ int icaf_dmff_upsample_merge(const void* tokens, const void* fea_rgb, int ld_rgb
 int icaf_detect_decode(const float* p, int ldp, float* z, float* logits, float* raw, int B, int ny, int nx, int na,
                        int no, long long rows_total, long long row_offset, float stride, const float* anchors_px,
                        icaf_stream_t s);
+/* A Detect level in ONE launch (16-bit feature maps, 3 anchors, no in {6, 8, 14}): the level's 1x1 output convolution
+ * (models/yolo_test.py:50; `a` describes it as for icaf_conv2d: 1x1, no activation, groups 1, Cout = na * no; a->y is ignored)
+ * with the decode above as the epilogue of the persistent streaming GEMM — the fp32 conv map is never written.  z / logits / raw
+ * are bit-identical to icaf_conv2d (fp32 out) followed by icaf_detect_decode. */
+int icaf_detect_conv(const icaf_conv_args* a, float* z, float* logits, float* raw, int na, int no, long long rows_total,
+                     long long row_offset, float stride, const float* anchors_px, icaf_stream_t s);
 
 /* ---- fused DMFF block (16-bit token types) -------------------------------------------------------------------
  * One CrossTransformerBlock iteration (models/common.py:737-759) in two launches:

@@ -41,7 +41,7 @@ def _check_loaded(m, yaml_names):
     for dtype in (torch.float32, torch.bfloat16):
         plan = m.build_plan(2, 320, 352, "cpu", dtype)
         names = [l.name for l in plan.launches]
-        assert len(names) > 40 and names[-1] == "detect_decode"
+        assert len(names) > 40 and names[-1] == ("detect_decode" if dtype == torch.float32 else "detect_conv+decode")
         assert names.count("cross_attention") + names.count("dmff_attn_mlp") == 3
         assert ("dmff_attn_mlp" in names) == (dtype != torch.float32)          # 16-bit: the fused block kernels at the narrow levels
     m.compute_dtype, m.use_graph = torch.bfloat16, True           # what test.py / detect_twostream.py do after loading

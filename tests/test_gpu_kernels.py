@@ -826,6 +826,39 @@ def test_detect_decode(nc, path, monkeypatch):
         assert torch.equal(a.cpu(), b)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nc", [1, 3, 9])
+def test_detect_level_in_one_launch(nc, dt):
+    """icaf_detect_conv (the level's 1x1 conv as the persistent streaming GEMM with the decode as its epilogue) must give the SAME
+    BITS — z, logits, raw — as icaf_conv2d (fp32 out) followed by icaf_detect_decode, on every level shape of a plan: many pixel
+    tiles per workgroup (80 x 80 x 6 images), fewer tiles than workgroups (20 x 20), a ragged last tile."""
+    B, na, no = 6, 3, nc + 5
+    anchors = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+    dims = [(80, 80, 128), (37, 41, 256), (20, 20, 512)]
+    rows = sum(na * h * w for h, w, _ in dims)
+    zs = [torch.zeros((B, rows, no), dtype=torch.float32, device=DEV) for _ in range(2)]
+    lgs = [torch.zeros((B, rows, nc), dtype=torch.float32, device=DEV) for _ in range(2)]
+    raws, off = [[], []], 0
+    for l, (h, w, c) in enumerate(dims):
+        x = to_act(rnd((B, c, h, w), 70 + l), dt, pad_to=c + 16)
+        wt = rnd((na * no, c, 1, 1), 80 + l, 2.0 / math.sqrt(c))
+        bias = rnd((na * no,), 90 + l, 1.0)
+        wp, kp = ops.pack_conv_weight(wt.to(DEV), dt)
+        bp = ops.pack_bias(bias.to(DEV), na * no)
+        assert ops.detect_conv_ok(x, na, no, c)
+        r1 = torch.zeros((B, na, h, w, no), dtype=torch.float32, device=DEV)
+        run(ops.detect_conv(x, wp, kp, bp, zs[0], lgs[0], r1, na, no, off, oracle.STRIDES[l], anchors[l], c))
+        pmap = torch.zeros((B, h, w, (na * no + 3) // 4 * 4), dtype=torch.float32, device=DEV)[..., :na * no]
+        r2 = torch.zeros_like(r1)
+        run(ops.conv2d(x, wp, kp, bp, pmap, 1, 1, 1, 1, 0, 0, c, na * no, ops.ACT_NONE))
+        run(ops.detect_decode(pmap, zs[1], lgs[1], r2, na, no, off, oracle.STRIDES[l], anchors[l]))
+        raws[0].append(r1); raws[1].append(r2)
+        off += na * h * w
+    assert torch.equal(zs[0], zs[1]) and torch.equal(lgs[0], lgs[1])
+    assert all(torch.equal(a, b) for a, b in zip(*raws))
+    assert float(zs[0].abs().max()) > 1.0 and float(lgs[0].abs().max()) > 0.0
+
+
 def _rand_pred(B, rows, nc, seed, ties=False):
     g = np.random.default_rng(seed)
     xy = g.uniform(0, 640, (B, rows, 2))

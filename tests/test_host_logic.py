@@ -147,6 +147,10 @@ def test_pmc_summary_kernel_names_match_bench_names():
         "void icaf::stem_kernel<1, 32, false>(icaf::StemP)": "stem",
         "void icaf::pool_tokens_rows_kernel<1, 12>(icaf::Elem<1>::type const*, int)": "dmff_pool_tokens",
         "void icaf::detect_pixel_kernel<3, 6>(float const*, int, float*)": "detect_decode",
+        "void icaf::igemm_stream_kernel<1, 128, 1>(icaf::ConvP)": "igemm_stream_bf16_128x128",
+        "void icaf::igemm_stream_kernel<2, 64, 0>(icaf::ConvP)": "igemm_stream_f16_128x64",
+        "void icaf::igemm_wreg_kernel<1, 8, 1, 2>(icaf::ConvP, void const*, long long)": "igemm_wreg_bf16_128x256",
+        "void icaf::detect_conv_kernel<1, 3, 6>(icaf::ConvP, icaf::DetectEpi<3, 6>)": "detect_conv+decode",
         "void icaf::detect_decode_kernel<true>(float const*, int, float*)": "detect_decode",
         "void icaf::upsample_kernel<true>(unsigned int __vector(4) const*, int)": "upsample_nearest",
         "void icaf::pool_tokens_kernel<1>(icaf::Elem<1>::type const*, int)": "dmff_pool_tokens",

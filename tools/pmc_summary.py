@@ -24,6 +24,16 @@ def short(name):
         dt, odt, bm, bn, wm, wn, rb, ns = map(int, m.groups())
         w8 = "w8" if bm == 128 and (bm // wm) * (bn // wn) == 8 else ""          # 8-wavefront build of a 128-row tile
         return f"igemm_dma{rb}x{ns}_{_DN[dt]}_{_DN[odt]}_{bm}x{bn}{w8}"
+    m = re.match(r"icaf::igemm_stream_kernel<(\d+), (\d+), \d+>", name)          # persistent streaming GEMM (1x1 layers)
+    if m:
+        dt, bn = map(int, m.groups())
+        return f"igemm_stream_{_DN[dt]}_128x{bn}"
+    m = re.match(r"icaf::igemm_wreg_kernel<(\d+), (\d+), \d+, \d+>", name)     # weight operand fed from registers
+    if m:
+        dt, nwv = map(int, m.groups())
+        return f"igemm_wreg_{_DN[dt]}_128x{32 * nwv}"
+    if name.startswith("icaf::detect_conv_kernel<"):
+        return "detect_conv+decode"
     m = re.match(r"icaf::igemm_kernel<(\d+), (\d+), (\d+), (\d+),", name)
     if m:
         dt, odt, bm, bn = map(int, m.groups())
