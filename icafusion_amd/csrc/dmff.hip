@@ -19,13 +19,17 @@ static inline unsigned grid_for(long long total) {
 // ---------------------------------------------------------------------------------------------------------------
 // tokens[g][b][n][c] = w1_g * avgpool + w2_g * maxpool + pos_g[n][c]     (reference models/common.py:817-823,868-891)
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT>
+// I32: the flat index fits 31 bits (every configuration in use) and is taken apart with FastDiv (icaf_common.h) instead of 64-bit
+// divisions; the window is walked row by row instead of dividing the tap index by kw — at 4x4 windows (P3) the index arithmetic
+// was a third of the kernel's instructions.
+struct PoolDiv { FastDiv nv, N, tw; };
+template <int DT, bool I32>
 __global__ __launch_bounds__(256) void pool_tokens_kernel(const typename Elem<DT>::type* __restrict__ f0, int ld0,
                                                           const typename Elem<DT>::type* __restrict__ f1, int ld1,
                                                           const float* __restrict__ pos0, const float* __restrict__ pos1,
                                                           typename Elem<DT>::type* __restrict__ tok, int B, int H, int W, int C, int th,
                                                           int tw, int kh, int kw, int sh, int sw, float w1_0, float w2_0, float w1_1,
-                                                          float w2_1) {
+                                                          float w2_1, PoolDiv dv) {
     using E = Elem<DT>;
     const int nv = C / E::VEC, N = th * tw;
     const long long per_g = (long long)B * N * nv, total = 2 * per_g;
@@ -33,10 +37,19 @@ __global__ __launch_bounds__(256) void pool_tokens_kernel(const typename Elem<DT
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int g = idx >= per_g;
         const long long r = idx - (g ? per_g : 0);
-        const int v = (int)(r % nv);
-        const long long bn = r / nv;
-        const int n = (int)(bn % N), b = (int)(bn / N);
-        const int oy = n / tw, ox = n - oy * tw;
+        int v, n, b, oy, ox;
+        if constexpr (I32) {
+            unsigned int bn, uv, un, ub, uoy, uox;
+            fd_divmod((unsigned int)r, dv.nv, bn, uv);
+            fd_divmod(bn, dv.N, ub, un);
+            fd_divmod(un, dv.tw, uoy, uox);
+            v = (int)uv; n = (int)un; b = (int)ub; oy = (int)uoy; ox = (int)uox;
+        } else {
+            v = (int)(r % nv);
+            const long long bn = r / nv;
+            n = (int)(bn % N); b = (int)(bn / N);
+            oy = n / tw; ox = n - oy * tw;
+        }
         const typename E::type* f = g ? f1 : f0;
         const int ld = g ? ld1 : ld0;
         float sum[E::VEC], mx[E::VEC];
@@ -44,25 +57,23 @@ __global__ __launch_bounds__(256) void pool_tokens_kernel(const typename Elem<DT
         for (int j = 0; j < E::VEC; ++j) { sum[j] = 0.0f; mx[j] = -INFINITY; }
         // the window is walked in (dy, dx) order, four loads in flight at a time: with one load per iteration the
         // 100-pixel windows of P4 (10x10, stride 2) were a chain of 100 L2 round trips per thread
-        const int area = kh * kw;
+        // (same (dy, dx) order and the same additions as before: the sums are bit-identical)
         const typename E::type* f00 = f + (((long long)b * H + oy * sh) * W + ox * sw) * ld + v * E::VEC;
-        for (int i0 = 0; i0 < area; i0 += 4) {
-            u32x4 raw[4];
+        for (int dy = 0; dy < kh; ++dy) {
+            const typename E::type* frow = f00 + (long long)dy * W * ld;
+            for (int dx0 = 0; dx0 < kw; dx0 += 4) {
+                u32x4 raw[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u;
-                if (i < area) {
-                    const int dy = i / kw, dx = i - dy * kw;
-                    raw[u] = *(const u32x4*)(f00 + ((long long)dy * W + dx) * ld);
-                }
-            }
+                for (int u = 0; u < 4; ++u)
+                    if (dx0 + u < kw) raw[u] = *(const u32x4*)(frow + (long long)(dx0 + u) * ld);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (i0 + u < area) {
-                    float t[E::VEC];
-                    unpack16<DT>(raw[u], t);
+                for (int u = 0; u < 4; ++u) {
+                    if (dx0 + u < kw) {
+                        float t[E::VEC];
+                        unpack16<DT>(raw[u], t);
 #pragma unroll
-                    for (int j = 0; j < E::VEC; ++j) { sum[j] += t[j]; mx[j] = fmaxf(mx[j], t[j]); }
+                        for (int j = 0; j < E::VEC; ++j) { sum[j] += t[j]; mx[j] = fmaxf(mx[j], t[j]); }
+                    }
                 }
             }
         }
@@ -552,8 +563,13 @@ int run_pool_tokens(const void* f0, int ld0, const void* f1, int ld1, const floa
         return ICAF_OK;
     }
     const long long total = 2LL * B * th * tw * (C / Elem<DT>::VEC);
-    pool_tokens_kernel<DT><<<dim3(grid_for(total)), dim3(256), 0, s>>>((const T*)f0, ld0, (const T*)f1, ld1, p0, p1, (T*)tok, B, H, W, C, th,
-                                                                        tw, kh, kw, sh, sw, a0, b0, a1, b1);
+    const PoolDiv dv{make_fastdiv((unsigned)(C / Elem<DT>::VEC)), make_fastdiv((unsigned)(th * tw)), make_fastdiv((unsigned)tw)};
+    if (total < (1ll << 31))
+        pool_tokens_kernel<DT, true><<<dim3(grid_for(total)), dim3(256), 0, s>>>((const T*)f0, ld0, (const T*)f1, ld1, p0, p1, (T*)tok, B, H, W, C,
+                                                                                  th, tw, kh, kw, sh, sw, a0, b0, a1, b1, dv);
+    else
+        pool_tokens_kernel<DT, false><<<dim3(grid_for(total)), dim3(256), 0, s>>>((const T*)f0, ld0, (const T*)f1, ld1, p0, p1, (T*)tok, B, H, W, C,
+                                                                                   th, tw, kh, kw, sh, sw, a0, b0, a1, b1, dv);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }

@@ -178,33 +178,52 @@ __global__ __launch_bounds__(256) void sppf_lds_kernel(const typename Elem<DT>::
     const int b = blockIdx.x / nvb, vg = blockIdx.x - b * nvb;
     const int n = H * W * vpb, r = k / 2;
     const long long pix0 = (long long)b * H * W;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int v = i % vpb, p = i / vpb;
-        cur[i] = PM::in(*(const u32x4*)(x + (pix0 + p) * ldx + (vg * vpb + v) * E::VEC));
+    // Item i = (pixel p, vector v) -> (v, x, y) is the same in all seven passes: taken apart ONCE per thread (the launcher caps the
+    // plane at 60 KB = 1920 items, i.e. at most MAXIT items per thread) instead of four integer divisions per item and pass, which
+    // cost more instructions than the pass's LDS traffic.
+    constexpr int MAXIT = 8;
+    short iv[MAXIT], ix[MAXIT], iy[MAXIT];
+#pragma unroll
+    for (int t = 0; t < MAXIT; ++t) {
+        const int i = threadIdx.x + t * 256;
+        const int ii = i < n ? i : 0;
+        const int v = ii % vpb, pp = ii / vpb;
+        iv[t] = (short)v; ix[t] = (short)(pp % W); iy[t] = (short)(pp / W);
+    }
+#pragma unroll
+    for (int t = 0; t < MAXIT; ++t) {
+        const int i = threadIdx.x + t * 256;
+        if (i < n) cur[i] = PM::in(*(const u32x4*)(x + (pix0 + iy[t] * W + ix[t]) * ldx + (vg * vpb + iv[t]) * E::VEC));
     }
     __syncthreads();
     typename E::type* outs[3] = {y1, y2, y3};
 #pragma unroll
     for (int stage = 0; stage < 3; ++stage) {
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const int v = i % vpb, p = i / vpb, xx = p % W, yy = p / W;
+#pragma unroll
+        for (int t = 0; t < MAXIT; ++t) {
+            const int i = threadIdx.x + t * 256;
+            if (i >= n) continue;
+            const int xx = ix[t];
             u32x4 m = cur[i];
             for (int d = -r; d <= r; ++d) {
                 if (d == 0 || (unsigned)(xx + d) >= (unsigned)W) continue;
-                m = PM::mx(m, cur[(yy * W + xx + d) * vpb + v]);
+                m = PM::mx(m, cur[i + d * vpb]);
             }
             tmp[i] = m;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const int v = i % vpb, p = i / vpb, xx = p % W, yy = p / W;
+#pragma unroll
+        for (int t = 0; t < MAXIT; ++t) {
+            const int i = threadIdx.x + t * 256;
+            if (i >= n) continue;
+            const int yy = iy[t];
             u32x4 m = tmp[i];
             for (int d = -r; d <= r; ++d) {
                 if (d == 0 || (unsigned)(yy + d) >= (unsigned)H) continue;
-                m = PM::mx(m, tmp[((yy + d) * W + xx) * vpb + v]);
+                m = PM::mx(m, tmp[i + d * W * vpb]);
             }
             cur[i] = m;
-            *(u32x4*)(outs[stage] + (pix0 + p) * ldy + (vg * vpb + v) * E::VEC) = PM::out(m);
+            *(u32x4*)(outs[stage] + (pix0 + yy * W + ix[t]) * ldy + (vg * vpb + iv[t]) * E::VEC) = PM::out(m);
         }
         __syncthreads();
     }
