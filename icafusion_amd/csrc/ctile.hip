@@ -17,6 +17,12 @@
 // 32..256 bytes per pixel, Cout <= BN, SiLU, out dtype == dtype.
 #include "conv_common.h"
 
+// Ablation switches for timing studies (tools/quick_variant.py -DICAF_CTILE_ABL=n; results are then meaningless):
+//   1 = no halo-patch DMA, 2 = no weight-ring DMA, 4 = no LDS fragment reads in the 3x3 loop, 8 = no MFMAs in the 3x3 loop
+#ifndef ICAF_CTILE_ABL
+#define ICAF_CTILE_ABL 0
+#endif
+
 namespace icaf {
 
 template <int S, int TW> struct HaloGeom {
@@ -97,7 +103,8 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
             const int gy = gy0 + hy, gx = gx0 + hx;
             const bool ok = hy < HH && hx < HWD && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             const unsigned voff = ok ? img_off + (unsigned)((gy * p.W + gx) * p.ldx) * E::BYTES + (unsigned)(cs << 4) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(xpatch + (j << 10)), 16, voff, 0, 0, 0);
+            if constexpr (!(ICAF_CTILE_ABL & 1))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(xpatch + (j << 10)), 16, voff, 0, 0, 0);
         }
     }
 
@@ -112,7 +119,8 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
             const unsigned voff = cvalid ? w_off0 + (unsigned)chunk * RB + (unsigned)(32 * i) * (unsigned)p.Kp * E::BYTES : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + (wave + 4 * i) * 1024), 16, voff, 0, 0, 0);
+            if constexpr (!(ICAF_CTILE_ABL & 2))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + (wave + 4 * i) * 1024), 16, voff, 0, 0, 0);
         }
     };
 
@@ -237,14 +245,21 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
                 for (int bb = 0; bb < TM; ++bb) {
                     const int idx = lbase[bb] + toff;
                     const int slot = (idx << lsp) + ((csl ^ (idx >> gsh)) & cin_slots_mask);
-                    fp[bb] = *(const u32x4*)(halo + (slot << 4));
+                    if constexpr (ICAF_CTILE_ABL & 4) fp[bb] = u32x4{(unsigned)slot, (unsigned)c, 0x3f803f80u, 0x3f803f80u};
+                    else fp[bb] = *(const u32x4*)(halo + (slot << 4));
                 }
 #pragma unroll
-                for (int a = 0; a < TN; ++a) fw[a] = *(const u32x4*)(b_s + (a * 32) * RB + foff[s]);
+                for (int a = 0; a < TN; ++a) {
+                    if constexpr (ICAF_CTILE_ABL & 4) fw[a] = u32x4{(unsigned)foff[s], (unsigned)(c + a), 0x3f803f80u, 0x3f803f80u};
+                    else fw[a] = *(const u32x4*)(b_s + (a * 32) * RB + foff[s]);
+                }
 #pragma unroll
                 for (int a = 0; a < TN; ++a)
 #pragma unroll
-                    for (int bb = 0; bb < TM; ++bb) mma_step<DT>(acc[a][bb], fw[a], fp[bb]);
+                    for (int bb = 0; bb < TM; ++bb) {
+                        if constexpr (ICAF_CTILE_ABL & 8) { acc[a][bb][0] += __uint_as_float(fw[a][0] ^ fp[bb][0]); }
+                        else mma_step<DT>(acc[a][bb], fw[a], fp[bb]);
+                    }
             }
         }
     }

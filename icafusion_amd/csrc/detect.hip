@@ -205,7 +205,7 @@ struct DetectEpi {
 
 template <int DT, int NA, int NO>
 __global__ __launch_bounds__(512) void detect_conv_kernel(const ConvP p, const DetectEpi<NA, NO> epi) {
-    stream_gemm<DT, 64>(p, epi);
+    stream_gemm<DT, 64, 1>(p, epi);
 }
 
 template <int DT, int NA, int NO>

@@ -1,5 +1,5 @@
-// Persistent streaming GEMM for the 1x1 / stride-1 layers (stream_core.h): the plain layer epilogue — bias + activation, rounded to
-// the storage type, 16-byte NHWC stores — and the host side of tile ids 51 / 52.  (detect.hip instantiates the same core with the
+// Persistent streaming implicit GEMM (stream_core.h): the plain layer epilogue — bias + activation, rounded to the storage type,
+// optional residual (the Bottleneck shortcut / coefficient mixes), 16-byte NHWC stores — and the host side of tile ids 51 / 52.  (detect.hip instantiates the same core with the
 // Detect head's decode as its epilogue.)
 #include "stream_core.h"
 
@@ -10,6 +10,7 @@ struct StoreEpi {
     using E = Elem<DT>;
     static constexpr int SO = BN * E::BYTES + 16;
     typename E::type* yg; float alpha_acc; int M, Cout, ldy;
+    const typename E::type* rg; float alpha_res; int ldr;           // residual (nullptr = none); may alias yg (in-place Bottleneck chain)
     template <int TM>
     __device__ __forceinline__ void stage(const f32x16 (&acc)[TM], const f32x4 (&bq)[4], unsigned char* stg, int row0, int col0, int l31, int hi) const {
 #pragma unroll
@@ -36,18 +37,29 @@ struct StoreEpi {
             const int idx = tid + itv * 512;
             const int row = idx / VPR, cv = idx - row * VPR;
             const int m = m0 + row, n = n0 + cv * E::VEC;
-            const u32x4 sv = *(const u32x4*)(stg + row * SO + cv * 16);
-            if (m < M && n < Cout) *(u32x4*)(yg + (long long)m * ldy + n) = sv;
+            u32x4 sv = *(const u32x4*)(stg + row * SO + cv * 16);
+            if (m < M && n < Cout) {
+                if (rg) {                              // the shared epilogue's arithmetic (conv_common.h): staged value + alpha_res * residual
+                    float v[E::VEC], r[E::VEC];
+                    unpack16<DT>(sv, v);
+                    unpack16<DT>(*(const u32x4*)(rg + (long long)m * ldr + n), r);
+#pragma unroll
+                    for (int j = 0; j < E::VEC; ++j) v[j] = __builtin_fmaf(alpha_res, r[j], v[j]);
+                    sv = pack16<DT>(v);
+                }
+                *(u32x4*)(yg + (long long)m * ldy + n) = sv;
+            }
         }
     }
 };
 
-template <int DT, int BN, int ACT>
+template <int DT, int BN, int ACT, int MODE>
 __global__ __launch_bounds__(512) void igemm_stream_kernel(const ConvP p) {
     using E = Elem<DT>;
     const int g = blockIdx.z;
-    const StoreEpi<DT, BN, ACT> epi{(typename E::type*)p.y + g * p.y_gs, p.alpha_acc[g], p.M, p.Cout, p.ldy};
-    stream_gemm<DT, BN>(p, epi);
+    const StoreEpi<DT, BN, ACT> epi{(typename E::type*)p.y + g * p.y_gs, p.alpha_acc[g], p.M, p.Cout, p.ldy,
+                                    p.res ? (const typename E::type*)p.res + g * p.res_gs : nullptr, p.alpha_res[g], p.ldr};
+    stream_gemm<DT, BN, MODE>(p, epi);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -58,9 +70,9 @@ const char* stream_tag(int shape) { return shape == 1 ? "128x128" : shape == 2 ?
 int stream_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     if (shape < 1 || shape > 2) return fail(ICAF_ERR_ARG, "igemm_stream: unknown shape %d", shape);
     if (a->dtype == ICAF_F32 || a->out_dtype != a->dtype) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: 16-bit types, out dtype == dtype");
-    if (a->kh != 1 || a->kw != 1 || a->sh != 1 || a->sw != 1 || a->ph != 0 || a->pw != 0) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: 1x1 / stride 1 layers only");
     if ((a->Cin * 2) % 128) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: Cin * 2 bytes must be a multiple of 128 (Cin = %d)", a->Cin);
-    if (a->res || a->pre || a->w2) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: no residual / pre-activation term / chained layer");
+    if (a->pre || a->w2) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: no pre-activation term / chained layer");
+    if (a->res && !p.vec_r) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: the residual must take 16-byte vectors");
     if (p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: operand exceeds the 2 GiB buffer-descriptor range");
     if (!p.vec_y || a->Cout % 8) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: y must take 16-byte vectors (ldy %% 8, Cout %% 8, alignment)");
     if (shape == 1 && a->Cout <= 64) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream 128x128: Cout = %d <= 64 (use 128x64)", a->Cout);
@@ -73,7 +85,7 @@ static int launch_stream_cfg(const ConvP& p, int groups, hipStream_t s) {
     ConvP q = p;
     q.mtiles = (p.M + 127) / 128;
     q.ntiles = (p.Cout + BN - 1) / BN;
-    q.nchunks = p.K / 64;                          // 128-byte slices of a 16-bit type (K = Cin is a multiple of 64)
+    q.nchunks = p.K / 64;                          // 128-byte slices of a 16-bit type (K = kh * kw * Cin is a multiple of 64)
     int dev = 0, cus = 256;
     ICAF_HIP(hipGetDevice(&dev));
     ICAF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -81,14 +93,19 @@ static int launch_stream_cfg(const ConvP& p, int groups, hipStream_t s) {
     const int wgx = grid >> 3;
     if (wgx < q.ntiles || wgx % q.ntiles) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: %d channel tiles do not divide the %d workgroups of an XCD", q.ntiles, wgx);
     // (fewer pixel tiles than pixel slots: the surplus workgroups find their range empty and exit)
-    static std::atomic<bool> attr{false};          // one flag per instantiation (one process drives one GPU)
-    if (!attr) {
-        ICAF_HIP(hipFuncSetAttribute((const void*)igemm_stream_kernel<DT, BN, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
-    }
-    igemm_stream_kernel<DT, BN, ACT><<<dim3((unsigned)grid, 1, (unsigned)groups), dim3(512), LDS, s>>>(q);
-    ICAF_LAUNCH_CHECK();
-    return ICAF_OK;
+    const bool plain = q.kh == 1 && q.kw == 1 && q.sh == 1 && q.sw == 1 && q.ph == 0 && q.pw == 0;
+    auto go = [&](auto kern) -> int {
+        static std::atomic<bool> attr{false};      // one flag per instantiation (one process drives one GPU)
+        if (!attr) {
+            ICAF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            attr = true;
+        }
+        kern<<<dim3((unsigned)grid, 1, (unsigned)groups), dim3(512), LDS, s>>>(q);
+        ICAF_LAUNCH_CHECK();
+        return ICAF_OK;
+    };
+    if (plain) return go(igemm_stream_kernel<DT, BN, ACT, 1>);
+    return go(igemm_stream_kernel<DT, BN, ACT, 2>);
 }
 
 template <int DT, int BN>

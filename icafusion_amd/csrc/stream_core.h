@@ -30,7 +30,9 @@ namespace icaf {
 //   EPI::SO                        staging row stride in bytes (the workgroup's staging buffer is 128 rows)
 //   epi.stage(acc, bq, stg, row0, col0, l31, hi)   this lane's accumulator quads (+ bias bq) -> staging rows row0 + b * 32 + l31
 //   epi.flush(stg, m0, n0, tid)                    staging -> global memory, after an LDS-only barrier
-template <int DT, int BN, class EPI>
+// MODE 1: 1x1 / stride 1 / pad 0 — the pixel operand is a plain row-major matrix.  MODE 2: any filter with Cin * bytes a multiple of
+// 128 (a K slice lies inside ONE tap): igemm.hip's implicit-GEMM gather with a wave-uniform tap walk, restarted at every tile.
+template <int DT, int BN, int MODE, class EPI>
 __device__ __forceinline__ void stream_gemm(const ConvP& p, const EPI& epi) {
     using E = Elem<DT>;
     static_assert(DT != ICAF_F32, "16-bit types");
@@ -77,7 +79,9 @@ __device__ __forceinline__ void stream_gemm(const ConvP& p, const EPI& epi) {
 
     // issue cursor (runs NS - 1 .. NS slices ahead of the consume cursor)
     int it = m_first, ic = 0;
+    int kc = 0, ky = 0, kx = 0;                   // MODE 2: K position of the cursor's slice (wave-uniform): tap (ky, kx), channel kc
     unsigned ia_off[NA], iw_off[NB];
+    int ia_h0[NA], ia_w0[NA];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
         iw_off[i] = ((unsigned)(n0 + (wave + NW * i) * RPI + rsub) * (unsigned)p.Kp + (unsigned)(lslot * VEC)) * E::BYTES;
@@ -86,17 +90,36 @@ __device__ __forceinline__ void stream_gemm(const ConvP& p, const EPI& epi) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = it * BM + (wave + NW * i) * RPI + rsub;
-            ia_off[i] = (live && m < p.M) ? ((unsigned)m * (unsigned)p.ldx + (unsigned)(lslot * VEC)) * E::BYTES : OOB;
+            const bool ok = live && m < p.M;
+            if constexpr (MODE == 1) {
+                ia_off[i] = ok ? ((unsigned)m * (unsigned)p.ldx + (unsigned)(lslot * VEC)) * E::BYTES : OOB;
+            } else {
+                const int mm = ok ? m : 0;
+                const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, b = t / p.Ho;
+                ia_h0[i] = ok ? ho * p.sh - p.ph : -0x10000;                          // (dead rows: every tap fails the bounds test)
+                ia_w0[i] = wo * p.sw - p.pw;
+                ia_off[i] = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.ldx * (unsigned)E::BYTES
+                          + (unsigned)((ia_h0[i] * p.W + ia_w0[i]) * p.ldx + lslot * VEC) * E::BYTES;   // tap (0, 0) (may wrap below 0)
+            }
         }
     };
     // DMA instructions of the cursor's slice, portion `part` of NSTEP, into ring stage `stage`
     auto issue_part = [&](int stage, int part) {
         unsigned char* st = lds + stage * STAGE;
         const unsigned koff = (unsigned)ic * RB;
+        unsigned tap_delta = 0;
+        if constexpr (MODE == 2) tap_delta = (unsigned)((ky * p.W + kx) * p.ldx + kc) * E::BYTES;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (i % NSTEP != part) continue;
-            const unsigned voff = ia_off[i] == OOB ? OOB : ia_off[i] + koff;
+            unsigned voff;
+            if constexpr (MODE == 1) {
+                voff = ia_off[i] == OOB ? OOB : ia_off[i] + koff;
+            } else {
+                const int h = ia_h0[i] + ky, w = ia_w0[i] + kx;
+                const bool ok = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                voff = ok ? ia_off[i] + tap_delta : OOB;
+            }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
         }
 #pragma unroll
@@ -107,7 +130,15 @@ __device__ __forceinline__ void stream_gemm(const ConvP& p, const EPI& epi) {
         }
     };
     auto issue_advance = [&]() {                  // (wave-uniform)
-        if (++ic == nch) { ic = 0; it += mstride; issue_setup(); }
+        if constexpr (MODE == 2) {
+            kc += RB / E::BYTES;
+            if (kc >= p.Cin) { kc = 0; if (++kx == p.kw) { kx = 0; ++ky; } }
+        }
+        if (++ic == nch) {
+            ic = 0; kc = 0; ky = 0; kx = 0;
+            it += mstride;
+            issue_setup();
+        }
     };
 
     // bias of this lane's channels, in registers for the workgroup's whole life; consumed right here: otherwise the compiler's

@@ -266,9 +266,8 @@ def conv_candidates(a):
             cands.append(28)
         if a.Cout >= 256:
             cands.append(26)
-    if ((a.kh, a.kw, a.sh, a.sw, a.ph, a.pw) == (1, 1, 1, 1, 0, 0) and a.dtype != F32 and a.out_dtype == a.dtype and not a.pre and not a.w2
-            and not a.res and (a.Cin * 2) % 128 == 0 and a.Cout % 8 == 0 and STREAM_GEMM):
-        cands.append(52)                     # persistent streaming GEMM (igemm_stream.hip): 128 x 64 tile ...
+    if (a.dtype != F32 and a.out_dtype == a.dtype and not a.pre and not a.w2 and (a.Cin * 2) % 128 == 0 and a.Cout % 8 == 0 and STREAM_GEMM):
+        cands.append(52)                     # persistent streaming implicit GEMM (igemm_stream.hip): 128 x 64 tile ...
         if a.Cout > 64:
             cands.append(51)                 # ... and 128 x 128; a launch the shape rules out returns an error and is skipped
     if a.wf and not a.pre and not a.w2:

@@ -126,40 +126,49 @@ def test_conv2d(case, dt):
 
 
 STREAM_CASES = [
-    # B, H, W, cin, cout, act, groups, shape (tile id 50 + shape): persistent streaming GEMM for 1x1 layers (igemm_stream.hip)
-    (8, 80, 80, 128, 128, ops.ACT_SILU, 2, 1),      # C3 cv3 at 80x80, both backbones side by side: 6 tiles per workgroup
-    (8, 80, 80, 64, 64, ops.ACT_SILU, 2, 2),        # ONE 128-byte slice per tile, 128 x 64 tile
-    (12, 37, 41, 256, 256, ops.ACT_SILU, 1, 1),     # two channel tiles per pixel tile, 143 pixel tiles (1-2 per workgroup), ragged last one
-    (4, 40, 40, 512, 256, ops.ACT_NONE, 1, 1),      # K = 8 slices
-    (2, 64, 72, 128, 512, ops.ACT_GELU, 2, 1),      # four channel tiles, GELU (DMFF fc1)
-    (5, 33, 29, 192, 64, ops.ACT_SILU, 1, 2),       # K = 3 slices (odd), Cout = one 64-wide tile
-    (9, 40, 40, 1024, 512, ops.ACT_SILU, 1, 1),     # SPPF cv2: K = 16 slices
-    (6, 52, 52, 64, 136, ops.ACT_NONE, 1, 2),       # ragged N on the 128 x 64 tile (three channel tiles: rejected when they do not
-]                                                   # divide an XCD's workgroups - the test then expects the error)
+    # B, H, W, cin, cout, k, stride, act, use_res, groups, shape (tile id 50 + shape): persistent streaming implicit GEMM (igemm_stream.hip)
+    (8, 80, 80, 128, 128, 1, 1, ops.ACT_SILU, False, 2, 1),     # C3 cv3 at 80x80, both backbones side by side: 6 tiles per workgroup
+    (8, 80, 80, 64, 64, 1, 1, ops.ACT_SILU, False, 2, 2),       # ONE 128-byte slice per tile, 128 x 64 tile
+    (12, 37, 41, 256, 256, 1, 1, ops.ACT_SILU, False, 1, 1),    # two channel tiles per pixel tile, 143 pixel tiles (1-2 per workgroup), ragged last one
+    (4, 40, 40, 512, 256, 1, 1, ops.ACT_NONE, True, 1, 1),      # K = 8 slices, residual (DMFF fc2-like mix)
+    (2, 64, 72, 128, 512, 1, 1, ops.ACT_GELU, False, 2, 1),     # four channel tiles, GELU (DMFF fc1)
+    (5, 33, 29, 192, 64, 1, 1, ops.ACT_SILU, False, 1, 2),      # K = 3 slices (odd), Cout = one 64-wide tile
+    (9, 40, 40, 1024, 512, 1, 1, ops.ACT_SILU, False, 1, 1),    # SPPF cv2: K = 16 slices
+    (6, 52, 52, 64, 136, 1, 1, ops.ACT_NONE, False, 1, 2),      # three channel tiles do not divide an XCD's workgroups: rejected (checked below)
+    (8, 80, 80, 64, 64, 3, 1, ops.ACT_SILU, True, 2, 2),        # Bottleneck 3x3 + shortcut at 80x80, paired: the tap walk restarts per tile
+    (6, 41, 37, 128, 128, 3, 1, ops.ACT_SILU, False, 1, 1),     # 3x3, ragged map / last tile: taps leave the image on every side
+    (4, 80, 80, 64, 128, 3, 2, ops.ACT_SILU, False, 2, 1),      # stride 2 down-sampling conv
+    (3, 23, 31, 64, 64, 5, 2, ops.ACT_SILU, True, 1, 2),        # 5x5 / stride 2 / pad 2
+]
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", STREAM_CASES)
-def test_conv1x1_streaming_kernel(case, dt):
+def test_conv_streaming_kernel(case, dt):
     """igemm_stream.hip vs torch, and BIT-EXACT vs the implicit-GEMM kernel (same K order, MFMA step and epilogue expressions):
     a persistent workgroup walks several tiles through one DMA ring, so the cases cover several tiles per workgroup, ragged last
-    tiles, one to sixteen K slices per tile, one to four channel tiles, and the paired (groups = 2) launch."""
-    B, H, W, cin, cout, act, G, shape = case
+    tiles, one to sixteen K slices per tile, one to four channel tiles, 1x1 / 3x3 / 5x5 filters with stride and padding, residuals
+    and the paired (groups = 2) launch."""
+    B, H, W, cin, cout, k, st, act, use_res, G, shape = case
+    p_ = k // 2
+    Ho, Wo = (H + 2 * p_ - k) // st + 1, (W + 2 * p_ - k) // st + 1
     xs = [rnd((B, cin, H, W), 51 + g) for g in range(G)]
-    ws = [rnd((cout, cin, 1, 1), 53 + g, 1.0 / math.sqrt(cin)) for g in range(G)]
+    ws = [rnd((cout, cin, k, k), 53 + g, 1.0 / math.sqrt(cin * k * k)) for g in range(G)]
     bs = [rnd((cout,), 55 + g, 0.2) for g in range(G)]
+    rs = [rnd((B, cout, Ho, Wo), 57 + g) for g in range(G)] if use_res else None
     stk = (lambda t: torch.stack(t).contiguous()) if G == 2 else (lambda t: t[0])
     xa = stk([to_act(x, dt, pad_to=cin + 16) for x in xs])
     packs = [ops.pack_conv_weight(w.to(DEV), dt) for w in ws]
-    wp, kp = stk([p_[0] for p_ in packs]), packs[0][1]
+    wp, kp = stk([p0[0] for p0 in packs]), packs[0][1]
     bp = stk([ops.pack_bias(b.to(DEV), cout) for b in bs])
+    ra = stk([to_act(r, dt) for r in rs]) if use_res else None
     ldy = -(-cout // 8) * 8 + 8
     outs = []
     for tile in (50 + shape, 2):
-        ybuf = torch.full((G, B, H, W, ldy) if G == 2 else (B, H, W, ldy), 7.0, dtype=dt, device=DEV)
+        ybuf = torch.full((G, B, Ho, Wo, ldy) if G == 2 else (B, Ho, Wo, ldy), 7.0, dtype=dt, device=DEV)
         y = ybuf[..., :cout]
         try:
-            run(ops.conv2d(xa, wp, kp, bp, y, 1, 1, 1, 1, 0, 0, cin, cout, act, alpha_acc=0.75, tile=tile))
+            run(ops.conv2d(xa, wp, kp, bp, y, k, k, st, st, p_, p_, cin, cout, act, res=ra, alpha_acc=0.75, alpha_res=1.25, tile=tile))
         except ops._lib.IcafError as e:
             assert tile > 50 and "channel tiles do not divide" in str(e) and cout == 136, e
             return
@@ -167,18 +176,20 @@ def test_conv1x1_streaming_kernel(case, dt):
         outs.append(y.clone())
     assert torch.equal(outs[0], outs[1]), f"streaming kernel != igemm, max diff {(outs[0].float() - outs[1].float()).abs().max().item()}"
     for g in range(G):
-        ref = F.conv2d(q(xs[g], dt), q(ws[g], dt), bs[g])
+        ref = F.conv2d(q(xs[g], dt), q(ws[g], dt), bs[g], st, p_)
         ref = {ops.ACT_NONE: lambda t: t, ops.ACT_SILU: F.silu, ops.ACT_GELU: F.gelu}[act](ref) * 0.75
+        if use_res:
+            ref = ref + 1.25 * q(rs[g], dt)
         close(from_act(outs[0][g] if G == 2 else outs[0]), ref, dt, f"stream {case} group {g}")
 
 
-def test_conv1x1_streaming_kernel_rejects_other_layers():
-    x = torch.zeros((1, 32, 32, 64), dtype=torch.bfloat16, device=DEV)
-    w3 = rnd((64, 64, 3, 3), 1)
+def test_conv_streaming_kernel_rejects_other_layers():
+    x = torch.zeros((1, 32, 32, 32), dtype=torch.bfloat16, device=DEV)          # Cin * 2 bytes = 64: a K slice would straddle taps
+    w3 = rnd((64, 32, 3, 3), 1)
     wp, kp = ops.pack_conv_weight(w3.to(DEV), torch.bfloat16)
     y = torch.zeros((1, 32, 32, 64), dtype=torch.bfloat16, device=DEV)
     with pytest.raises(ops._lib.IcafError):
-        run(ops.conv2d(x, wp, kp, None, y, 3, 3, 1, 1, 1, 1, 64, 64, ops.ACT_SILU, tile=52))
+        run(ops.conv2d(x, wp, kp, None, y, 3, 3, 1, 1, 1, 1, 32, 64, ops.ACT_SILU, tile=52))
 
 
 WREG_CASES = [
