@@ -454,6 +454,9 @@ const char* ctile_tag(int shape);
 int stream_check(const icaf_conv_args* a, const ConvP& p, int shape);
 int launch_stream(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
 const char* stream_tag(int shape);
+// cstream.hip
+int cstream_check(const icaf_conv_args* a, const ConvP& p);
+int launch_cstream(const icaf_conv_args* a, const ConvP& p, hipStream_t s);
 // igemm_wreg.hip
 int wreg_check(const icaf_conv_args* a, const ConvP& p, int shape);
 int launch_wreg(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
@@ -461,10 +464,10 @@ const char* wreg_tag(int shape);
 
 //   40 + shape: 3x3 direct convolution from an LDS halo tile (ctile.hip); 50 + shape: persistent streaming GEMM for 1x1 layers
 //   (igemm_stream.hip); 60 + shape: weight operand fed from registers (igemm_wreg.hip); an explicit request that the layer cannot
-//   satisfy is an error (the autotuner skips it), it is never chosen silently.
+//   satisfy is an error (the autotuner skips it), it is never chosen silently.  71: persistent 3x3 with a resident filter (cstream.hip).
 static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
     const bool dma_ok = p.x_bytes != 0;
-    if (a->tile > 40 && a->tile < 70) return a->tile;
+    if (a->tile > 40 && a->tile < 80) return a->tile;
     if (a->tile >= 1 && a->tile <= 34 && a->tile % 10 >= 1 && a->tile % 10 <= 4) {
         const int pipe = a->tile / 10;
         return (pipe != 1 && !dma_ok) ? a->tile % 10 + 10 : a->tile;
@@ -698,6 +701,8 @@ extern "C" int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s) {
     fill(a, p);
     const int tile = pick_tile(a, p);
     hipStream_t hs = S(s);
+    if (tile == 71) return launch_cstream(a, p, hs);        // persistent 3x3 with the filter resident in LDS (64 -> 64 channels)
+    if (tile > 70) return fail(ICAF_ERR_ARG, "unknown tile id %d", tile);
     if (tile > 60) return launch_wreg(a, p, tile - 60, hs);
     if (tile > 50) return launch_stream(a, p, tile - 50, hs);
     if (tile > 40) return launch_ctile(a, p, tile - 40, hs);
@@ -734,6 +739,13 @@ extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int b
     fill(a, p);
     const int tile = pick_tile(a, p);
     static const char* dn[] = {"f32", "bf16", "f16"};
+    if (tile == 71) {
+        st = cstream_check(a, p);
+        if (st) return st;
+        snprintf(buf, buf_len, "cstream_%s_8x16n64", dn[a->dtype]);
+        return ICAF_OK;
+    }
+    if (tile > 70) return fail(ICAF_ERR_ARG, "unknown tile id %d", tile);
     if (tile > 60) {
         st = wreg_check(a, p, tile - 60);
         if (st) return st;

@@ -100,6 +100,7 @@ def pack_conv_weight(w4d, dt, cin_pad=None):
 
 
 _FRAG_CACHE = {}
+CSTREAM = os.environ.get("ICAF_CSTREAM", "1") != "0"           # A/B switch: persistent resident-filter 3x3 kernel as a tuner candidate
 WREG_GEMM = os.environ.get("ICAF_WREG_GEMM", "1") != "0"       # A/B switch: weights-from-registers kernels as tuner candidates
 
 
@@ -246,9 +247,13 @@ def conv_candidates(a):
     """Launch-configuration ids worth timing for one conv (ConvArgs `a`): igemm tiles x pipelines, the 8-wavefront tiles,
     the 3x3 halo-patch kernel; chained / pre-term launches only have the configurations that are built for them."""
     cands = []
+    cs_ok = ((a.kh, a.kw, a.sh, a.sw, a.ph, a.pw) == (3, 3, 1, 1, 1, 1) and a.Cin == 64 and a.Cout <= 64 and a.Cout % 8 == 0 and a.dtype != F32
+             and a.out_dtype == a.dtype and a.act == ACT_SILU and not a.pre and CSTREAM)
     if a.w2:                           # chained 1x1: one N tile covering both layers, LDS-DMA pipelines 0 / 2
         t = 2 if max(a.Cout, a.Cout2) <= 64 else 1
         cands = [t, t + 20]
+        if cs_ok and a.Cout == 64 and a.Cout2 <= 64:
+            cands.append(71)                 # persistent 3x3 with the filter (and the chained 1x1) resident in LDS (cstream.hip)
     elif a.pre:                          # pre-activation term: built for tiles 128x128 / 128x64 on the LDS-DMA pipelines 0 / 2
         cands = [t + 10 * pipe for pipe in (0, 2) for t in (1, 2) if not (t == 1 and (a.out_dtype == F32 or a.Cout <= 64))]
         if a.dtype != F32 and a.out_dtype == a.dtype and a.Cout >= 128 and (a.Cin * 2) % 128 == 0:
@@ -270,6 +275,8 @@ def conv_candidates(a):
         cands.append(52)                     # persistent streaming implicit GEMM (igemm_stream.hip): 128 x 64 tile ...
         if a.Cout > 64:
             cands.append(51)                 # ... and 128 x 128; a launch the shape rules out returns an error and is skipped
+    if cs_ok and not a.w2:
+        cands.append(71)
     if a.wf and not a.pre and not a.w2:
         cands.append(61)                     # weights fed from registers (igemm_wreg.hip): 128 x 128 ...
         if a.Cout > 128:

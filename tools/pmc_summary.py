@@ -32,6 +32,9 @@ def short(name):
     if m:
         dt, nwv = map(int, m.groups())
         return f"igemm_wreg_{_DN[dt]}_128x{32 * nwv}"
+    m = re.match(r"icaf::cstream_kernel<(\d+), (true|false)>", name)              # persistent 3x3, filter resident in LDS
+    if m:
+        return f"cstream_{_DN[int(m.group(1))]}_8x16n64" + ("+1x1" if m.group(2) == "true" else "")
     if name.startswith("icaf::detect_conv_kernel<"):
         return "detect_conv+decode"
     m = re.match(r"icaf::igemm_kernel<(\d+), (\d+), (\d+), (\d+),", name)
