@@ -256,4 +256,28 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 
+// Four consecutive channels of one token row (what a lane's accumulator quad holds) in the storage type: 8 bytes for the 16-bit
+// types, 16 bytes for fp32.
+template <int DT> struct Quad { using type = u32x2; };
+template <> struct Quad<ICAF_F32> { using type = u32x4; };
+template <int DT> __device__ __forceinline__ typename Quad<DT>::type pack4(float a, float b, float c, float d) {
+    typename Quad<DT>::type v;
+    if constexpr (DT == ICAF_F32) { v[0] = __float_as_uint(a); v[1] = __float_as_uint(b); v[2] = __float_as_uint(c); v[3] = __float_as_uint(d); }
+    else if constexpr (DT == ICAF_BF16) { v[0] = pack2_bf16(a, b); v[1] = pack2_bf16(c, d); }
+    else { v[0] = pack2_f16(a, b); v[1] = pack2_f16(c, d); }
+    return v;
+}
+template <int DT> __device__ __forceinline__ void unpack4(const typename Quad<DT>::type& v, float* f) {
+    if constexpr (DT == ICAF_F32) {
+        f[0] = __uint_as_float(v[0]); f[1] = __uint_as_float(v[1]); f[2] = __uint_as_float(v[2]); f[3] = __uint_as_float(v[3]);
+    } else if constexpr (DT == ICAF_BF16) {
+        f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xffff0000u);
+        f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xffff0000u);
+    } else {
+        f[0] = f16_to_f32((unsigned short)(v[0] & 0xffffu)); f[1] = f16_to_f32((unsigned short)(v[0] >> 16));
+        f[2] = f16_to_f32((unsigned short)(v[1] & 0xffffu)); f[3] = f16_to_f32((unsigned short)(v[1] >> 16));
+    }
+}
+
+
 }  // namespace icaf

@@ -120,28 +120,88 @@ template <int DT, int SLB> struct WS {
     }
 };
 
-// Four consecutive channels of one token row (what a lane's accumulator quad holds) in the storage type: 8 bytes for the 16-bit
-// types, 16 bytes for fp32.
-template <int DT> struct Quad { using type = u32x2; };
-template <> struct Quad<ICAF_F32> { using type = u32x4; };
-template <int DT> __device__ __forceinline__ typename Quad<DT>::type pack4(float a, float b, float c, float d) {
-    typename Quad<DT>::type v;
-    if constexpr (DT == ICAF_F32) { v[0] = __float_as_uint(a); v[1] = __float_as_uint(b); v[2] = __float_as_uint(c); v[3] = __float_as_uint(d); }
-    else if constexpr (DT == ICAF_BF16) { v[0] = pack2_bf16(a, b); v[1] = pack2_bf16(c, d); }
-    else { v[0] = pack2_f16(a, b); v[1] = pack2_f16(c, d); }
-    return v;
-}
-template <int DT> __device__ __forceinline__ void unpack4(const typename Quad<DT>::type& v, float* f) {
-    if constexpr (DT == ICAF_F32) {
-        f[0] = __uint_as_float(v[0]); f[1] = __uint_as_float(v[1]); f[2] = __uint_as_float(v[2]); f[3] = __uint_as_float(v[3]);
-    } else if constexpr (DT == ICAF_BF16) {
-        f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xffff0000u);
-        f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xffff0000u);
-    } else {
-        f[0] = f16_to_f32((unsigned short)(v[0] & 0xffffu)); f[1] = f16_to_f32((unsigned short)(v[0] >> 16));
-        f[2] = f16_to_f32((unsigned short)(v[1] & 0xffffu)); f[3] = f16_to_f32((unsigned short)(v[1] >> 16));
+// Weight-slice stream by LDS-DMA, for the wide levels (C >= 256, 16-bit types).  At C = 256 / 512 the register-staged stream above
+// is a chain of exposed L2 round trips (phase clocks, batch 32: 1850 cycles per 16 KB slice against 256 cycles of MFMAs — the MLP
+// alone 118 k / 461 k cycles at P4 / P5).  Here the slices of the WHOLE out-projection + MLP sequence of a workgroup form one stream
+// that `buffer_load ... lds` writes straight into an NS-stage ring, NS - 1 slices ahead of the MFMAs and across pass and phase
+// boundaries (the producer cursor walks the passes in the order the kernel consumes them), synchronised like the conv kernels:
+// a counted `s_waitcnt vmcnt` (a wave's own 4 instructions per slice, in issue order) + one LDS-only barrier per slice.  Other
+// vector-memory operations issued in between (bias / residual loads, parked rows) are younger than the slice a wait targets or
+// have been waited for by the compiler — they can only make a counted wait stricter.  Rows are 128 bytes, their 16-byte slots
+// XOR-swizzled by (row >> 1) & 7 on the global side (igemm's layout: conflict-free b128 fragment reads without padding).
+template <int DT, int NS, int NT = FT> struct WSD {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    static constexpr int SLB = 128, BKE = SLB / E::BYTES, STAGE = 128 * SLB, BYTES = NS * STAGE;
+    static constexpr int PER = 128 / 8 / (NT / 64);            // DMA instructions per wave per slice (4; 2 with eight wavefronts)
+    struct State {
+        const T *Wo, *W1, *W2;                                  // the program: out-projection passes, then per hidden chunk fc1 + fc2 passes
+        int Kp, Kp4, nsl, npass, nchunk;
+        const T* base; long long ld; int left, seg;             // producer cursor: `left` slices of segment `seg` remain, next one at `base`
+        int fill, cons, inflight;                               // ring: next stage to fill / to consume, slices issued but not consumed
+    };
+    static __device__ __forceinline__ void segment(State& st) {
+        const int s = st.seg;
+        if (s < st.npass) { st.base = st.Wo + (long long)s * 128 * st.Kp; st.ld = st.Kp; st.left = st.nsl; return; }
+        const int m = s - st.npass, chunk = m / (1 + st.npass), r = m - chunk * (1 + st.npass);
+        if (chunk >= st.nchunk) { st.left = 0; return; }
+        if (r == 0) { st.base = st.W1 + (long long)chunk * 128 * st.Kp; st.ld = st.Kp; st.left = st.nsl; }
+        else { st.base = st.W2 + (long long)(r - 1) * 128 * st.Kp4 + chunk * 128; st.ld = st.Kp4; st.left = 128 / BKE; }
     }
-}
+    static __device__ __forceinline__ void issue(State& st, unsigned char* ring) {
+        if (st.left == 0) return;
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)st.base, 0, 0x7fffffff, 0x00020000);
+        unsigned char* stage = ring + st.fill * STAGE;
+        const int rsub = lane >> 3;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int j = wave + (NT / 64) * i;
+            const int sl = (lane & 7) ^ (((j & 1) << 2) | (rsub >> 1));
+            const unsigned voff = (unsigned)(((long long)(j * 8 + rsub) * st.ld + sl * E::VEC) * E::BYTES);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(stage + (j * 8) * SLB), 16, voff, 0, 0, 0);
+        }
+        st.base += BKE;
+        if (--st.left == 0) { ++st.seg; segment(st); }
+        st.fill = st.fill + 1 == NS ? 0 : st.fill + 1;
+        ++st.inflight;
+    }
+    static __device__ __forceinline__ void begin(State& st, const DmffP& p, int dir, unsigned char* ring) {
+        st.Wo = (const T*)p.wo + dir * p.wo_gs; st.W1 = (const T*)p.w1 + dir * p.w1_gs; st.W2 = (const T*)p.w2 + dir * p.w2_gs;
+        st.Kp = p.Kp; st.Kp4 = p.Kp4; st.nsl = p.C / BKE; st.npass = (p.C + 127) / 128; st.nchunk = p.hid / 128;
+        st.seg = 0; st.fill = 0; st.cons = 0; st.inflight = 0;
+        segment(st);
+#pragma unroll
+        for (int i = 0; i < NS - 1; ++i) issue(st, ring);
+    }
+    // acc[t] += W[wn*64 + t*32 + i][k] * A[wm*32 + j][k] over the next n slices of the stream (the pass the program has reached)
+    static __device__ __forceinline__ void pass(f32x16 (&acc)[2], const unsigned char* A, int SA, int n, unsigned char* ring, State& st) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+        const int wm = wave & 1, wn = wave >> 1;
+        const unsigned char* arow = A + (size_t)(wm * 32 + l31) * SA + hi * 16;
+        const int fkey = (l31 >> 1) & 7;
+        const int wbase = (wn * 64 + l31) * SLB;
+        for (int c = 0; c < n; ++c) {
+            if (st.inflight - 1 >= NS - 2) wait_vmcnt<PER * (NS - 2)>();      // the slice to consume has landed (this wave's part of it)
+            else wait_vmcnt<0>();
+            lds_barrier();                                                    // ... everyone's part; and the stage consumed last is free
+            issue(st, ring);
+            const unsigned char* w = ring + st.cons * STAGE + wbase;
+            const unsigned char* a = arow + (size_t)c * SLB;
+#pragma unroll
+            for (int ks = 0; ks < SLB / 32; ++ks) {
+                const int off = ((2 * ks + hi) ^ fkey) << 4;
+                const u32x4 xf = *(const u32x4*)(a + ks * 32);
+                const u32x4 w0 = *(const u32x4*)(w + off);
+                const u32x4 w1 = *(const u32x4*)(w + 32 * SLB + off);
+                mma_step<DT>(acc[0], w0, xf);
+                mma_step<DT>(acc[1], w1, xf);
+            }
+            st.cons = st.cons + 1 == NS ? 0 : st.cons + 1;
+            --st.inflight;
+        }
+    }
+};
 
 // LayerNorm of the 64 rows of an LDS tile (row stride S bytes, C channels), in place or into `dst`: 4 threads per row,
 // two-pass statistics in fp32 on the stored (16-bit) values, exactly the arithmetic of layernorm_kernel (dmff.hip).
@@ -277,11 +337,17 @@ template <int DT> __device__ __forceinline__ void scatter_vt(unsigned char* Vt, 
     }
 }
 
+constexpr int DMFF_NSD = 4;          // stages of the DMA weight ring (16 KB each)
+template <int DT, int NP2, int SLB> constexpr bool attn_mlp_dma() { return NP2 >= 2 && DT != ICAF_F32 && SLB == 128; }
+
 template <int DT, int DKP, int NP2, int SLB>
 __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32 && DT != ICAF_F32) ? 2 : 1) void dmff_attn_mlp_kernel(const DmffP p) {      // C <= 128: two workgroups per CU (<= 256 registers)
     using E = Elem<DT>;
     using T = typename E::type;
     using S = WS<DT, SLB>;
+    constexpr bool DMA = attn_mlp_dma<DT, NP2, SLB>();     // C >= 256: weight slices by LDS-DMA, DMFF_NSD-stage ring (WSD)
+    using D = WSD<DT == ICAF_F32 ? ICAF_BF16 : DT, DMFF_NSD>;
+    constexpr int RING_BYTES = DMA ? D::BYTES : Ring<SLB>::BYTES;
     constexpr int VEC = E::VEC, EB = E::BYTES;
     constexpr int KSTEP = 2 * VEC, QSTEPS = DKP / KSTEP, TD = (DKP + 31) / 32, PSTEPS = 32 / KSTEP;
     // K row stride: 32-byte rows (dk <= 16) are read as ONE contiguous kilobyte per b128 wave read — no padding needed, and the
@@ -298,7 +364,7 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32 && DT != ICAF_F32) ? 2 :
     const size_t kv_head = (size_t)NP * KS + (size_t)DKP * VS;
     unsigned char* Hb = U;
     unsigned char* ring = U + hb_bytes;
-    float* red = (float*)(ring + Ring<SLB>::BYTES);  // [2][64] row partial sums of the two column halves
+    float* red = (float*)(ring + RING_BYTES);        // [2][64] row partial sums of the two column halves
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     // Workgroup -> (64-row tile, image, direction).  The tiles of one (image, direction) pair all stage the same K / V^T, and the two
@@ -488,8 +554,10 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32 && DT != ICAF_F32) ? 2 :
     const T* W2 = (const T*)p.w2 + dir * p.w2_gs;
     const int nsl = C / S::BKE, nsl2 = 128 / S::BKE, npass = (C + 127) / 128;
     T* yrow = (T*)p.y + dir * p.y_gs + ((long long)b * N + (rok ? tok : 0)) * p.ldy;
-    u32x4 r0v[S::NV], r1v[S::NV];
-    S::start(r0v, r1v, Wo, p.Kp, ring);
+    u32x4 r0v[DMA ? 1 : S::NV], r1v[DMA ? 1 : S::NV];
+    typename D::State dst;
+    if constexpr (DMA) D::begin(dst, p, dir, ring);
+    else S::start(r0v, r1v, Wo, p.Kp, ring);
     typename Quad<DT>::type xatt[NP2][2][4];
     {
         const float* bias = p.bo + dir * p.bo_gs;
@@ -503,7 +571,8 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32 && DT != ICAF_F32) ? 2 :
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
                 const T* Wn = i + 1 < npass ? Wo + (long long)(i + 1) * 128 * p.Kp : W1;       // then the first MLP chunk
-                S::pass(acc, T0, SA, nsl, Wo + (long long)i * 128 * p.Kp, p.Kp, Wn, p.Kp, ring, r0v, r1v);
+                if constexpr (DMA) D::pass(acc, T0, SA, nsl, ring, dst);
+                else S::pass(acc, T0, SA, nsl, Wo + (long long)i * 128 * p.Kp, p.Kp, Wn, p.Kp, ring, r0v, r1v);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -602,7 +671,8 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32 && DT != ICAF_F32) ? 2 :
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-            S::pass(acc, T0, SA, nsl, W1 + (long long)hc * p.Kp, p.Kp, W2 + hc, p.Kp4, ring, r0v, r1v);
+            if constexpr (DMA) D::pass(acc, T0, SA, nsl, ring, dst);
+            else S::pass(acc, T0, SA, nsl, W1 + (long long)hc * p.Kp, p.Kp, W2 + hc, p.Kp4, ring, r0v, r1v);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -620,9 +690,11 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32 && DT != ICAF_F32) ? 2 :
                     const T* Wn = i + 1 < npass ? W2 + (long long)(i + 1) * 128 * p.Kp4 + hc
                                                 : (hc + 128 < p.hid ? W1 + (long long)(hc + 128) * p.Kp : nullptr);
                     const long long ldn = i + 1 < npass ? p.Kp4 : p.Kp;
-                    S::pass(acc2[i], Hb, SH, nsl2, W2 + (long long)i * 128 * p.Kp4 + hc, p.Kp4, Wn, ldn, ring, r0v, r1v);
+                    if constexpr (DMA) D::pass(acc2[i], Hb, SH, nsl2, ring, dst);
+                    else S::pass(acc2[i], Hb, SH, nsl2, W2 + (long long)i * 128 * p.Kp4 + hc, p.Kp4, Wn, ldn, ring, r0v, r1v);
                 }
-            // (every pass ends with a barrier: all waves are done with Hb before the next chunk overwrites it)
+            // (all waves are done with Hb before the next chunk overwrites it: every register-staged pass ends with a barrier, and
+            //  every step of the DMA stream's next fc1 pass begins with one)
         }
     }
     DMFF_STAMP(5);
@@ -658,7 +730,8 @@ static size_t attn_mlp_lds(int C, int N, int dkp, int eb) {      // (eb = 4: alw
     const size_t tile = (size_t)TMROWS * (C * eb + 16), hb = (size_t)TMROWS * (128 * eb + 16);
     const size_t ks = dkp * eb == 32 ? 32 : dkp * eb + 16;
     const size_t kv2 = 2 * ((size_t)NP * ks + (size_t)dkp * (NP * eb + 16));
-    const size_t ring = (eb == 4 || slice_bytes(C) == 128) ? Ring<128>::BYTES : Ring<64>::BYTES;
+    const bool dma = eb == 2 && slice_bytes(C) == 128 && C > 128;         // = attn_mlp_dma<>() of the instantiation dispatch_np2 picks
+    const size_t ring = dma ? (size_t)DMFF_NSD * 128 * 128 : (eb == 4 || slice_bytes(C) == 128) ? Ring<128>::BYTES : Ring<64>::BYTES;
     const size_t chain = hb + ring + 2 * 64 * sizeof(float);
     return tile + (kv2 > chain ? kv2 : chain);
 }

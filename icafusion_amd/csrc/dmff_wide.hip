@@ -1,0 +1,524 @@
+// DMFF block kernels for the WIDE levels (C = 256 / 512, 16-bit types) on gfx950 — one CrossTransformerBlock iteration (reference
+// models/common.py:737-759, CrossAttention :641-687, MLP :704-709) as THREE launches:
+//
+//   dmff_wide_ln_qkv_kernel    LayerNorm (CrossAttention.LN1 / LN2, :661-662) + the six Linear(C, C) projections (:664-669)
+//   cross_attn_kernel          (dmff.hip) softmax(q_other k^T / sqrt(dk)) v per (image, direction, head) (:670-681)
+//   dmff_wide_proj_mlp_kernel  out-projection + coefficient mix (:682-685, :745-746), the block's shared LayerNorm (:749-750),
+//                              MLP Linear(C, 4C) -> GELU(erf) -> Linear(4C, C) and the final mix (:704-709, :751-752)
+//
+// Why not the two-launch form of dmff_fused.hip: with C >= 256 its 64-row tile + K / V^T of two heads leave ONE four-wave
+// workgroup per CU, and its weight stream — through LDS, one barrier per 16 KB slice — measured 1200-1850 cycles per slice against
+// 256 cycles of MFMAs (phase clocks at batch 32; the same stream by LDS-DMA with a 4-stage ring and eight waves: still 1200: every
+// MFMA needs two fragment reads, 64 KB of LDS reads per 16 KB slice).  Here the GEMMs are organised around what is scarce:
+//   * the 64-row token tile is RESIDENT in LDS (read-only during a pass);
+//   * EIGHT wavefronts, wave w owns output channels [32 w, 32 w + 32) of a 256-channel pass and BOTH 32-row halves of the tile:
+//     one weight fragment feeds two MFMAs;
+//   * the weights never touch LDS: a wave reads ITS fragments straight from L2 into registers, from a FRAGMENT-MAJOR copy of the
+//     packed matrix ([Np/32][Kp/16][64 lanes][8 elements]: one coalesced 16-byte load per lane = one MFMA A operand), four K slices
+//     (64 K elements each) ahead, as one continuous per-wave stream across the passes and phases of the kernel — no ring, no DMA
+//     issue slots, NO barrier inside a pass;
+//   * LDS traffic per 32 KB of weights: 64 KB of token-fragment reads (8 waves x 8 b128 reads), against 128 + 32 KB before.
+// Rounding points are those of the per-layer launches (activations rounded to the storage type between layers, fp32 accumulate,
+// two-pass LayerNorm statistics on the rounded values); only fp32 summation orders differ.
+#include "icaf_common.h"
+#include "conv_common.h"
+
+namespace icaf {
+
+struct WideP {
+    const void* x;            // tokens [2][rows][C]: LN + QKV input / residual of the attention mix
+    const void* att;          // proj_mlp: attention output [2][rows][C]
+    void* qkv;                // ln_qkv: [2][rows][3C]
+    void* y;                  // proj_mlp: element (g, row, c) at y + g * y_gs + row * ldy + c
+    const void* wqkv; const float* bqkv;      // FRAGMENT-MAJOR weights [2][Np/32][Kp/16][64][8]; biases fp32 [2][Np]
+    const void* wo; const float* bo;
+    const void* w1; const float* b1;
+    const void* w2; const float* b2;
+    const float* ln_a_g[2]; const float* ln_a_b[2];
+    const float* ln_m_g; const float* ln_m_b;
+    long long wqkv_gs, bqkv_gs, wo_gs, bo_gs, w1_gs, b1_gs, w2_gs, b2_gs, x_gs, y_gs;
+    long long rows;
+    int C, Kp, Kp4, hid, ldy;
+    float eps_a, eps_m;
+    float c_res_a[2], c_acc_a[2], c_res_m[2], c_acc_m[2];
+};
+
+constexpr int WT = 512;              // threads per workgroup (8 wavefronts)
+constexpr int WROWS = 64;            // token rows per workgroup
+constexpr int WPASS = 256;           // output channels per pass (8 waves x 32)
+constexpr int WSL = 4;               // MFMA K steps per slice (64 K elements)
+constexpr int WDEPTH = 4;            // slices in flight per wave (register ring; every pass is a multiple of it)
+
+// One wave's weight stream.  A SEGMENT is one pass's fragments for this wave's 32 channels: n slices of WSL consecutive K steps,
+// 64 lanes x 16 bytes each, contiguous in the fragment-major copy.  `next` yields the segment after the current one.
+struct WCursor {
+    const u32x4* base;       // next slice (lane offset included)
+    int left, seg;
+};
+
+template <class NEXT>
+__device__ __forceinline__ void wfetch(u32x4 (&w)[WSL], WCursor& c, const NEXT& next) {
+    if (c.left == 0) return;                         // end of the kernel's stream (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < WSL; ++k) w[k] = c.base[k * 64];
+    c.base += WSL * 64;
+    if (--c.left == 0) { ++c.seg; next(c); }
+}
+
+// acc[t] += W[32 wn + i][k] * A[32 t + j][k] over the next n slices (n % WDEPTH == 0) of the wave's stream; A: LDS tile, row stride SA
+template <int DT, class NEXT>
+__device__ __forceinline__ void wpass(f32x16 (&acc)[2], const unsigned char* A, int SA, int n, u32x4 (&wq)[WDEPTH][WSL], WCursor& c, const NEXT& next) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const unsigned char* a0 = A + (size_t)l31 * SA + hi * 16;
+    const unsigned char* a1 = a0 + (size_t)32 * SA;
+    for (int s = 0; s < n; s += WDEPTH) {
+#pragma unroll
+        for (int u = 0; u < WDEPTH; ++u) {
+#pragma unroll
+            for (int k = 0; k < WSL; ++k) {
+                const int off = ((s + u) * WSL + k) * 32;
+                const u32x4 x0 = *(const u32x4*)(a0 + off);
+                const u32x4 x1 = *(const u32x4*)(a1 + off);
+                mma_step<DT>(acc[0], wq[u][k], x0);
+                mma_step<DT>(acc[1], wq[u][k], x1);
+            }
+            wfetch(wq[u], c, next);
+            __builtin_amdgcn_sched_barrier(0);             // (left alone the scheduler hoists the token-fragment reads of all four slices: 128 registers)
+        }
+    }
+}
+
+// LayerNorm of the 64 rows of an LDS tile in place: 8 threads per row, two-pass statistics in fp32 on the stored values
+// (the arithmetic of layernorm_kernel, dmff.hip).
+template <int DT>
+__device__ __forceinline__ void wide_tile_layernorm(unsigned char* tile, int S, int C, const float* __restrict__ gam, const float* __restrict__ bet, float eps) {
+    using E = Elem<DT>;
+    const int tid = threadIdx.x, row = tid >> 3, part = tid & 7;
+    const int nv = C / E::VEC;
+    unsigned char* r = tile + (size_t)row * S;
+    float s = 0.0f;
+    for (int v = part; v < nv; v += 8) {
+        float t[E::VEC];
+        unpack16<DT>(*(const u32x4*)(r + v * 16), t);
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) s += t[j];
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    const float mean = s / (float)C;
+    float q = 0.0f;
+    for (int v = part; v < nv; v += 8) {
+        float t[E::VEC];
+        unpack16<DT>(*(const u32x4*)(r + v * 16), t);
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) { const float d = t[j] - mean; q += d * d; }
+    }
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    for (int v = part; v < nv; v += 8) {
+        float t[E::VEC], o[E::VEC];
+        unpack16<DT>(*(const u32x4*)(r + v * 16), t);
+#pragma unroll
+        for (int j = 0; j < E::VEC; ++j) o[j] = (t[j] - mean) * rstd * gam[v * E::VEC + j] + bet[v * E::VEC + j];
+        *(u32x4*)(r + v * 16) = pack16<DT>(o);
+    }
+}
+
+// workgroup id -> (modality, index): XCDs 0-3 take modality 0, XCDs 4-7 modality 1 (hardware deals consecutive ids round-robin
+// over the 8 XCDs), so an XCD's L2 holds ONE modality's weights — at C = 512 that is 4.7 of the 9.4 MB of a block
+__device__ __forceinline__ void wide_place(int bid, int& g, int& idx) { g = (bid & 7) >> 2; idx = (bid >> 3) * 4 + (bid & 3); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm + QKV projection: a workgroup = 64 token rows x 768 output channels (three passes) of one modality.
+// grid = 8 * ceil(tiles * C / 256 / 4)
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(WT) void dmff_wide_ln_qkv_kernel(const WideP p) {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    constexpr int VEC = E::VEC, EB = E::BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = p.C, SA = C * EB + 16;
+    unsigned char* tile = smem;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ngrp = C / WPASS;                                    // column groups of 768 channels
+    const int ntiles = (int)((p.rows + WROWS - 1) / WROWS);
+    int g, idx;
+    wide_place(blockIdx.x, g, idx);
+    if (idx >= ntiles * ngrp) return;
+    const int tile_i = idx / ngrp, grp = idx - tile_i * ngrp;
+    const long long r0 = (long long)tile_i * WROWS;
+    const int ks_row = p.Kp / 16, nsl = C / (16 * WSL);
+
+    const u32x4* wf = (const u32x4*)((const T*)p.wqkv + g * p.wqkv_gs) + lane;
+    auto next = [&](WCursor& c) {
+        if (c.seg >= 3) { c.left = 0; return; }
+        c.base = wf + (long long)((grp * 3 + c.seg) * 8 + wn) * ks_row * 64;
+        c.left = nsl;
+    };
+    WCursor cur; cur.seg = 0; next(cur);
+    u32x4 wq[WDEPTH][WSL];
+#pragma unroll
+    for (int u = 0; u < WDEPTH; ++u) wfetch(wq[u], cur, next);      // the first weight slices travel while the tokens are normalised
+
+    {
+        const T* xg = (const T*)p.x + g * p.x_gs;
+        const int nv = C / VEC;
+        for (int i = tid; i < WROWS * nv; i += WT) {               // raw tokens -> LDS (rows beyond the tensor: clamped, never stored)
+            const int row = i / nv, v = i - row * nv;
+            long long r = r0 + row;
+            r = r < p.rows ? r : p.rows - 1;
+            *(u32x4*)(tile + (size_t)row * SA + v * 16) = *(const u32x4*)(xg + r * C + v * VEC);
+        }
+    }
+    lds_barrier();
+    wide_tile_layernorm<DT>(tile, SA, C, p.ln_a_g[g], p.ln_a_b[g], p.eps_a);
+    lds_barrier();
+
+    const float* bias = p.bqkv + g * p.bqkv_gs;
+    const int nout = 3 * C;
+    T* out = (T*)p.qkv + (long long)g * p.rows * nout;
+    for (int j = 0; j < 3; ++j) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        wpass<DT>(acc, tile, SA, nsl, wq, cur, next);
+        const int nb = (grp * 3 + j) * WPASS + wn * 32;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const long long row = r0 + t * 32 + l31;
+            if (row < p.rows) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nb + 8 * q + 4 * hi;
+                    const f32x4 b = *(const f32x4*)(bias + n);
+                    *(typename Quad<DT>::type*)(out + row * nout + n) =
+                        pack4<DT>(acc[t][4 * q] + b[0], acc[t][4 * q + 1] + b[1], acc[t][4 * q + 2] + b[2], acc[t][4 * q + 3] + b[3]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// out-projection + LayerNorm + MLP: a workgroup = 64 token rows of one modality.  grid = 8 * ceil(tiles / 4)
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT, int NPW>          // NPW = C / 256 passes per C-wide product
+__global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    constexpr int VEC = E::VEC, EB = E::BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = p.C, SA = C * EB + 16;
+    constexpr int SH = WPASS * EB + 16;
+    unsigned char* T0 = smem;                                      // attention output -> later the LayerNorm'ed MLP input
+    unsigned char* Hb = T0 + (size_t)WROWS * SA;                   // hidden chunk [64][256]
+    float* red = (float*)(Hb + (size_t)WROWS * SH);                // [8][64] row partial sums of the eight channel groups
+    float* b1s = red + 8 * 64;                                     // fc1 bias (hid floats)
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = (int)((p.rows + WROWS - 1) / WROWS);
+    int g, tile_i;
+    wide_place(blockIdx.x, g, tile_i);
+    if (tile_i >= ntiles) return;
+    const long long r0 = (long long)tile_i * WROWS;
+    const int ks_row = p.Kp / 16, ks_row4 = p.Kp4 / 16, nsl = C / (16 * WSL), nchunk = p.hid / WPASS;
+    constexpr int NSL2 = WPASS / (16 * WSL);                       // slices of an fc2 pass over one hidden chunk (4)
+
+    // the wave's stream: NPW out-projection passes, then per hidden chunk one fc1 pass and NPW fc2 passes
+    const u32x4* wof = (const u32x4*)((const T*)p.wo + g * p.wo_gs) + lane;
+    const u32x4* w1f = (const u32x4*)((const T*)p.w1 + g * p.w1_gs) + lane;
+    const u32x4* w2f = (const u32x4*)((const T*)p.w2 + g * p.w2_gs) + lane;
+    auto next = [&](WCursor& c) {
+        const int s = c.seg;
+        if (s < NPW) { c.base = wof + (long long)(s * 8 + wn) * ks_row * 64; c.left = nsl; return; }
+        const int m = s - NPW, chunk = m / (1 + NPW), r = m - chunk * (1 + NPW);
+        if (chunk >= nchunk) { c.left = 0; return; }
+        if (r == 0) { c.base = w1f + (long long)(chunk * 8 + wn) * ks_row * 64; c.left = nsl; }
+        else { c.base = w2f + ((long long)((r - 1) * 8 + wn) * ks_row4 + chunk * (WPASS / 16)) * 64; c.left = NSL2; }
+    };
+    WCursor cur; cur.seg = 0; next(cur);
+    u32x4 wq[WDEPTH][WSL];
+#pragma unroll
+    for (int u = 0; u < WDEPTH; ++u) wfetch(wq[u], cur, next);      // the first weight slices travel while the tile is loaded
+
+    {
+        const T* att = (const T*)p.att + (long long)g * p.rows * C;
+        const int nv = C / VEC;
+        for (int i = tid; i < WROWS * nv; i += WT) {               // (rows beyond the tensor: clamped, never stored)
+            const int row = i / nv, v = i - row * nv;
+            long long r = r0 + row;
+            r = r < p.rows ? r : p.rows - 1;
+            *(u32x4*)(T0 + (size_t)row * SA + v * 16) = *(const u32x4*)(att + r * C + v * VEC);
+        }
+        const float* b1 = p.b1 + g * p.b1_gs;
+        for (int i = tid; i < p.hid; i += WT) b1s[i] = b1[i];
+    }
+    lds_barrier();
+
+    bool rok[2];
+    const T* xres[2];
+    T* yrow[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long long row = r0 + t * 32 + l31;
+        rok[t] = row < p.rows;
+        const long long grow = rok[t] ? row : p.rows - 1;
+        xres[t] = (const T*)p.x + g * p.x_gs + grow * C;
+        yrow[t] = (T*)p.y + g * p.y_gs + grow * p.ldy;
+    }
+
+    // ---- out-projection + coefficient mix: x_att = c_res * x + c_acc * (att W_o^T + b), rounded to the storage type, in registers ----
+    constexpr bool PARK = NPW >= 2;
+    typename Quad<DT>::type xatt[NPW][2][4];
+    {
+        const float* bias = p.bo + g * p.bo_gs;
+        const float ca = p.c_acc_a[g], cr = p.c_res_a[g];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+            wpass<DT>(acc, T0, SA, nsl, wq, cur, next);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = i * WPASS + wn * 32 + 8 * q + 4 * hi;
+                    const f32x4 bv = *(const f32x4*)(bias + n);
+                    float rv[4], v[4];
+                    unpack4<DT>(*(const typename Quad<DT>::type*)(xres[t] + n), rv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (acc[t][4 * q + j] + bv[j]) * ca);
+                    xatt[i][t][q] = pack4<DT>(v[0], v[1], v[2], v[3]);
+                }
+        }
+    }
+    // ---- the block's shared LayerNorm over x_att, from registers: row sums = this lane's channels + the other lane half (shuffle) +
+    //      the other seven channel groups (LDS); the normalised tile overwrites T0 — every wave has passed a barrier after its last
+    //      out-projection read by then ----
+    {
+        float mean[2], rstd[2];
+        float sum[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+                    unpack4<DT>(xatt[i][t][q], v);
+                    sum[t] += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            sum[t] += __shfl_xor(sum[t], 32);
+            if (hi == 0) red[wn * 64 + t * 32 + l31] = sum[t];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += red[w * 64 + t * 32 + l31];
+            mean[t] = s / (float)C;
+        }
+        lds_barrier();
+        float sq[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+                    unpack4<DT>(xatt[i][t][q], v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float d = v[j] - mean[t]; sq[t] += d * d; }
+                }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            sq[t] += __shfl_xor(sq[t], 32);
+            if (hi == 0) red[wn * 64 + t * 32 + l31] = sq[t];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += red[w * 64 + t * 32 + l31];
+            rstd[t] = 1.0f / sqrtf(s / (float)C + p.eps_m);
+        }
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = i * WPASS + wn * 32 + 8 * q + 4 * hi;
+                const f32x4 gv = *(const f32x4*)(p.ln_m_g + n), bv = *(const f32x4*)(p.ln_m_b + n);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float v[4], o[4];
+                    unpack4<DT>(xatt[i][t][q], v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean[t]) * rstd[t] * gv[j] + bv[j];
+                    *(typename Quad<DT>::type*)(T0 + (size_t)(t * 32 + l31) * SA + n * EB) = pack4<DT>(o[0], o[1], o[2], o[3]);
+                    // C = 512: x_att is needed once more, as the residual of the final mix — parked in the workgroup's own rows of the
+                    // output tensor (read back by the same lane) instead of holding 32 more registers through the MLP (spills otherwise)
+                    if constexpr (PARK) { if (rok[t]) *(typename Quad<DT>::type*)(yrow[t] + n) = xatt[i][t][q]; }
+                }
+            }
+        lds_barrier();
+    }
+    // ---- MLP in 256-column hidden chunks: H = GELU(n2 W1_chunk^T + b1) -> LDS, then acc2 += H W2[:, chunk]^T ----
+    f32x16 acc2[NPW][2];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][t][r] = 0.0f;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        wpass<DT>(acc, T0, SA, nsl, wq, cur, next);
+        lds_barrier();                                             // every wave is done with the previous chunk's H
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wn * 32 + 8 * q + 4 * hi;
+                const f32x4 bv = *(const f32x4*)(b1s + chunk * WPASS + nl);
+                *(typename Quad<DT>::type*)(Hb + (size_t)(t * 32 + l31) * SH + nl * EB) =
+                    pack4<DT>(apply_act<ICAF_ACT_GELU, DT>(acc[t][4 * q] + bv[0]), apply_act<ICAF_ACT_GELU, DT>(acc[t][4 * q + 1] + bv[1]),
+                              apply_act<ICAF_ACT_GELU, DT>(acc[t][4 * q + 2] + bv[2]), apply_act<ICAF_ACT_GELU, DT>(acc[t][4 * q + 3] + bv[3]));
+            }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) wpass<DT>(acc2[i], Hb, SH, NSL2, wq, cur, next);
+    }
+    // ---- output: x' = c_res2 * x_att + c_acc2 * (mlp + b2) ----
+    {
+        const float* b2 = p.b2 + g * p.b2_gs;
+        const float ca = p.c_acc_m[g], cr = p.c_res_m[g];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = i * WPASS + wn * 32 + 8 * q + 4 * hi;
+                const f32x4 bv = *(const f32x4*)(b2 + n);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float rv[4], v[4];
+                    if constexpr (PARK) unpack4<DT>(*(const typename Quad<DT>::type*)(yrow[t] + n), rv);     // (clamped row when !rok: never stored)
+                    else unpack4<DT>(xatt[i][t][q], rv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (acc2[i][t][4 * q + j] + bv[j]) * ca);
+                    if (rok[t]) *(typename Quad<DT>::type*)(yrow[t] + n) = pack4<DT>(v[0], v[1], v[2], v[3]);
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+static int wide_fill(const icaf_dmff_args* a, WideP& p, const char* who) {
+    if (!a || !a->x) return fail(ICAF_ERR_ARG, "%s: null pointer", who);
+    if (a->dtype != ICAF_BF16 && a->dtype != ICAF_F16) return fail(ICAF_ERR_UNSUPPORTED, "%s: 16-bit types only (dtype %d)", who, a->dtype);
+    if (a->B < 1 || a->N < 1) return fail(ICAF_ERR_ARG, "%s: bad B/N", who);
+    if (a->C != 256 && a->C != 512) return fail(ICAF_ERR_UNSUPPORTED, "%s: C=%d (built for 256 and 512: 256-channel passes, K slices in fours)", who, a->C);
+    if (a->Kp < a->C || a->Kp % 64) return fail(ICAF_ERR_ARG, "%s: Kp=%d", who, a->Kp);
+    p.x = a->x; p.qkv = a->qkv; p.y = a->y; p.att = nullptr;
+    p.wqkv = a->wqkv; p.bqkv = a->bqkv; p.wo = a->wo; p.bo = a->bo; p.w1 = a->w1; p.b1 = a->b1; p.w2 = a->w2; p.b2 = a->b2;
+    p.ln_a_g[0] = a->ln_attn_gamma[0]; p.ln_a_g[1] = a->ln_attn_gamma[1]; p.ln_a_b[0] = a->ln_attn_beta[0]; p.ln_a_b[1] = a->ln_attn_beta[1];
+    p.ln_m_g = a->ln_mlp_gamma; p.ln_m_b = a->ln_mlp_beta;
+    p.wqkv_gs = a->wqkv_gs; p.bqkv_gs = a->bqkv_gs; p.wo_gs = a->wo_gs; p.bo_gs = a->bo_gs; p.w1_gs = a->w1_gs; p.b1_gs = a->b1_gs;
+    p.w2_gs = a->w2_gs; p.b2_gs = a->b2_gs; p.x_gs = a->x_gs; p.y_gs = a->y_gs;
+    p.rows = (long long)a->B * a->N; p.C = a->C; p.Kp = a->Kp; p.Kp4 = a->Kp4; p.hid = a->hidden; p.ldy = a->ldy;
+    p.eps_a = a->eps_attn; p.eps_m = a->eps_mlp;
+    for (int g = 0; g < 2; ++g) {
+        p.c_res_a[g] = a->coef_res_attn[g]; p.c_acc_a[g] = a->coef_acc_attn[g];
+        p.c_res_m[g] = a->coef_res_mlp[g]; p.c_acc_m[g] = a->coef_acc_mlp[g];
+    }
+    return ICAF_OK;
+}
+
+template <class K>
+static int wide_attr(K kern, size_t lds, const char* who) {
+    if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "%s: %zu bytes of LDS exceed 160 KiB", who, lds);
+    ICAF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return ICAF_OK;
+}
+
+template <int DT>
+static int launch_wide_ln_qkv(const WideP& p, hipStream_t s) {
+    const size_t lds = (size_t)WROWS * (p.C * 2 + 16);
+    static std::atomic<bool> attr_set[ICAF_MAX_DEVICES];
+    int dev = 0;
+    ICAF_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= ICAF_MAX_DEVICES) return fail(ICAF_ERR_UNSUPPORTED, "device ordinal %d", dev);
+    if (!attr_set[dev]) {
+        int st = wide_attr(dmff_wide_ln_qkv_kernel<DT>, lds, "icaf_dmff_wide_ln_qkv");
+        if (st) return st;
+        attr_set[dev] = true;
+    }
+    const long long work = ((p.rows + WROWS - 1) / WROWS) * (p.C / WPASS);
+    hipLaunchKernelGGL((dmff_wide_ln_qkv_kernel<DT>), dim3((unsigned)(8 * ((work + 3) / 4))), dim3(WT), lds, s, p);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+static size_t wide_proj_mlp_lds(int C, int hid) {
+    return (size_t)WROWS * (C * 2 + 16) + (size_t)WROWS * (WPASS * 2 + 16) + 8 * 64 * sizeof(float) + (size_t)hid * sizeof(float);
+}
+
+template <int DT, int NPW>
+static int launch_wide_proj_mlp(const WideP& p, hipStream_t s) {
+    const size_t lds = wide_proj_mlp_lds(p.C, p.hid);
+    static std::atomic<bool> attr_set[ICAF_MAX_DEVICES];
+    int dev = 0;
+    ICAF_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= ICAF_MAX_DEVICES) return fail(ICAF_ERR_UNSUPPORTED, "device ordinal %d", dev);
+    if (!attr_set[dev]) {
+        int st = wide_attr(dmff_wide_proj_mlp_kernel<DT, NPW>, lds, "icaf_dmff_wide_proj_mlp");
+        if (st) return st;
+        attr_set[dev] = true;
+    }
+    const long long ntiles = (p.rows + WROWS - 1) / WROWS;
+    hipLaunchKernelGGL((dmff_wide_proj_mlp_kernel<DT, NPW>), dim3((unsigned)(8 * ((ntiles + 3) / 4))), dim3(WT), lds, s, p);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+}  // namespace icaf
+
+using namespace icaf;
+
+extern "C" int icaf_dmff_wide_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s) {
+    WideP p;
+    int st = wide_fill(a, p, "icaf_dmff_wide_ln_qkv");
+    if (st) return st;
+    if (!a->qkv || !a->wqkv || !a->bqkv || !a->ln_attn_gamma[0] || !a->ln_attn_gamma[1] || !a->ln_attn_beta[0] || !a->ln_attn_beta[1])
+        return fail(ICAF_ERR_ARG, "icaf_dmff_wide_ln_qkv: null pointer");
+    return a->dtype == ICAF_BF16 ? launch_wide_ln_qkv<ICAF_BF16>(p, S(s)) : launch_wide_ln_qkv<ICAF_F16>(p, S(s));
+}
+
+extern "C" int icaf_dmff_wide_proj_mlp(const icaf_dmff_args* a, const void* att, icaf_stream_t s) {
+    WideP p;
+    int st = wide_fill(a, p, "icaf_dmff_wide_proj_mlp");
+    if (st) return st;
+    if (!att || !a->y || !a->wo || !a->bo || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ln_mlp_gamma || !a->ln_mlp_beta) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp: null pointer");
+    if (a->hidden % WPASS || a->hidden < WPASS || a->Kp4 < a->hidden || a->Kp4 % 64) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp: hidden width %d must be a multiple of 256", a->hidden);
+    if (a->ldy < a->C || a->ldy % 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp: ldy=%d", a->ldy);
+    p.att = att;
+    if (a->dtype == ICAF_BF16) return a->C == 256 ? launch_wide_proj_mlp<ICAF_BF16, 1>(p, S(s)) : launch_wide_proj_mlp<ICAF_BF16, 2>(p, S(s));
+    return a->C == 256 ? launch_wide_proj_mlp<ICAF_F16, 1>(p, S(s)) : launch_wide_proj_mlp<ICAF_F16, 2>(p, S(s));
+}

@@ -742,6 +742,15 @@ class CrossTransformerBlock(HipModule):
                 and (plan.device.type != "cuda" or ops.dmff_fused_lds_bytes(C, N, h, plan.dtype) is not None)
                 and (plan.device.type == "cuda" or C <= 512))
 
+    # wide levels, 16-bit types: three launches per iteration (ICAF_DMFF_WIDE=0: the seven per-layer launches, A/B switch)
+    fuse_wide = os.environ.get("ICAF_DMFF_WIDE", "1") != "0"
+    wide_max_c = int(os.environ.get("ICAF_DMFF_WIDE_MAX_C", "512"))
+
+    def wide_fusable(self, plan, C):
+        hid, h = self.mlp_vis[0].out_features, self.crossatt.h
+        return (self.fuse_wide and self.fuse_block and self.fuse_max_c < C <= self.wide_max_c and ops.dmff_wide_ok(C, hid, plan.dtype)
+                and (C // h) % 8 == 0 and self.mlp_vis[2].in_features == hid)
+
     def emit_tokens(self, plan, tok, B, N, final_out=None):
         """tok: (2, B*N, C) [0]=RGB [1]=IR -> same shape after `loops` shared-weight iterations.  final_out: optional
         (2, B*N, C) view (any row / group strides) that the last iteration writes instead of a fresh buffer."""
@@ -760,6 +769,19 @@ class CrossTransformerBlock(HipModule):
                 plan.add(ops.dmff_ln_qkv(tok, qkv, p, ln, coef, p["eps"], B, N, self.crossatt.h))
                 nxt = final_out if (final_out is not None and it == nloops - 1) else plan.tokens(2, rows, C)
                 plan.add(ops.dmff_attn_mlp(tok, qkv, nxt, p, ln, coef, p["eps"], B, N, self.crossatt.h))
+                tok = nxt
+            return tok
+        if self.wide_fusable(plan, C):
+            # wide levels (C = 256 / 512): LayerNorm + QKV, attention, out-projection + LayerNorm + MLP — three launches; x_att, the
+            # normalised tile and the hidden activations never reach HBM (dmff_wide.hip)
+            coef = dict(co=co, hidden=hid)
+            qkv = plan.tokens(2, rows, 3 * C)
+            att = plan.tokens(2, rows, C)
+            for it in range(nloops):
+                plan.add(ops.dmff_wide_ln_qkv(tok, qkv, p, ln, coef, p["eps"], B, N, self.crossatt.h))
+                plan.add(ops.cross_attention(qkv, att, B, N, self.crossatt.h))
+                nxt = final_out if (final_out is not None and it == nloops - 1) else plan.tokens(2, rows, C)
+                plan.add(ops.dmff_wide_proj_mlp(tok, att, nxt, p, ln, coef, p["eps"], B, N, self.crossatt.h))
                 tok = nxt
             return tok
         for it in range(nloops):

@@ -520,16 +520,16 @@ def _dmff_args(x, qkv, y, packs, ln, coef, eps, B, N, heads):
     """icaf_dmff_args for one block iteration.  x: (2, B*N, C) contiguous tokens; qkv: (2, B*N, 3C); y: (2, B*N, C) view with
     any group / row stride; packs = dict(qkv=, out=, fc1=, fc2=) of (weights [2][Np][Kp], Kp, bias [2][Np]) stacks."""
     G, rows, Cc = x.shape
-    assert G == 2 and rows == B * N and x.is_contiguous() and qkv.shape == (2, rows, 3 * Cc) and qkv.is_contiguous()
+    assert G == 2 and rows == B * N and x.is_contiguous() and (qkv is None or (qkv.shape == (2, rows, 3 * Cc) and qkv.is_contiguous()))
     a = DmffArgs()
-    a.x, a.qkv = x.data_ptr(), qkv.data_ptr()
+    a.x, a.qkv = x.data_ptr(), (qkv.data_ptr() if qkv is not None else None)
     a.x_gs = x.stride(0)
     if y is not None:
         assert y.shape == (2, rows, Cc) and y.stride(2) == 1 and y.dtype == x.dtype
         a.y, a.y_gs, a.ldy = y.data_ptr(), y.stride(0), y.stride(1)
     for name, key in (("wqkv", "qkv"), ("wo", "out"), ("w1", "fc1"), ("w2", "fc2")):
         w, kp, b = packs[key]
-        assert w.dtype == x.dtype and w.dim() == 3 and b.dim() == 2
+        assert w.dtype == x.dtype and w.dim() in (3, 5) and b.dim() == 2          # ([2][Np][Kp], or its fragment-major copy)
         setattr(a, name, w.data_ptr()); setattr(a, "b" + name[1:], b.data_ptr())
         setattr(a, name + "_gs", w.stride(0)); setattr(a, "b" + name[1:] + "_gs", b.stride(0))
     a.Kp, a.Kp4 = packs["qkv"][1], packs["fc2"][1]
@@ -565,6 +565,39 @@ def dmff_attn_mlp(x, qkv, y, packs, ln, coef, eps, B, N, heads, name="dmff_attn_
     flops = 2.0 * (B * heads * 4.0 * N * N * (Cc // heads)) + 2.0 * 2 * rows * (Cc * Cc + 2 * Cc * hid)
     nbytes = 2 * (rows * 3 * Cc * es + 2 * rows * Cc * es + (Cc * Cc + 2 * Cc * hid) * es)
     return Launch(lib().icaf_dmff_attn_mlp, (C.byref(a),), keep=(a, x, qkv, y, packs, ln), name=name, flops=flops, nbytes=nbytes)
+
+
+def dmff_wide_ok(C_, hidden, dt):
+    """The wide-level block kernels (dmff_wide.hip) cover this shape: C = 256 / 512, 16-bit types, hidden a multiple of 256."""
+    lds = 64 * (C_ * 2 + 16) + 64 * (256 * 2 + 16) + 8 * 64 * 4 + hidden * 4
+    return dt in (torch.bfloat16, torch.float16) and C_ in (256, 512) and hidden % 256 == 0 and lds <= 160 * 1024
+
+
+def _wide_packs(packs):
+    """packs with fragment-major weight copies (frag_weights: cached per packed tensor) — what the dmff_wide kernels read"""
+    return {k: ((frag_weights(v[0]), v[1], v[2]) if k in ("qkv", "out", "fc1", "fc2") else v) for k, v in packs.items()}
+
+
+def dmff_wide_ln_qkv(x, qkv, packs, ln, coef, eps, B, N, heads, name="dmff_ln_qkv"):
+    """LayerNorm + the six Linear(C, C) projections, wide levels (icaf_dmff_wide_ln_qkv)."""
+    wp = _wide_packs(packs)
+    a = _dmff_args(x, qkv, None, wp, ln, coef, eps, B, N, heads)
+    rows, Cc = x.shape[1], x.shape[2]
+    es = x.element_size()
+    return Launch(lib().icaf_dmff_wide_ln_qkv, (C.byref(a),), keep=(a, x, qkv, wp, packs, ln), name=name, flops=2.0 * 2 * rows * Cc * 3 * Cc,
+                  nbytes=2 * (rows * Cc * es + 3 * Cc * Cc * es + rows * 3 * Cc * es))
+
+
+def dmff_wide_proj_mlp(x, att, y, packs, ln, coef, eps, B, N, heads, name="dmff_proj_mlp"):
+    """Out-projection + LayerNorm + MLP of one block iteration as one launch behind cross_attention (icaf_dmff_wide_proj_mlp)."""
+    rows, Cc = x.shape[1], x.shape[2]
+    assert att.shape == (2, rows, Cc) and att.is_contiguous() and att.dtype == x.dtype
+    wp = _wide_packs(packs)
+    a = _dmff_args(x, None, y, wp, ln, coef, eps, B, N, heads)
+    es, hid = x.element_size(), coef["hidden"]
+    flops = 2.0 * 2 * rows * (Cc * Cc + 2 * Cc * hid)
+    nbytes = 2 * (3 * rows * Cc * es + (Cc * Cc + 2 * Cc * hid) * es)
+    return Launch(lib().icaf_dmff_wide_proj_mlp, (C.byref(a), att.data_ptr()), keep=(a, x, att, y, wp, packs, ln), name=name, flops=flops, nbytes=nbytes)
 
 
 def dmff_upsample_merge(tokens, fea_rgb, fea_ir, out, th, tw, name="dmff_upsample_merge"):

@@ -260,6 +260,17 @@ typedef struct icaf_dmff_args {
 } icaf_dmff_args;
 int icaf_dmff_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s);
 int icaf_dmff_attn_mlp(const icaf_dmff_args* a, icaf_stream_t s);
+/* The block for the WIDE levels (C = 256 or 512, 16-bit types; dmff_wide.hip): one iteration = icaf_dmff_wide_ln_qkv,
+ * icaf_cross_attention, icaf_dmff_wide_proj_mlp.
+ *   icaf_dmff_wide_ln_qkv    as icaf_dmff_ln_qkv (LayerNorm :661-662 + the six projections :664-669);
+ *   icaf_dmff_wide_proj_mlp  out-projection + coefficient mix (:682-685, :745-746), the shared LayerNorm (:749-750), MLP + mix
+ *                            (:704-709, :751-752) of 64 token rows per workgroup; att = the attention output tokens [2][B*N][C]
+ *                            (contiguous, as icaf_cross_attention writes them); a->qkv / wqkv / bqkv are not read.
+ * DIFFERENT WEIGHT LAYOUT: a->wqkv / wo / w1 / w2 point at FRAGMENT-MAJOR copies of the packed [2][Np][Kp] matrices,
+ * [2][Np/32][Kp/16][64][8] (lane (hi*32 + r) of block (nb, ks) = w[nb*32 + r][ks*16 + hi*8 .. +8], the layout of icaf_conv_args.wf;
+ * same *_gs strides): each wavefront streams its MFMA weight operands straight from L2 into registers.  hidden % 256 == 0. */
+int icaf_dmff_wide_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s);
+int icaf_dmff_wide_proj_mlp(const icaf_dmff_args* a, const void* att, icaf_stream_t s);
 int icaf_dmff_attn_mlp_lds_bytes(int C, int N, int heads, int dtype, size_t* bytes);
 
 /* ---- NMS (utils/general.py:518-607 + torchvision.ops.nms semantics) ----------------------------------------

@@ -23,8 +23,8 @@ def make_block(C, heads, loops, seed):
     return blk, {"b." + k: v for k, v in sd.items()}
 
 
-def run_block(blk, tok, B, N, dtype, fused):
-    blk.fuse_block, blk.fuse_max_c = fused, 512          # (the plan uses the fused kernels up to C = 128 by default; they are built to 512)
+def run_block(blk, tok, B, N, dtype, fused, max_c=512):
+    blk.fuse_block, blk.fuse_max_c = fused, max_c        # (the plan uses the two-launch kernels up to C = 128 by default; they are built to 512)
     blk.fuse_fp32 = fused                                 # fp32: the parity instantiation of the same template (C <= 128)
     blk.invalidate()
     plan = Plan(DEV, dtype)
@@ -66,6 +66,31 @@ def test_fused_block_vs_oracle_and_per_layer_launches(shape, dtype):
     assert e_f <= 1.5 * e_p + 1e-4 and m_f <= 1.25 * m_p + 1e-5
     ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     assert (fused - plain).abs().max().item() / scale <= 24 * ulp
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(256, 8, 256, 2, 1), (512, 8, 100, 3, 1), (256, 8, 400, 1, 2), (512, 8, 64, 1, 1), (256, 4, 77, 3, 3), (512, 16, 130, 2, 2)])
+def test_wide_block_three_launches_vs_oracle_and_per_layer_launches(shape, dtype):
+    """C = 256 / 512 (what the plan runs at P4 / P5): icaf_dmff_wide_ln_qkv + icaf_cross_attention + icaf_dmff_wide_proj_mlp per iteration."""
+    C, heads, N, B, loops = shape
+    blk, sd = make_block(C, heads, loops, seed=C + N)
+    blk = blk.to(DEV)
+    g = np.random.default_rng(C * 1000 + N + 1)
+    tok = torch.from_numpy(g.normal(0.2, 0.8, (2, B * N, C)).astype(np.float32))
+    tq = tok.to(dtype).float()
+    rv, ri = oracle.cross_transformer(tq[0].reshape(B, N, C), tq[1].reshape(B, N, C), sd, "b", heads, loops)
+    ref = torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
+    wide, names_w = run_block(blk, tok, B, N, dtype, True, max_c=128)
+    plain, names_p = run_block(blk, tok, B, N, dtype, False)
+    assert names_w == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp"] * loops and len(names_p) == 7 * loops
+    scale = ref.abs().max().item()
+    e_w, e_p = (wide - ref).abs().max().item() / scale, (plain - ref).abs().max().item() / scale
+    m_w, m_p = (wide - ref).abs().mean().item() / scale, (plain - ref).abs().mean().item() / scale
+    print(f"C={C} N={N} B={B} loops={loops} {dtype}: three launches max {e_w:.3e} mean {m_w:.3e} | per-layer max {e_p:.3e} mean {m_p:.3e}")
+    assert torch.isfinite(wide).all()
+    assert e_w <= 1.5 * e_p + 1e-4 and m_w <= 1.25 * m_p + 1e-5
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert (wide - plain).abs().max().item() / scale <= 24 * ulp
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -12,7 +12,7 @@ from icafusion_amd.synth import synth_tensor
 for C, N, B in ((128, 400, 32), (256, 256, 32), (512, 100, 32)):
     blk = CrossTransformerBlock(C, C, C, 8, 4, 0.1, 0.1).eval()
     blk.load_state_dict({k: synth_tensor("b." + k, v.shape, seed=1) for k, v in blk.state_dict().items()})
-    blk = blk.to("cuda:0"); blk.fuse_block = True
+    blk = blk.to("cuda:0"); blk.fuse_block = True; blk.fuse_max_c = 512
     plan = Plan("cuda:0", torch.bfloat16)
     t = plan.tokens(2, B * N, C); t.copy_(torch.randn(2, B * N, C, device="cuda:0").to(torch.bfloat16))
     blk.emit_tokens(plan, t, B, N)
