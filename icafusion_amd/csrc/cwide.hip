@@ -1,0 +1,295 @@
+// 3x3 / stride 1 convolution for the 128-channel layers at 40 x 40 (C3 Bottlenecks of the P4 backbones, the head's 3x3 layers) on
+// gfx950: halo patch RESIDENT in LDS, weights streamed PER WAVE from L2 straight into registers.
+//
+// What bounds these layers in the implicit-GEMM kernel (igemm.hip) is not HBM and not the MFMA pipe but the feed: a 128 x 128 tile
+// with K = 9 x 128 moves 590 KB through 576 LDS-DMA instructions (the pixel operand re-fetched once per filter tap, the weights
+// through the same ring), every MFMA pair waits on two b128 fragment reads, and a barrier closes every 64-K slice — measured 24 %
+// of the MFMA peak at batch 32.  Here a workgroup (4 wavefronts, two workgroups per CU) owns an 8 x 16 patch of output pixels:
+//   * its 10 x 18 input halo patch is fetched ONCE (60 DMA instructions; out-of-image pixels zero-filled by the descriptor range
+//     check), pixel-major, 256 bytes per pixel, the 16-byte channel slots XOR-swizzled by the entry index, row pitch 24 entries —
+//     a 4 x 8 sub-tile's rows then start 8 keys apart and its 32 lanes read 32 distinct slots;
+//   * wave w owns output channels [32 w, 32 w + 32) and ALL four 4 x 8 sub-tiles: one weight fragment feeds four MFMAs, and the
+//     fragments come from the fragment-major copy of the packed filter (icaf.h: icaf_conv_args.wf; one coalesced 16-byte load per
+//     lane = one MFMA A operand), three 4-step slices ahead in registers: no weight ring, no barrier inside the K loop;
+//   * the chained 1x1 (C3: b_i.cv2 -> b_{i+1}.cv1) takes its weights through the same per-wave stream.
+// K walks (ky, kx, cin) in igemm's order with igemm's MFMA step, and the epilogue repeats the shared epilogue's expressions (bias +
+// SiLU on the fp32 accumulator, rounding to the storage type, residual added to the rounded value, chained 1x1 on the tile as
+// stored): results are bit-identical to every other launch configuration of the layer (tests/test_gpu_fullsize.py).
+#include "conv_common.h"
+
+// Ablation switches for timing studies (tools/quick_variant.py -DICAF_CW_ABL=n; results are then meaningless):
+//   1 = no halo-patch DMA, 2 = no weight loads inside the K loop, 4 = no LDS fragment reads, 8 = no MFMAs, 16 = no residual loads
+#ifndef ICAF_CW_ABL
+#define ICAF_CW_ABL 0
+#endif
+
+namespace icaf {
+
+constexpr int CW_C = 128;                        // input channels = output channels of the 3x3
+constexpr int CW_TH = 8, CW_TW = 16;             // output pixels per workgroup
+constexpr int CW_HH = CW_TH + 2, CW_HWD = CW_TW + 2, CW_PITCH = 24;
+constexpr int CW_PB = CW_C * 2;                  // bytes per patch entry
+constexpr int CW_PATCH = CW_HH * CW_PITCH * CW_PB;        // 61440
+constexpr int CW_SO = CW_C * 2 + 16;             // staging row stride
+constexpr int CW_KSTEPS = 9 * CW_C / 16;         // 72
+constexpr int CW_SL = 4, CW_DEPTH = 3;           // K steps per weight slice; slices held in registers
+
+struct CwGeom { int tiles_x, tiles_y, ntile; };
+
+template <int DT, bool CHAIN>
+__global__ __launch_bounds__(256, 2) void cwide_kernel(const ConvP p, const CwGeom gm, const void* __restrict__ wfrag, const long long wf_gs) {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    static_assert(DT != ICAF_F32, "16-bit types");
+    constexpr int VEC = E::VEC;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char* patch = lds;
+    unsigned char* stg = lds;                                        // the output tile is staged over the patch once the K loop is done
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = 32-channel group
+    const int g = blockIdx.z;
+    const int tile = xcd_tile(gm.ntile);
+    const int per_img = gm.tiles_x * gm.tiles_y;
+    const int b = tile / per_img, tr = tile - b * per_img, ty = tr / gm.tiles_x;
+    const int y0 = ty * CW_TH, x0 = (tr - ty * gm.tiles_x) * CW_TW;
+
+    // ---- the wave's weight stream: 18 slices of the 3x3 filter, then (CHAIN) 2 slices of the chained 1x1 -----------------------
+    const u32x4* wf = (const u32x4*)((const T*)wfrag + g * wf_gs) + (long long)wave * CW_KSTEPS * 64 + lane;
+    u32x4 wq[CW_DEPTH][CW_SL];
+#pragma unroll
+    for (int u = 0; u < CW_DEPTH; ++u)
+#pragma unroll
+        for (int k = 0; k < CW_SL; ++k) wq[u][k] = wf[(u * CW_SL + k) * 64];
+
+    // ---- halo patch -> LDS -----------------------------------------------------------------------------------------------------
+    {
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.x + g * p.x_gs), 0, p.x_bytes, 0x00020000);
+        constexpr unsigned OOB = 0x80000000u;
+        const unsigned img_off = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.ldx * (unsigned)E::BYTES;
+#pragma unroll
+        for (int i = 0; i < CW_PATCH / 1024 / 4; ++i) {
+            const int j = wave + 4 * i;
+            const int L = (j << 6) + lane, idx = L >> 4;
+            const int cs = (L & 15) ^ (idx & 15);
+            const int hy = idx / CW_PITCH, hx = idx - hy * CW_PITCH;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const bool ok = hx < CW_HWD && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const unsigned voff = ok ? img_off + (unsigned)((gy * p.W + gx) * p.ldx) * E::BYTES + (unsigned)(cs << 4) : OOB;
+            if constexpr (!(ICAF_CW_ABL & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(patch + (j << 10)), 16, voff, 0, 0, 0);
+        }
+    }
+
+    // per-lane constants
+    T* __restrict__ yg = (T*)p.y + g * p.y_gs;
+    const T* __restrict__ rg = p.res ? (const T*)p.res + g * p.res_gs : nullptr;
+    const float alpha_acc = p.alpha_acc[g], alpha_res = p.alpha_res[g];
+    // staging row r (sub-tile major: sub-tile = 4 rows x 8 columns) -> output pixel index, or -1 outside the tensor
+    auto row_to_m = [&](int r) {
+        const int st = r >> 5, q = r & 31;
+        const int gy = y0 + (st >> 1) * 4 + (q >> 3), gx = x0 + (st & 1) * 8 + (q & 7);
+        return (gy < p.Ho && gx < p.Wo) ? (b * p.Ho + gy) * p.Wo + gx : -1;
+    };
+    constexpr int NIT = CW_TH * CW_TW * (CW_C / VEC) / 256;          // 16-byte vectors of the tile per thread (8)
+    u32x4 rres[NIT];
+    if (rg && !(ICAF_CW_ABL & 16)) {                                 // the residual vectors of this thread's flush positions: in flight during the K loop
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
+            const int m = row_to_m(row);
+            rres[it] = *(const u32x4*)(rg + (long long)(m < 0 ? 0 : m) * p.ldr + cv * VEC);
+        }
+    }
+    f32x4 bq[4], bq2[4];
+    {
+        const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
+        const float* __restrict__ bias2 = (CHAIN && p.bias2) ? p.bias2 + g * p.bias2_gs : nullptr;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int n = wave * 32 + 8 * qd + 4 * hi;
+            bq[qd] = bias ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bq2[qd] = bias2 ? *(const f32x4*)(bias2 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // this lane's pixel of each sub-tile: row l31 >> 3, column l31 & 7; patch entry of tap (0, 0)
+    int lbase[4];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) lbase[bb] = ((bb >> 1) * 4 + (l31 >> 3)) * CW_PITCH + (bb & 1) * 8 + (l31 & 7);
+
+    wait_vmcnt<0>();                               // patch (this wave's share), residual vectors, biases, first weight slices
+    __syncthreads();
+
+    // ---- K loop: 72 MFMA steps x 4 sub-tiles, weights from the register stream ----------------------------------------------------
+    f32x16 acc[4];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[bb][r] = 0.0f;
+    constexpr int NSLICE = CW_KSTEPS / CW_SL;      // 18
+    const u32x4* w2f = nullptr;
+    if constexpr (CHAIN) w2f = (const u32x4*)((const T*)p.w2 + g * p.w2_gs);
+#pragma unroll
+    for (int sl = 0; sl < NSLICE; ++sl) {
+        const int u = sl % CW_DEPTH;
+#pragma unroll
+        for (int k = 0; k < CW_SL; ++k) {
+            const int ks = sl * CW_SL + k, tap = ks >> 3, s = ks & 7, ky = tap / 3, kx = tap - 3 * ky;
+            const int toff = ky * CW_PITCH + kx;
+            u32x4 fp[4];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int idx = lbase[bb] + toff;
+                if constexpr (ICAF_CW_ABL & 4) fp[bb] = u32x4{(unsigned)idx, (unsigned)ks, 0x3f803f80u, 0x3f803f80u};
+                else fp[bb] = *(const u32x4*)(patch + (idx << 8) + ((((2 * s + hi) ^ idx) & 15) << 4));
+            }
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                if constexpr (ICAF_CW_ABL & 8) acc[bb][0] += __uint_as_float(wq[u][k][0] ^ fp[bb][0]);
+                else mma_step<DT>(acc[bb], wq[u][k], fp[bb]);
+            }
+        }
+        // refill the slot: slice sl + 3 of the filter, or (CHAIN) the chained 1x1's fragments behind it — row-major packed
+        // [Np2][Kp2], lane (hi, r) of step ks2 reads w2[32 wave + r][16 ks2 + 8 hi .. + 8]
+        if (sl + CW_DEPTH < NSLICE && !(ICAF_CW_ABL & 2)) {
+#pragma unroll
+            for (int k = 0; k < CW_SL; ++k) wq[u][k] = wf[((sl + CW_DEPTH) * CW_SL + k) * 64];
+        } else if constexpr (CHAIN) {
+            const int c2 = sl + CW_DEPTH - NSLICE;                   // 0 .. 2: the chained 1x1 has 8 steps = 2 slices
+            if (c2 < 2) {
+#pragma unroll
+                for (int k = 0; k < CW_SL; ++k)
+                    wq[u][k] = *(const u32x4*)((const T*)w2f + (long long)(wave * 32 + l31) * p.Kp2 + (c2 * CW_SL + k) * 16 + hi * 8);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                               // every wave has left the K loop: the patch may be overwritten by the staged tile
+
+    auto stage = [&](const f32x16 (&a)[4], const f32x4 (&bv)[4], float scale) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int nl = wave * 32 + 8 * qd + 4 * hi;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act<ICAF_ACT_SILU, DT>(a[bb][4 * qd + j] + bv[qd][j] + 0.0f) * scale;
+                u32x2 pk;
+                if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
+                else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
+                *(u32x2*)(stg + (bb * 32 + l31) * CW_SO + nl * E::BYTES) = pk;
+            }
+    };
+    stage(acc, bq, alpha_acc);
+    __syncthreads();
+    if constexpr (!CHAIN) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
+            const int m = row_to_m(row), n = cv * VEC;
+            if (m >= 0 && n < p.Cout) {
+                u32x4 sv = *(const u32x4*)(stg + row * CW_SO + cv * 16);
+                if (rg) {                          // the shared epilogue's arithmetic: staged value + alpha_res * residual
+                    float v[VEC], r[VEC];
+                    unpack16<DT>(sv, v);
+                    unpack16<DT>(rres[it], r);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) v[j] = __builtin_fmaf(alpha_res, r[j], v[j]);
+                    sv = pack16<DT>(v);
+                }
+                *(u32x4*)(yg + (long long)m * p.ldy + n) = sv;
+            }
+        }
+    } else {
+        // chained layer: y is completed now — staged vector + alpha_res * residual, written to y when the chain keeps it and BACK into
+        // the staging tile, which the chained 1x1 consumes as stored (igemm's CHAIN + WB)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
+            const int m = row_to_m(row), n = cv * VEC;
+            if (m >= 0 && n < p.Cout) {
+                u32x4 sv = *(const u32x4*)(stg + row * CW_SO + cv * 16);
+                if (rg) {
+                    float v[VEC], r[VEC];
+                    unpack16<DT>(sv, v);
+                    unpack16<DT>(rres[it], r);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) v[j] = __builtin_fmaf(alpha_res, r[j], v[j]);
+                    sv = pack16<DT>(v);
+                    *(u32x4*)(stg + row * CW_SO + cv * 16) = sv;
+                }
+                if (p.keep1) *(u32x4*)(yg + (long long)m * p.ldy + n) = sv;
+            }
+        }
+        __syncthreads();                           // the completed tile is visible
+        f32x16 acc2[4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[bb][r] = 0.0f;
+#pragma unroll
+        for (int ks2 = 0; ks2 < CW_C / 16; ++ks2) {                  // K = 128 channels of the tile: eight MFMA steps
+            // (slice c2 = ks2 / 4 of the chained weights sits in ring slot (NSLICE + c2) % CW_DEPTH — the refill order above)
+            const int u = (NSLICE + ks2 / CW_SL) % CW_DEPTH, k = ks2 % CW_SL;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const u32x4 fp2 = *(const u32x4*)(stg + (bb * 32 + l31) * CW_SO + ((2 * ks2 + hi) << 4));
+                mma_step<DT>(acc2[bb], wq[u][k], fp2);
+            }
+        }
+        __syncthreads();                           // the tile has been consumed
+        stage(acc2, bq2, 1.0f);
+        __syncthreads();
+        T* __restrict__ y2g = (T*)p.y2 + g * p.y2_gs;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
+            const int m = row_to_m(row), n = cv * VEC;
+            if (m >= 0 && n < p.Cout2) *(u32x4*)(y2g + (long long)m * p.ldy2 + n) = *(const u32x4*)(stg + row * CW_SO + cv * 16);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+int cwide_check(const icaf_conv_args* a, const ConvP& p) {
+    if (a->dtype == ICAF_F32 || a->out_dtype != a->dtype) return fail(ICAF_ERR_UNSUPPORTED, "cwide: 16-bit types, out dtype == dtype");
+    if (a->kh != 3 || a->kw != 3 || a->sh != 1 || a->sw != 1 || a->ph != 1 || a->pw != 1) return fail(ICAF_ERR_UNSUPPORTED, "cwide: 3x3 / stride 1 / pad 1 layers");
+    if (a->Cin != CW_C || a->Cout != CW_C || a->Kp != 9 * CW_C) return fail(ICAF_ERR_UNSUPPORTED, "cwide: built for 128 -> 128 channels (Cin = %d, Cout = %d, Kp = %d)", a->Cin, a->Cout, a->Kp);
+    if (a->act != ICAF_ACT_SILU || a->pre) return fail(ICAF_ERR_UNSUPPORTED, "cwide: SiLU layers without a pre-activation term");
+    if (!a->wf) return fail(ICAF_ERR_UNSUPPORTED, "cwide: needs the fragment-major weight copy (icaf_conv_args.wf)");
+    if (p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "cwide: operand exceeds the 2 GiB buffer-descriptor range");
+    if (!p.vec_y || (a->res && !p.vec_r)) return fail(ICAF_ERR_UNSUPPORTED, "cwide: y / res must take 16-byte vectors");
+    if (a->w2) {
+        if (a->Cout2 > CW_C || a->Cout2 % 32 || a->Kp2 != CW_C || !p.vec_y2) return fail(ICAF_ERR_UNSUPPORTED, "cwide: chained 1x1 of 128 -> (32, 64, 96 or 128) channels with Kp2 = 128");
+        if (a->res && !a->chain_keep) return fail(ICAF_ERR_UNSUPPORTED, "cwide: a residual needs chain_keep");
+        if (a->chain_keep && (a->alpha_acc[0] != 1.0f || a->alpha_acc[1] != 1.0f)) return fail(ICAF_ERR_UNSUPPORTED, "cwide: chain_keep with alpha_acc != 1");
+    }
+    return ICAF_OK;
+}
+
+template <int DT, bool CHAIN>
+static int launch_cwide_cfg(const icaf_conv_args* a, const ConvP& p, hipStream_t s) {
+    CwGeom gm;
+    gm.tiles_x = (p.Wo + CW_TW - 1) / CW_TW;
+    gm.tiles_y = (p.Ho + CW_TH - 1) / CW_TH;
+    gm.ntile = p.B * gm.tiles_x * gm.tiles_y;
+    static std::atomic<bool> attr{false};
+    if (!attr) {
+        ICAF_HIP(hipFuncSetAttribute((const void*)cwide_kernel<DT, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_PATCH));
+        attr = true;
+    }
+    cwide_kernel<DT, CHAIN><<<dim3((unsigned)gm.ntile, 1, (unsigned)a->groups), dim3(256), CW_PATCH, s>>>(p, gm, a->wf, a->wf_gs);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+int launch_cwide(const icaf_conv_args* a, const ConvP& p, hipStream_t s) {
+    int st = cwide_check(a, p);
+    if (st) return st;
+    if (a->dtype == ICAF_BF16) return a->w2 ? launch_cwide_cfg<ICAF_BF16, true>(a, p, s) : launch_cwide_cfg<ICAF_BF16, false>(a, p, s);
+    return a->w2 ? launch_cwide_cfg<ICAF_F16, true>(a, p, s) : launch_cwide_cfg<ICAF_F16, false>(a, p, s);
+}
+
+}  // namespace icaf

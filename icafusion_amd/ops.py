@@ -100,6 +100,7 @@ def pack_conv_weight(w4d, dt, cin_pad=None):
 
 
 _FRAG_CACHE = {}
+CWIDE = os.environ.get("ICAF_CWIDE", "1") != "0"               # A/B switch: resident-patch / streamed-weights 3x3 kernel (cwide.hip) as a tuner candidate
 CSTREAM = os.environ.get("ICAF_CSTREAM", "1") != "0"           # A/B switch: persistent resident-filter 3x3 kernel as a tuner candidate
 WREG_GEMM = os.environ.get("ICAF_WREG_GEMM", "1") != "0"       # A/B switch: weights-from-registers kernels as tuner candidates
 
@@ -169,8 +170,9 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
     a.alpha_res[0], a.alpha_res[1] = float(ar[0]), float(ar[1])
     a.tile = tile
     wf = None
-    if (WREG_GEMM and x.dtype != torch.float32 and y.dtype == x.dtype and (cin * 2) % 128 == 0 and kp % 64 == 0 and pre is None
-            and chain is None and cout > 64):
+    cw_layer = (CWIDE and (kh, kw, sh, sw, ph, pw) == (3, 3, 1, 1, 1, 1) and cin == 128 and cout == 128 and act == ACT_SILU)      # cwide.hip
+    if (x.dtype != torch.float32 and y.dtype == x.dtype and (cin * 2) % 128 == 0 and kp % 64 == 0 and pre is None
+            and ((WREG_GEMM and chain is None and cout > 64) or cw_layer)):
         wf = frag_weights(w_packed)                   # igemm_wreg.hip: weight operand from registers (tile ids 61 / 62)
         a.wf, a.wf_gs = wf.data_ptr(), (wf.stride(0) if w_packed.dim() == 3 else 0)
     if pre is not None:               # fp32 coarse map (B, h, w, >= cout) added, bilinearly resized, before the activation
@@ -249,9 +251,13 @@ def conv_candidates(a):
     cands = []
     cs_ok = ((a.kh, a.kw, a.sh, a.sw, a.ph, a.pw) == (3, 3, 1, 1, 1, 1) and a.Cin == 64 and a.Cout <= 64 and a.Cout % 8 == 0 and a.dtype != F32
              and a.out_dtype == a.dtype and a.act == ACT_SILU and not a.pre and CSTREAM)
+    cw_ok = ((a.kh, a.kw, a.sh, a.sw, a.ph, a.pw) == (3, 3, 1, 1, 1, 1) and a.Cin == 128 and a.Cout == 128 and a.dtype != F32 and a.wf
+             and a.out_dtype == a.dtype and a.act == ACT_SILU and not a.pre and CWIDE)
     if a.w2:                           # chained 1x1: one N tile covering both layers, LDS-DMA pipelines 0 / 2
         t = 2 if max(a.Cout, a.Cout2) <= 64 else 1
         cands = [t, t + 20]
+        if cw_ok and a.Cout2 <= 128 and a.Cout2 % 32 == 0:
+            cands.append(81)                 # resident halo patch, weights (and the chained 1x1's) streamed into registers (cwide.hip)
         if cs_ok and a.Cout == 64 and a.Cout2 <= 64:
             cands.append(71)                 # persistent 3x3 with the filter (and the chained 1x1) resident in LDS (cstream.hip)
     elif a.pre:                          # pre-activation term: built for tiles 128x128 / 128x64 on the LDS-DMA pipelines 0 / 2
@@ -277,6 +283,8 @@ def conv_candidates(a):
             cands.append(51)                 # ... and 128 x 128; a launch the shape rules out returns an error and is skipped
     if cs_ok and not a.w2:
         cands.append(71)
+    if cw_ok and not a.w2:
+        cands.append(81)
     if a.wf and not a.pre and not a.w2:
         cands.append(61)                     # weights fed from registers (igemm_wreg.hip): 128 x 128 ...
         if a.Cout > 128:

@@ -254,6 +254,67 @@ def test_conv3x3_resident_filter_kernel(case, dt):
             close(from_act(outs[0][1][g] if G == 2 else outs[0][1]), F.silu(F.conv2d(q(m, dt), q(w2s[g], dt), b2s[g])), dt, f"cstream chain {case}", factor=2.0)
 
 
+CWIDE_CASES = [
+    # B, H, W, use_res, groups, chain (None | (cout2, keep)): 3x3 128 -> 128 from a resident halo patch, weights streamed into registers (cwide.hip, tile id 81)
+    (8, 40, 40, True, 2, None),             # Bottleneck.cv2 + shortcut at 40 x 40, both backbones: 15 tiles per image (right column half empty)
+    (4, 40, 40, False, 1, None),            # head C3 (no shortcut)
+    (3, 21, 27, True, 1, None),             # ragged map: partial tiles on both edges
+    (1, 8, 16, False, 1, None),             # ONE tile
+    (8, 40, 40, True, 2, (128, True)),      # 3x3 + shortcut, then the next Bottleneck's 1x1 (chain_keep): y and y2
+    (3, 33, 17, False, 1, (128, False)),    # chained 1x1 without keeping y, ragged map
+    (2, 24, 40, True, 1, (64, True)),       # narrower chained layer
+]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", CWIDE_CASES)
+def test_conv3x3_resident_patch_streamed_weights_kernel(case, dt):
+    """cwide.hip vs torch and BIT-EXACT vs igemm (same K order, MFMA step, epilogue / chain expressions): ragged maps, the residual,
+    the chained 1x1 with and without chain_keep, and the paired launch."""
+    B, H, W, use_res, G, chain = case
+    cin = cout = 128
+    xs = [rnd((B, cin, H, W), 171 + g) for g in range(G)]
+    ws = [rnd((cout, cin, 3, 3), 173 + g, 1.0 / math.sqrt(cin * 9)) for g in range(G)]
+    bs = [rnd((cout,), 175 + g, 0.2) for g in range(G)]
+    rs = [rnd((B, cout, H, W), 177 + g) for g in range(G)] if use_res else None
+    stk = (lambda t: torch.stack(t).contiguous()) if G == 2 else (lambda t: t[0])
+    xa = stk([to_act(x, dt) for x in xs])
+    packs = [ops.pack_conv_weight(w.to(DEV), dt) for w in ws]
+    wp, kp = stk([p0[0] for p0 in packs]), packs[0][1]
+    bp = stk([ops.pack_bias(b.to(DEV), cout) for b in bs])
+    ra = stk([to_act(r, dt) for r in rs]) if use_res else None
+    ch = None
+    if chain:
+        c2, keep = chain
+        w2s = [rnd((c2, cout, 1, 1), 181 + g, 1.0 / math.sqrt(cout)) for g in range(G)]
+        b2s = [rnd((c2,), 183 + g, 0.2) for g in range(G)]
+        p2 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w2s]
+        w2p, kp2 = stk([p0[0] for p0 in p2]), p2[0][1]
+        b2p = stk([ops.pack_bias(b.to(DEV), c2) for b in b2s])
+    outs = []
+    for tile in (81, 28 if not chain else 21):
+        shape = (G, B, H, W) if G == 2 else (B, H, W)
+        y = torch.full(shape + (cout + 8,), 7.0, dtype=dt, device=DEV)[..., :cout]
+        if chain:
+            y2 = torch.full(shape + (c2 + 8,), 7.0, dtype=dt, device=DEV)[..., :c2]
+            ch = dict(w=w2p, kp=kp2, bias=b2p, y=y2, cout=c2, keep=keep)
+        run(ops.conv2d(xa, wp, kp, bp, y, 3, 3, 1, 1, 1, 1, cin, cout, ops.ACT_SILU, res=ra if (not chain or chain[1]) else None,
+                       alpha_res=1.25 if not chain else 1.0, tile=tile, chain=ch))
+        outs.append((y.clone(), ch["y"].clone() if chain else None))
+    if not chain or chain[1]:
+        assert torch.equal(outs[0][0], outs[1][0]), f"cwide y != igemm, max diff {(outs[0][0].float() - outs[1][0].float()).abs().max().item()}"
+    if chain:
+        assert torch.equal(outs[0][1], outs[1][1]), f"cwide y2 != igemm, max diff {(outs[0][1].float() - outs[1][1].float()).abs().max().item()}"
+    for g in range(G):
+        m = F.silu(F.conv2d(q(xs[g], dt), q(ws[g], dt), bs[g], 1, 1))
+        if use_res and (not chain or chain[1]):
+            m = m + (1.25 if not chain else 1.0) * q(rs[g], dt)
+        if not chain or chain[1]:
+            close(from_act(outs[0][0][g] if G == 2 else outs[0][0]), m, dt, f"cwide {case} group {g}", factor=2.0)
+        if chain:
+            close(from_act(outs[0][1][g] if G == 2 else outs[0][1]), F.silu(F.conv2d(q(m, dt), q(w2s[g], dt), b2s[g])), dt, f"cwide chain {case}", factor=2.0)
+
+
 WREG_CASES = [
     # B, H, W, cin, cout, k, stride, act, use_res, groups, shape (tile id 60 + shape): weight operand fed from registers (igemm_wreg.hip)
     (4, 40, 40, 128, 128, 3, 1, ops.ACT_SILU, True, 2, 1),      # Bottleneck 3x3 + shortcut, both backbones: 18 K slices

@@ -229,7 +229,8 @@ def test_committed_tune_caches_only_name_configurations_the_tuner_would_time():
     for f in files:
         for key, tile in json.load(open(f)):
             (M, cout, cin, kh, kw, sh, sw, H, W, ldx, ldy, groups, dtype, out_dtype, act, res, pre, cout2, chain_keep) = key
-            wf = dtype != ops.F32 and out_dtype == dtype and (cin * 2) % 128 == 0 and not pre and not cout2 and cout > 64   # ops.conv2d's rule
+            cw = (kh, kw, sh, sw) == (3, 3, 1, 1) and cin == 128 and cout == 128 and act == ops.ACT_SILU
+            wf = (dtype != ops.F32 and out_dtype == dtype and (cin * 2) % 128 == 0 and not pre and ((not cout2 and cout > 64) or cw))   # ops.conv2d's rule
             a = SimpleNamespace(Cout=cout, Cin=cin, kh=kh, kw=kw, sh=sh, sw=sw, ph=kh // 2, pw=kw // 2, dtype=dtype, out_dtype=out_dtype,
                                 act=act, pre=bool(pre), w2=bool(cout2), Cout2=cout2, res=bool(res), wf=wf)
             assert tile in ops.conv_candidates(a), (os.path.basename(f), key, tile)
