@@ -1,17 +1,20 @@
-// 3x3 / stride 1 convolution for the 128-channel layers at 40 x 40 (C3 Bottlenecks of the P4 backbones, the head's 3x3 layers) on
-// gfx950: halo patch RESIDENT in LDS, weights streamed PER WAVE from L2 straight into registers.
+// 3x3 convolutions (stride 1 or 2) of the 64- / 128-channel layers with 128 or more output channels on gfx950: halo patch RESIDENT
+// in LDS, weights streamed PER WAVE from L2 straight into registers.  (C3 Bottlenecks of the P4 backbones, the head's 3x3 layers at
+// 40 x 40, the down-sampling convolutions 160 -> 80 and 80 -> 40.)
 //
 // What bounds these layers in the implicit-GEMM kernel (igemm.hip) is not HBM and not the MFMA pipe but the feed: a 128 x 128 tile
-// with K = 9 x 128 moves 590 KB through 576 LDS-DMA instructions (the pixel operand re-fetched once per filter tap, the weights
-// through the same ring), every MFMA pair waits on two b128 fragment reads, and a barrier closes every 64-K slice — measured 24 %
-// of the MFMA peak at batch 32.  Here a workgroup (4 wavefronts, two workgroups per CU) owns an 8 x 16 patch of output pixels:
-//   * its 10 x 18 input halo patch is fetched ONCE (60 DMA instructions; out-of-image pixels zero-filled by the descriptor range
-//     check), pixel-major, 256 bytes per pixel, the 16-byte channel slots XOR-swizzled by the entry index, row pitch 24 entries —
-//     a 4 x 8 sub-tile's rows then start 8 keys apart and its 32 lanes read 32 distinct slots;
-//   * wave w owns output channels [32 w, 32 w + 32) and ALL four 4 x 8 sub-tiles: one weight fragment feeds four MFMAs, and the
-//     fragments come from the fragment-major copy of the packed filter (icaf.h: icaf_conv_args.wf; one coalesced 16-byte load per
-//     lane = one MFMA A operand), three 4-step slices ahead in registers: no weight ring, no barrier inside the K loop;
-//   * the chained 1x1 (C3: b_i.cv2 -> b_{i+1}.cv1) takes its weights through the same per-wave stream.
+// with K = 9 x 128 moves 590 KB through 576 LDS-DMA instructions (the pixel operand re-fetched once per filter tap — with stride 2
+// neighbouring output pixels share nothing of a tap's row — and the weights through the same ring), every MFMA pair waits on two
+// b128 fragment reads, and a barrier closes every 64-K slice: measured 24 % of the MFMA peak at batch 32.  Here a workgroup
+// (4 wavefronts) owns an 8 x 16 or 8 x 8 patch of output pixels and 128 output channels:
+//   * its input halo patch ((TH-1)S+3 x (TW-1)S+3 pixels) is fetched ONCE by LDS-DMA (out-of-image pixels zero-filled by the
+//     descriptor range check), pixel-major, the 16-byte channel slots of a pixel XOR-swizzled by the entry index (ctile.hip's
+//     layout); for stride 2 a row holds its even columns, then its odd columns, so a tap still reads consecutive entries for
+//     consecutive output pixels;
+//   * wave w owns output channels [32 w, 32 w + 32) of the block and ALL the 4 x 8 sub-tiles: one weight fragment feeds NSUB MFMAs,
+//     and the fragments come from the fragment-major copy of the packed filter (icaf.h: icaf_conv_args.wf; one coalesced 16-byte
+//     load per lane = one MFMA A operand), three 4-step slices ahead in registers: no weight ring, no barrier inside the K loop;
+//   * the chained 1x1 (128 -> <= 128) takes its weights through the same per-wave stream.
 // K walks (ky, kx, cin) in igemm's order with igemm's MFMA step, and the epilogue repeats the shared epilogue's expressions (bias +
 // SiLU on the fp32 accumulator, rounding to the storage type, residual added to the rounded value, chained 1x1 on the tile as
 // stored): results are bit-identical to every other launch configuration of the layer (tests/test_gpu_fullsize.py).
@@ -25,56 +28,83 @@
 
 namespace icaf {
 
-constexpr int CW_C = 128;                        // input channels = output channels of the 3x3
-constexpr int CW_TH = 8, CW_TW = 16;             // output pixels per workgroup
-constexpr int CW_HH = CW_TH + 2, CW_HWD = CW_TW + 2, CW_PITCH = 24;
-constexpr int CW_PB = CW_C * 2;                  // bytes per patch entry
-constexpr int CW_PATCH = CW_HH * CW_PITCH * CW_PB;        // 61440
-constexpr int CW_SO = CW_C * 2 + 16;             // staging row stride
-constexpr int CW_KSTEPS = 9 * CW_C / 16;         // 72
+constexpr int CW_N = 128;                        // output channels per workgroup (4 waves x 32)
+constexpr int CW_TH = 8;                         // output rows per workgroup
+constexpr int CW_SO = CW_N * 2 + 16;             // staging row stride
 constexpr int CW_SL = 4, CW_DEPTH = 3;           // K steps per weight slice; slices held in registers
+
+// NSUB = 4: 8 x 16 output pixels per workgroup (four 4 x 8 sub-tiles per wave); NSUB = 2: 8 x 8 (two sub-tiles per wave: a 40 x 40
+// map is covered without the half-empty right column of the 16-wide tiling and the smaller patch lets one more workgroup share the
+// CU — at twice the weight traffic per pixel, which the L2 can afford here).
+template <int CIN, int STR, int NSUB> struct CwTile {
+    static constexpr int TW = NSUB == 4 ? 16 : 8;
+    static constexpr int HH = (CW_TH - 1) * STR + 3, HWD = (TW - 1) * STR + 3;
+    static constexpr int EH = STR == 2 ? TW + 1 : 0;                    // stride 2: entries of a row's even-column plane (odd: TW)
+    // stride 1: rows of a 4 x 8 sub-tile 8 swizzle keys apart (256-byte entries: pitch = 8 mod 16) where the LDS allows it
+    static constexpr int PITCH = STR == 2 ? ((HWD + 1) & ~1) : (NSUB == 4 ? 24 : HWD);
+    static constexpr int PB = CIN * 2;                                // bytes per patch entry (pixel)
+    static constexpr int LSP = CIN == 64 ? 3 : 4, SP = 1 << LSP, GSH = 4 - LSP;      // 16-byte slots per entry; swizzle key = (idx >> GSH) & (SP - 1)
+    static constexpr int NENT = HH * PITCH;
+    static constexpr int PATCH = (NENT * PB + 1023) / 1024 * 1024;
+    static constexpr int NPX = CW_TH * TW;
+    static constexpr int KSTEPS = 9 * CIN / 16, NSLICE = KSTEPS / CW_SL;
+    static constexpr int LDS = PATCH > NPX * CW_SO ? PATCH : NPX * CW_SO;
+    static constexpr int WG_PER_CU = (160 * 1024) / LDS >= 3 ? 3 : (160 * 1024) / LDS >= 2 ? 2 : 1;
+    static_assert(CIN == 64 || CIN == 128, "entries of 128 or 256 bytes");
+    static_assert(NSLICE % CW_DEPTH == 0, "the register ring rotates statically");
+};
 
 struct CwGeom { int tiles_x, tiles_y, ntile; };
 
-template <int DT, bool CHAIN>
-__global__ __launch_bounds__(256, 2) void cwide_kernel(const ConvP p, const CwGeom gm, const void* __restrict__ wfrag, const long long wf_gs) {
+template <int DT, int CIN, int STR, int NSUB, bool CHAIN>
+__global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwide_kernel(const ConvP p, const CwGeom gm, const void* __restrict__ wfrag,
+                                                                                    const long long wf_gs) {
     using E = Elem<DT>;
     using T = typename E::type;
+    using G = CwTile<CIN, STR, NSUB>;
+    constexpr int S = STR;
     static_assert(DT != ICAF_F32, "16-bit types");
     constexpr int VEC = E::VEC;
+    constexpr int PITCH = G::PITCH, LSP = G::LSP, SP = G::SP, GSH = G::GSH, KSTEPS = G::KSTEPS, NSLICE = G::NSLICE;
+    constexpr int KPT = CIN / 16;                                    // MFMA steps per filter tap
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     unsigned char* patch = lds;
     unsigned char* stg = lds;                                        // the output tile is staged over the patch once the K loop is done
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = 32-channel group
-    const int g = blockIdx.z;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = 32-channel group of the block
+    const int g = blockIdx.z, n0 = blockIdx.y * CW_N;                // modality / first output channel of the block
     const int tile = xcd_tile(gm.ntile);
     const int per_img = gm.tiles_x * gm.tiles_y;
     const int b = tile / per_img, tr = tile - b * per_img, ty = tr / gm.tiles_x;
-    const int y0 = ty * CW_TH, x0 = (tr - ty * gm.tiles_x) * CW_TW;
+    const int y0 = ty * CW_TH, x0 = (tr - ty * gm.tiles_x) * G::TW;  // output-pixel origin
 
-    // ---- the wave's weight stream: 18 slices of the 3x3 filter, then (CHAIN) 2 slices of the chained 1x1 -----------------------
-    const u32x4* wf = (const u32x4*)((const T*)wfrag + g * wf_gs) + (long long)wave * CW_KSTEPS * 64 + lane;
+    // ---- the wave's weight stream: NSLICE slices of the 3x3 filter, then (CHAIN) 2 slices of the chained 1x1 ---------------------
+    const u32x4* wf = (const u32x4*)((const T*)wfrag + g * wf_gs) + (long long)(blockIdx.y * 4 + wave) * KSTEPS * 64 + lane;
     u32x4 wq[CW_DEPTH][CW_SL];
 #pragma unroll
     for (int u = 0; u < CW_DEPTH; ++u)
 #pragma unroll
         for (int k = 0; k < CW_SL; ++k) wq[u][k] = wf[(u * CW_SL + k) * 64];
 
-    // ---- halo patch -> LDS -----------------------------------------------------------------------------------------------------
+    // ---- halo patch -> LDS (each DMA instruction fills 64 consecutive 16-byte slots) ------------------------------------------------
     {
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.x + g * p.x_gs), 0, p.x_bytes, 0x00020000);
         constexpr unsigned OOB = 0x80000000u;
         const unsigned img_off = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.ldx * (unsigned)E::BYTES;
+        const int gy0 = y0 * S - 1, gx0 = x0 * S - 1;
 #pragma unroll
-        for (int i = 0; i < CW_PATCH / 1024 / 4; ++i) {
+        for (int i = 0; i < (G::PATCH / 1024 + 3) / 4; ++i) {
             const int j = wave + 4 * i;
-            const int L = (j << 6) + lane, idx = L >> 4;
-            const int cs = (L & 15) ^ (idx & 15);
-            const int hy = idx / CW_PITCH, hx = idx - hy * CW_PITCH;
-            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            const bool ok = hx < CW_HWD && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            if (j >= G::PATCH / 1024) break;
+            const int L = (j << 6) + lane, idx = L >> LSP;
+            const int cs = (L & (SP - 1)) ^ ((idx >> GSH) & (SP - 1));
+            const int hy = idx / PITCH, rem = idx - hy * PITCH;
+            int hx;
+            if constexpr (S == 2) hx = rem < G::EH ? 2 * rem : 2 * (rem - G::EH) + 1;
+            else hx = rem;
+            const int gy = gy0 + hy, gx = gx0 + hx;
+            const bool ok = hy < G::HH && hx < G::HWD && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             const unsigned voff = ok ? img_off + (unsigned)((gy * p.W + gx) * p.ldx) * E::BYTES + (unsigned)(cs << 4) : OOB;
             if constexpr (!(ICAF_CW_ABL & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(patch + (j << 10)), 16, voff, 0, 0, 0);
         }
@@ -87,17 +117,17 @@ __global__ __launch_bounds__(256, 2) void cwide_kernel(const ConvP p, const CwGe
     // staging row r (sub-tile major: sub-tile = 4 rows x 8 columns) -> output pixel index, or -1 outside the tensor
     auto row_to_m = [&](int r) {
         const int st = r >> 5, q = r & 31;
-        const int gy = y0 + (st >> 1) * 4 + (q >> 3), gx = x0 + (st & 1) * 8 + (q & 7);
+        const int gy = y0 + (NSUB == 4 ? (st >> 1) : st) * 4 + (q >> 3), gx = x0 + (NSUB == 4 ? (st & 1) * 8 : 0) + (q & 7);
         return (gy < p.Ho && gx < p.Wo) ? (b * p.Ho + gy) * p.Wo + gx : -1;
     };
-    constexpr int NIT = CW_TH * CW_TW * (CW_C / VEC) / 256;          // 16-byte vectors of the tile per thread (8)
+    constexpr int NIT = G::NPX * (CW_N / VEC) / 256;                 // 16-byte vectors of the tile per thread (8 / 4)
     u32x4 rres[NIT];
     if (rg && !(ICAF_CW_ABL & 16)) {                                 // the residual vectors of this thread's flush positions: in flight during the K loop
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
             const int m = row_to_m(row);
-            rres[it] = *(const u32x4*)(rg + (long long)(m < 0 ? 0 : m) * p.ldr + cv * VEC);
+            rres[it] = *(const u32x4*)(rg + (long long)(m < 0 ? 0 : m) * p.ldr + n0 + cv * VEC);
         }
     }
     f32x4 bq[4], bq2[4];
@@ -107,43 +137,43 @@ __global__ __launch_bounds__(256, 2) void cwide_kernel(const ConvP p, const CwGe
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const int n = wave * 32 + 8 * qd + 4 * hi;
-            bq[qd] = bias ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bq[qd] = bias ? *(const f32x4*)(bias + n0 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
             bq2[qd] = bias2 ? *(const f32x4*)(bias2 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     // this lane's pixel of each sub-tile: row l31 >> 3, column l31 & 7; patch entry of tap (0, 0)
-    int lbase[4];
+    int lbase[NSUB];
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) lbase[bb] = ((bb >> 1) * 4 + (l31 >> 3)) * CW_PITCH + (bb & 1) * 8 + (l31 & 7);
+    for (int bb = 0; bb < NSUB; ++bb)
+        lbase[bb] = ((NSUB == 4 ? (bb >> 1) : bb) * 4 + (l31 >> 3)) * S * PITCH + (NSUB == 4 ? (bb & 1) * 8 : 0) + (l31 & 7);
 
     wait_vmcnt<0>();                               // patch (this wave's share), residual vectors, biases, first weight slices
     __syncthreads();
 
-    // ---- K loop: 72 MFMA steps x 4 sub-tiles, weights from the register stream ----------------------------------------------------
-    f32x16 acc[4];
+    // ---- K loop: KSTEPS MFMA steps x NSUB sub-tiles, weights from the register stream ----------------------------------------------
+    f32x16 acc[NSUB];
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb)
+    for (int bb = 0; bb < NSUB; ++bb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[bb][r] = 0.0f;
-    constexpr int NSLICE = CW_KSTEPS / CW_SL;      // 18
-    const u32x4* w2f = nullptr;
-    if constexpr (CHAIN) w2f = (const u32x4*)((const T*)p.w2 + g * p.w2_gs);
+    const T* w2f = nullptr;
+    if constexpr (CHAIN) w2f = (const T*)p.w2 + g * p.w2_gs;
 #pragma unroll
     for (int sl = 0; sl < NSLICE; ++sl) {
         const int u = sl % CW_DEPTH;
 #pragma unroll
         for (int k = 0; k < CW_SL; ++k) {
-            const int ks = sl * CW_SL + k, tap = ks >> 3, s = ks & 7, ky = tap / 3, kx = tap - 3 * ky;
-            const int toff = ky * CW_PITCH + kx;
-            u32x4 fp[4];
+            const int ks = sl * CW_SL + k, tap = ks / KPT, s = ks - tap * KPT, ky = tap / 3, kx = tap - 3 * ky;
+            const int toff = ky * PITCH + (S == 2 ? (kx & 1) * G::EH + (kx >> 1) : kx);
+            u32x4 fp[NSUB];
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
+            for (int bb = 0; bb < NSUB; ++bb) {
                 const int idx = lbase[bb] + toff;
                 if constexpr (ICAF_CW_ABL & 4) fp[bb] = u32x4{(unsigned)idx, (unsigned)ks, 0x3f803f80u, 0x3f803f80u};
-                else fp[bb] = *(const u32x4*)(patch + (idx << 8) + ((((2 * s + hi) ^ idx) & 15) << 4));
+                else fp[bb] = *(const u32x4*)(patch + ((((idx << LSP) + (((2 * s + hi) ^ (idx >> GSH)) & (SP - 1)))) << 4));
             }
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
+            for (int bb = 0; bb < NSUB; ++bb) {
                 if constexpr (ICAF_CW_ABL & 8) acc[bb][0] += __uint_as_float(wq[u][k][0] ^ fp[bb][0]);
                 else mma_step<DT>(acc[bb], wq[u][k], fp[bb]);
             }
@@ -155,19 +185,19 @@ __global__ __launch_bounds__(256, 2) void cwide_kernel(const ConvP p, const CwGe
             for (int k = 0; k < CW_SL; ++k) wq[u][k] = wf[((sl + CW_DEPTH) * CW_SL + k) * 64];
         } else if constexpr (CHAIN) {
             const int c2 = sl + CW_DEPTH - NSLICE;                   // 0 .. 2: the chained 1x1 has 8 steps = 2 slices
-            if (c2 < 2) {
+            if (c2 >= 0 && c2 < 2) {
 #pragma unroll
                 for (int k = 0; k < CW_SL; ++k)
-                    wq[u][k] = *(const u32x4*)((const T*)w2f + (long long)(wave * 32 + l31) * p.Kp2 + (c2 * CW_SL + k) * 16 + hi * 8);
+                    wq[u][k] = *(const u32x4*)(w2f + (long long)(wave * 32 + l31) * p.Kp2 + (c2 * CW_SL + k) * 16 + hi * 8);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);         // (left alone the scheduler hoists the fragment reads of several slices: registers)
     }
     __syncthreads();                               // every wave has left the K loop: the patch may be overwritten by the staged tile
 
-    auto stage = [&](const f32x16 (&a)[4], const f32x4 (&bv)[4], float scale) {
+    auto stage = [&](const f32x16 (&a)[NSUB], const f32x4 (&bv)[4], float scale) {
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
+        for (int bb = 0; bb < NSUB; ++bb)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int nl = wave * 32 + 8 * qd + 4 * hi;
@@ -186,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void cwide_kernel(const ConvP p, const CwGe
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
-            const int m = row_to_m(row), n = cv * VEC;
+            const int m = row_to_m(row), n = n0 + cv * VEC;
             if (m >= 0 && n < p.Cout) {
                 u32x4 sv = *(const u32x4*)(stg + row * CW_SO + cv * 16);
                 if (rg) {                          // the shared epilogue's arithmetic: staged value + alpha_res * residual
@@ -201,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void cwide_kernel(const ConvP p, const CwGe
             }
         }
     } else {
-        // chained layer: y is completed now — staged vector + alpha_res * residual, written to y when the chain keeps it and BACK into
-        // the staging tile, which the chained 1x1 consumes as stored (igemm's CHAIN + WB)
+        // chained layer (one channel block: n0 = 0): y is completed now — staged vector + alpha_res * residual, written to y when the
+        // chain keeps it and BACK into the staging tile, which the chained 1x1 consumes as stored (igemm's CHAIN + WB)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
@@ -222,17 +252,17 @@ __global__ __launch_bounds__(256, 2) void cwide_kernel(const ConvP p, const CwGe
             }
         }
         __syncthreads();                           // the completed tile is visible
-        f32x16 acc2[4];
+        f32x16 acc2[NSUB];
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
+        for (int bb = 0; bb < NSUB; ++bb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[bb][r] = 0.0f;
 #pragma unroll
-        for (int ks2 = 0; ks2 < CW_C / 16; ++ks2) {                  // K = 128 channels of the tile: eight MFMA steps
+        for (int ks2 = 0; ks2 < CW_N / 16; ++ks2) {                  // K = 128 channels of the tile: eight MFMA steps
             // (slice c2 = ks2 / 4 of the chained weights sits in ring slot (NSLICE + c2) % CW_DEPTH — the refill order above)
             const int u = (NSLICE + ks2 / CW_SL) % CW_DEPTH, k = ks2 % CW_SL;
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
+            for (int bb = 0; bb < NSUB; ++bb) {
                 const u32x4 fp2 = *(const u32x4*)(stg + (bb * 32 + l31) * CW_SO + ((2 * ks2 + hi) << 4));
                 mma_step<DT>(acc2[bb], wq[u][k], fp2);
             }
@@ -253,43 +283,68 @@ __global__ __launch_bounds__(256, 2) void cwide_kernel(const ConvP p, const CwGe
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-int cwide_check(const icaf_conv_args* a, const ConvP& p) {
+struct CwShape { int cin, s, nsub; const char* tag; };
+static const CwShape kCw[] = {{128, 1, 4, "8x16n128"}, {128, 1, 2, "8x8n128"}, {64, 2, 4, "8x16n128s2c64"}, {128, 2, 2, "8x8n128s2"}, {64, 2, 2, "8x8n128s2c64"}};
+constexpr int CW_NSHAPES = 5;
+
+const char* cwide_tag(int shape) { return (shape >= 1 && shape <= CW_NSHAPES) ? kCw[shape - 1].tag : "?"; }
+
+int cwide_check(const icaf_conv_args* a, const ConvP& p, int shape) {
+    if (shape < 1 || shape > CW_NSHAPES) return fail(ICAF_ERR_ARG, "cwide: unknown shape %d", shape);
+    const CwShape& sh = kCw[shape - 1];
     if (a->dtype == ICAF_F32 || a->out_dtype != a->dtype) return fail(ICAF_ERR_UNSUPPORTED, "cwide: 16-bit types, out dtype == dtype");
-    if (a->kh != 3 || a->kw != 3 || a->sh != 1 || a->sw != 1 || a->ph != 1 || a->pw != 1) return fail(ICAF_ERR_UNSUPPORTED, "cwide: 3x3 / stride 1 / pad 1 layers");
-    if (a->Cin != CW_C || a->Cout != CW_C || a->Kp != 9 * CW_C) return fail(ICAF_ERR_UNSUPPORTED, "cwide: built for 128 -> 128 channels (Cin = %d, Cout = %d, Kp = %d)", a->Cin, a->Cout, a->Kp);
+    if (a->kh != 3 || a->kw != 3 || a->sh != sh.s || a->sw != sh.s || a->ph != 1 || a->pw != 1) return fail(ICAF_ERR_UNSUPPORTED, "cwide %s: 3x3 / stride %d / pad 1 layers", sh.tag, sh.s);
+    if (a->Cin != sh.cin || a->Cout % CW_N || a->Kp != 9 * sh.cin) return fail(ICAF_ERR_UNSUPPORTED, "cwide %s: built for %d -> (multiples of 128) channels (Cin = %d, Cout = %d, Kp = %d)", sh.tag, sh.cin, a->Cin, a->Cout, a->Kp);
     if (a->act != ICAF_ACT_SILU || a->pre) return fail(ICAF_ERR_UNSUPPORTED, "cwide: SiLU layers without a pre-activation term");
     if (!a->wf) return fail(ICAF_ERR_UNSUPPORTED, "cwide: needs the fragment-major weight copy (icaf_conv_args.wf)");
     if (p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "cwide: operand exceeds the 2 GiB buffer-descriptor range");
     if (!p.vec_y || (a->res && !p.vec_r)) return fail(ICAF_ERR_UNSUPPORTED, "cwide: y / res must take 16-byte vectors");
     if (a->w2) {
-        if (a->Cout2 > CW_C || a->Cout2 % 32 || a->Kp2 != CW_C || !p.vec_y2) return fail(ICAF_ERR_UNSUPPORTED, "cwide: chained 1x1 of 128 -> (32, 64, 96 or 128) channels with Kp2 = 128");
+        if (a->Cout != CW_N || a->Cout2 > CW_N || a->Cout2 % 32 || a->Kp2 != CW_N || !p.vec_y2) return fail(ICAF_ERR_UNSUPPORTED, "cwide: chained 1x1 of 128 -> (32, 64, 96 or 128) channels with Kp2 = 128");
         if (a->res && !a->chain_keep) return fail(ICAF_ERR_UNSUPPORTED, "cwide: a residual needs chain_keep");
         if (a->chain_keep && (a->alpha_acc[0] != 1.0f || a->alpha_acc[1] != 1.0f)) return fail(ICAF_ERR_UNSUPPORTED, "cwide: chain_keep with alpha_acc != 1");
     }
     return ICAF_OK;
 }
 
-template <int DT, bool CHAIN>
+template <int DT, int CIN, int STR, int NSUB, bool CHAIN>
 static int launch_cwide_cfg(const icaf_conv_args* a, const ConvP& p, hipStream_t s) {
+    using G = CwTile<CIN, STR, NSUB>;
     CwGeom gm;
-    gm.tiles_x = (p.Wo + CW_TW - 1) / CW_TW;
+    gm.tiles_x = (p.Wo + G::TW - 1) / G::TW;
     gm.tiles_y = (p.Ho + CW_TH - 1) / CW_TH;
     gm.ntile = p.B * gm.tiles_x * gm.tiles_y;
     static std::atomic<bool> attr{false};
     if (!attr) {
-        ICAF_HIP(hipFuncSetAttribute((const void*)cwide_kernel<DT, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_PATCH));
+        ICAF_HIP(hipFuncSetAttribute((const void*)cwide_kernel<DT, CIN, STR, NSUB, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         attr = true;
     }
-    cwide_kernel<DT, CHAIN><<<dim3((unsigned)gm.ntile, 1, (unsigned)a->groups), dim3(256), CW_PATCH, s>>>(p, gm, a->wf, a->wf_gs);
+    cwide_kernel<DT, CIN, STR, NSUB, CHAIN><<<dim3((unsigned)gm.ntile, (unsigned)(a->Cout / CW_N), (unsigned)a->groups), dim3(256), G::LDS, s>>>(p, gm, a->wf, a->wf_gs);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
 
-int launch_cwide(const icaf_conv_args* a, const ConvP& p, hipStream_t s) {
-    int st = cwide_check(a, p);
+template <int DT, int CIN, int STR, int NSUB>
+static int launch_cwide_ch(const icaf_conv_args* a, const ConvP& p, hipStream_t s) {
+    return a->w2 ? launch_cwide_cfg<DT, CIN, STR, NSUB, true>(a, p, s) : launch_cwide_cfg<DT, CIN, STR, NSUB, false>(a, p, s);
+}
+
+template <int DT>
+static int launch_cwide_dt(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s) {
+    switch (shape) {
+        case 1: return launch_cwide_ch<DT, 128, 1, 4>(a, p, s);
+        case 2: return launch_cwide_ch<DT, 128, 1, 2>(a, p, s);
+        case 3: return launch_cwide_ch<DT, 64, 2, 4>(a, p, s);
+        case 4: return launch_cwide_ch<DT, 128, 2, 2>(a, p, s);
+        default: return launch_cwide_ch<DT, 64, 2, 2>(a, p, s);
+    }
+}
+
+// shapes: see kCw (tile id 80 + shape)
+int launch_cwide(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s) {
+    int st = cwide_check(a, p, shape);
     if (st) return st;
-    if (a->dtype == ICAF_BF16) return a->w2 ? launch_cwide_cfg<ICAF_BF16, true>(a, p, s) : launch_cwide_cfg<ICAF_BF16, false>(a, p, s);
-    return a->w2 ? launch_cwide_cfg<ICAF_F16, true>(a, p, s) : launch_cwide_cfg<ICAF_F16, false>(a, p, s);
+    return a->dtype == ICAF_BF16 ? launch_cwide_dt<ICAF_BF16>(a, p, shape, s) : launch_cwide_dt<ICAF_F16>(a, p, shape, s);
 }
 
 }  // namespace icaf

@@ -458,8 +458,9 @@ const char* stream_tag(int shape);
 int cstream_check(const icaf_conv_args* a, const ConvP& p);
 int launch_cstream(const icaf_conv_args* a, const ConvP& p, hipStream_t s);
 // cwide.hip
-int cwide_check(const icaf_conv_args* a, const ConvP& p);
-int launch_cwide(const icaf_conv_args* a, const ConvP& p, hipStream_t s);
+int cwide_check(const icaf_conv_args* a, const ConvP& p, int shape);
+int launch_cwide(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
+const char* cwide_tag(int shape);
 // igemm_wreg.hip
 int wreg_check(const icaf_conv_args* a, const ConvP& p, int shape);
 int launch_wreg(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
@@ -468,7 +469,7 @@ const char* wreg_tag(int shape);
 //   40 + shape: 3x3 direct convolution from an LDS halo tile (ctile.hip); 50 + shape: persistent streaming GEMM for 1x1 layers
 //   (igemm_stream.hip); 60 + shape: weight operand fed from registers (igemm_wreg.hip); an explicit request that the layer cannot
 //   satisfy is an error (the autotuner skips it), it is never chosen silently.  71: persistent 3x3 with a resident filter (cstream.hip);
-//   81: 3x3 from a resident halo patch with the weights streamed per wave into registers (cwide.hip).
+//   80 + shape: 3x3 (stride 1 / 2) from a resident halo patch with the weights streamed per wave into registers (cwide.hip).
 static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
     const bool dma_ok = p.x_bytes != 0;
     if (a->tile > 40 && a->tile < 90) return a->tile;
@@ -706,7 +707,7 @@ extern "C" int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s) {
     const int tile = pick_tile(a, p);
     hipStream_t hs = S(s);
     if (tile == 71) return launch_cstream(a, p, hs);        // persistent 3x3 with the filter resident in LDS (64 -> 64 channels)
-    if (tile == 81) return launch_cwide(a, p, hs);          // 3x3 from a resident halo patch, weights streamed into registers (128 -> 128)
+    if (tile > 80) return launch_cwide(a, p, tile - 80, hs);  // 3x3 (stride 1 / 2) from a resident halo patch, weights streamed into registers
     if (tile > 70) return fail(ICAF_ERR_ARG, "unknown tile id %d", tile);
     if (tile > 60) return launch_wreg(a, p, tile - 60, hs);
     if (tile > 50) return launch_stream(a, p, tile - 50, hs);
@@ -750,10 +751,10 @@ extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int b
         snprintf(buf, buf_len, "cstream_%s_8x16n64", dn[a->dtype]);
         return ICAF_OK;
     }
-    if (tile == 81) {
-        st = cwide_check(a, p);
+    if (tile > 80) {
+        st = cwide_check(a, p, tile - 80);
         if (st) return st;
-        snprintf(buf, buf_len, "cwide_%s_8x16n128", dn[a->dtype]);
+        snprintf(buf, buf_len, "cwide_%s_%s", dn[a->dtype], cwide_tag(tile - 80));
         return ICAF_OK;
     }
     if (tile > 70) return fail(ICAF_ERR_ARG, "unknown tile id %d", tile);

@@ -170,7 +170,7 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
     a.alpha_res[0], a.alpha_res[1] = float(ar[0]), float(ar[1])
     a.tile = tile
     wf = None
-    cw_layer = (CWIDE and (kh, kw, sh, sw, ph, pw) == (3, 3, 1, 1, 1, 1) and cin == 128 and cout == 128 and act == ACT_SILU)      # cwide.hip
+    cw_layer = bool(CWIDE and act == ACT_SILU and cwide_shapes(kh, kw, sh, sw, ph, pw, cin, cout))                               # cwide.hip
     if (x.dtype != torch.float32 and y.dtype == x.dtype and (cin * 2) % 128 == 0 and kp % 64 == 0 and pre is None
             and ((WREG_GEMM and chain is None and cout > 64) or cw_layer)):
         wf = frag_weights(w_packed)                   # igemm_wreg.hip: weight operand from registers (tile ids 61 / 62)
@@ -240,6 +240,17 @@ STREAM_GEMM = os.environ.get("ICAF_STREAM_GEMM", "1") != "0"      # A/B switch f
 CONV_PIPELINES = (0, 1, 2)        # LDS-DMA 64 B x3, register-staged, LDS-DMA 128 B x2 (3 = 128 B x3: never won)
 
 
+def cwide_shapes(kh, kw, sh, sw, ph, pw, cin, cout):
+    """Tile ids (80 + shape) of cwide.hip that are built for this 3x3 layer: resident halo patch, weights streamed into registers."""
+    if (kh, kw, ph, pw) != (3, 3, 1, 1) or sh != sw or cout % 128:
+        return []
+    if sh == 1:
+        return [81, 82] if (cin == 128 and cout == 128) else []          # 8 x 16 / 8 x 8 output pixels per workgroup
+    if sh == 2:
+        return [83, 85] if cin == 64 else [84] if cin == 128 else []     # stride 2: 64 -> 128 k (8 x 16 / 8 x 8), 128 -> 128 k (8 x 8)
+    return []
+
+
 def _conv_signature(a):
     return (a.B * a.Ho * a.Wo, a.Cout, a.Cin, a.kh, a.kw, a.sh, a.sw, a.H, a.W, a.ldx, a.ldy, a.groups, a.dtype,
             a.out_dtype, a.act, bool(a.res), bool(a.pre) + a.pre_mode, a.Cout2 if a.w2 else 0, bool(a.chain_keep))
@@ -251,13 +262,13 @@ def conv_candidates(a):
     cands = []
     cs_ok = ((a.kh, a.kw, a.sh, a.sw, a.ph, a.pw) == (3, 3, 1, 1, 1, 1) and a.Cin == 64 and a.Cout <= 64 and a.Cout % 8 == 0 and a.dtype != F32
              and a.out_dtype == a.dtype and a.act == ACT_SILU and not a.pre and CSTREAM)
-    cw_ok = ((a.kh, a.kw, a.sh, a.sw, a.ph, a.pw) == (3, 3, 1, 1, 1, 1) and a.Cin == 128 and a.Cout == 128 and a.dtype != F32 and a.wf
-             and a.out_dtype == a.dtype and a.act == ACT_SILU and not a.pre and CWIDE)
+    cw = (cwide_shapes(a.kh, a.kw, a.sh, a.sw, a.ph, a.pw, a.Cin, a.Cout)
+          if (a.dtype != F32 and a.wf and a.out_dtype == a.dtype and a.act == ACT_SILU and not a.pre and CWIDE) else [])
     if a.w2:                           # chained 1x1: one N tile covering both layers, LDS-DMA pipelines 0 / 2
         t = 2 if max(a.Cout, a.Cout2) <= 64 else 1
         cands = [t, t + 20]
-        if cw_ok and a.Cout2 <= 128 and a.Cout2 % 32 == 0:
-            cands.append(81)                 # resident halo patch, weights (and the chained 1x1's) streamed into registers (cwide.hip)
+        if cw and a.Cout == 128 and a.Cout2 <= 128 and a.Cout2 % 32 == 0:
+            cands += cw                      # resident halo patch, weights (and the chained 1x1's) streamed into registers (cwide.hip)
         if cs_ok and a.Cout == 64 and a.Cout2 <= 64:
             cands.append(71)                 # persistent 3x3 with the filter (and the chained 1x1) resident in LDS (cstream.hip)
     elif a.pre:                          # pre-activation term: built for tiles 128x128 / 128x64 on the LDS-DMA pipelines 0 / 2
@@ -283,8 +294,8 @@ def conv_candidates(a):
             cands.append(51)                 # ... and 128 x 128; a launch the shape rules out returns an error and is skipped
     if cs_ok and not a.w2:
         cands.append(71)
-    if cw_ok and not a.w2:
-        cands.append(81)
+    if cw and not a.w2:
+        cands += cw
     if a.wf and not a.pre and not a.w2:
         cands.append(61)                     # weights fed from registers (igemm_wreg.hip): 128 x 128 ...
         if a.Cout > 128:

@@ -266,9 +266,10 @@ CWIDE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("shape", [81, 82], ids=["8x16", "8x8"])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", CWIDE_CASES)
-def test_conv3x3_resident_patch_streamed_weights_kernel(case, dt):
+def test_conv3x3_resident_patch_streamed_weights_kernel(case, dt, shape):
     """cwide.hip vs torch and BIT-EXACT vs igemm (same K order, MFMA step, epilogue / chain expressions): ragged maps, the residual,
     the chained 1x1 with and without chain_keep, and the paired launch."""
     B, H, W, use_res, G, chain = case
@@ -292,7 +293,7 @@ def test_conv3x3_resident_patch_streamed_weights_kernel(case, dt):
         w2p, kp2 = stk([p0[0] for p0 in p2]), p2[0][1]
         b2p = stk([ops.pack_bias(b.to(DEV), c2) for b in b2s])
     outs = []
-    for tile in (81, 28 if not chain else 21):
+    for tile in (shape, 28 if not chain else 21):
         shape = (G, B, H, W) if G == 2 else (B, H, W)
         y = torch.full(shape + (cout + 8,), 7.0, dtype=dt, device=DEV)[..., :cout]
         if chain:
@@ -313,6 +314,56 @@ def test_conv3x3_resident_patch_streamed_weights_kernel(case, dt):
             close(from_act(outs[0][0][g] if G == 2 else outs[0][0]), m, dt, f"cwide {case} group {g}", factor=2.0)
         if chain:
             close(from_act(outs[0][1][g] if G == 2 else outs[0][1]), F.silu(F.conv2d(q(m, dt), q(w2s[g], dt), b2s[g])), dt, f"cwide chain {case}", factor=2.0)
+
+
+CWIDE_S2_CASES = [
+    # B, H, W, cin, cout, groups, chain cout2 (0 = none), tile id: stride-2 3x3 from a resident halo patch (even | odd column planes)
+    (4, 160, 160, 64, 128, 2, 128, 83),      # backbone 160 -> 80 + the C3's cv1 | cv2 (chained 1x1), both backbones
+    (2, 160, 160, 64, 128, 1, 128, 85),      # the same through the 8 x 8 tiling
+    (3, 63, 75, 64, 128, 1, 0, 83),          # odd input size: ragged output map (32 x 38), partial tiles, bottom / right padding rows
+    (2, 50, 34, 64, 256, 1, 0, 85),          # two channel blocks
+    (4, 80, 80, 128, 256, 2, 0, 84),         # backbone 80 -> 40, both backbones, two channel blocks
+    (3, 80, 80, 128, 128, 1, 0, 84),         # head down-sampling 80 -> 40
+    (2, 37, 45, 128, 128, 1, 64, 84),        # ragged, chained narrower 1x1
+]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", CWIDE_S2_CASES)
+def test_conv3x3_stride2_resident_patch_kernel(case, dt):
+    """cwide.hip, stride 2: vs torch and BIT-EXACT vs igemm."""
+    B, H, W, cin, cout, G, c2, tile_id = case
+    xs = [rnd((B, cin, H, W), 271 + g) for g in range(G)]
+    ws = [rnd((cout, cin, 3, 3), 273 + g, 1.0 / math.sqrt(cin * 9)) for g in range(G)]
+    bs = [rnd((cout,), 275 + g, 0.2) for g in range(G)]
+    stk = (lambda t: torch.stack(t).contiguous()) if G == 2 else (lambda t: t[0])
+    xa = stk([to_act(x, dt) for x in xs])
+    packs = [ops.pack_conv_weight(w.to(DEV), dt) for w in ws]
+    wp, kp = stk([p0[0] for p0 in packs]), packs[0][1]
+    bp = stk([ops.pack_bias(b.to(DEV), cout) for b in bs])
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if c2:
+        w2s = [rnd((c2, cout, 1, 1), 281 + g, 1.0 / math.sqrt(cout)) for g in range(G)]
+        b2s = [rnd((c2,), 283 + g, 0.2) for g in range(G)]
+        p2 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w2s]
+        w2p, kp2 = stk([p0[0] for p0 in p2]), p2[0][1]
+        b2p = stk([ops.pack_bias(b.to(DEV), c2) for b in b2s])
+    outs = []
+    for tile in (tile_id, 1 if c2 else 28):
+        shape = (G, B, Ho, Wo) if G == 2 else (B, Ho, Wo)
+        y = torch.full(shape + (cout + 8,), 7.0, dtype=dt, device=DEV)[..., :cout]
+        ch = None
+        if c2:
+            y2 = torch.full(shape + (c2 + 8,), 7.0, dtype=dt, device=DEV)[..., :c2]
+            ch = dict(w=w2p, kp=kp2, bias=b2p, y=y2, cout=c2, keep=False)
+        run(ops.conv2d(xa, wp, kp, bp, y, 3, 3, 2, 2, 1, 1, cin, cout, ops.ACT_SILU, tile=tile, chain=ch))
+        outs.append(ch["y"].clone() if c2 else y.clone())
+    assert torch.equal(outs[0], outs[1]), f"cwide s2 != igemm, max diff {(outs[0].float() - outs[1].float()).abs().max().item()}"
+    for g in range(G):
+        m = F.silu(F.conv2d(q(xs[g], dt), q(ws[g], dt), bs[g], 2, 1))
+        if c2:
+            m = F.silu(F.conv2d(q(m, dt), q(w2s[g], dt), b2s[g]))
+        close(from_act(outs[0][g] if G == 2 else outs[0]), m, dt, f"cwide s2 {case} group {g}", factor=2.0)
 
 
 WREG_CASES = [
