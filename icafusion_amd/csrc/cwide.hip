@@ -25,6 +25,10 @@
 #ifndef ICAF_CW_ABL
 #define ICAF_CW_ABL 0
 #endif
+// 1 = the halo patch travels global -> registers -> LDS (buffer_load_dwordx4 + ds_write_b128) instead of by LDS-DMA
+#ifndef ICAF_CW_REGPATCH
+#define ICAF_CW_REGPATCH 1
+#endif
 
 namespace icaf {
 
@@ -56,6 +60,16 @@ template <int CIN, int STR, int NSUB> struct CwTile {
 
 struct CwGeom { int tiles_x, tiles_y, ntile; };
 
+// Phase clocks for timing studies (-DICAF_CW_DBG: workgroup 0 and the LAST workgroup of group 0 stamp s_memtime at their phase
+// boundaries; icaf_cwide_debug_clocks copies the 16 stamps out).  Not compiled into the product library.
+#ifdef ICAF_CW_DBG
+__device__ long long icaf_cw_stamps[16];
+#define CW_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) \
+    icaf_cw_stamps[(blockIdx.x == 0 ? 0 : 8) + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CW_STAMP(i) do {} while (0)
+#endif
+
 template <int DT, int CIN, int STR, int NSUB, bool CHAIN>
 __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwide_kernel(const ConvP p, const CwGeom gm, const void* __restrict__ wfrag,
                                                                                     const long long wf_gs) {
@@ -79,6 +93,7 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
     const int b = tile / per_img, tr = tile - b * per_img, ty = tr / gm.tiles_x;
     const int y0 = ty * CW_TH, x0 = (tr - ty * gm.tiles_x) * G::TW;  // output-pixel origin
 
+    CW_STAMP(0);
     // ---- the wave's weight stream: NSLICE slices of the 3x3 filter, then (CHAIN) 2 slices of the chained 1x1 ---------------------
     const u32x4* wf = (const u32x4*)((const T*)wfrag + g * wf_gs) + (long long)(blockIdx.y * 4 + wave) * KSTEPS * 64 + lane;
     u32x4 wq[CW_DEPTH][CW_SL];
@@ -93,8 +108,10 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
         constexpr unsigned OOB = 0x80000000u;
         const unsigned img_off = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.ldx * (unsigned)E::BYTES;
         const int gy0 = y0 * S - 1, gx0 = x0 * S - 1;
+        constexpr int NPI = (G::PATCH / 1024 + 3) / 4;
+        u32x4 pv[ICAF_CW_REGPATCH ? NPI : 1];
 #pragma unroll
-        for (int i = 0; i < (G::PATCH / 1024 + 3) / 4; ++i) {
+        for (int i = 0; i < NPI; ++i) {
             const int j = wave + 4 * i;
             if (j >= G::PATCH / 1024) break;
             const int L = (j << 6) + lane, idx = L >> LSP;
@@ -106,7 +123,16 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
             const int gy = gy0 + hy, gx = gx0 + hx;
             const bool ok = hy < G::HH && hx < G::HWD && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             const unsigned voff = ok ? img_off + (unsigned)((gy * p.W + gx) * p.ldx) * E::BYTES + (unsigned)(cs << 4) : OOB;
-            if constexpr (!(ICAF_CW_ABL & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(patch + (j << 10)), 16, voff, 0, 0, 0);
+            if constexpr (ICAF_CW_REGPATCH) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 0, 0);       // (out of range: zeros)
+            else if constexpr (!(ICAF_CW_ABL & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(patch + (j << 10)), 16, voff, 0, 0, 0);
+        }
+        if constexpr (ICAF_CW_REGPATCH) {
+#pragma unroll
+            for (int i = 0; i < NPI; ++i) {
+                const int j = wave + 4 * i;
+                if (j >= G::PATCH / 1024) break;
+                *(u32x4*)(patch + (j << 10) + (lane << 4)) = pv[i];
+            }
         }
     }
 
@@ -147,8 +173,10 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
     for (int bb = 0; bb < NSUB; ++bb)
         lbase[bb] = ((NSUB == 4 ? (bb >> 1) : bb) * 4 + (l31 >> 3)) * S * PITCH + (NSUB == 4 ? (bb & 1) * 8 : 0) + (l31 & 7);
 
+    CW_STAMP(1);
     wait_vmcnt<0>();                               // patch (this wave's share), residual vectors, biases, first weight slices
     __syncthreads();
+    CW_STAMP(2);
 
     // ---- K loop: KSTEPS MFMA steps x NSUB sub-tiles, weights from the register stream ----------------------------------------------
     f32x16 acc[NSUB];
@@ -193,7 +221,9 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
         }
         __builtin_amdgcn_sched_barrier(0);         // (left alone the scheduler hoists the fragment reads of several slices: registers)
     }
+    CW_STAMP(3);
     __syncthreads();                               // every wave has left the K loop: the patch may be overwritten by the staged tile
+    CW_STAMP(4);
 
     auto stage = [&](const f32x16 (&a)[NSUB], const f32x4 (&bv)[4], float scale) {
 #pragma unroll
@@ -212,6 +242,7 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
     };
     stage(acc, bq, alpha_acc);
     __syncthreads();
+    CW_STAMP(5);
     if constexpr (!CHAIN) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -230,6 +261,7 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
                 *(u32x4*)(yg + (long long)m * p.ldy + n) = sv;
             }
         }
+        CW_STAMP(6);
     } else {
         // chained layer (one channel block: n0 = 0): y is completed now — staged vector + alpha_res * residual, written to y when the
         // chain keeps it and BACK into the staging tile, which the chained 1x1 consumes as stored (igemm's CHAIN + WB)
@@ -347,4 +379,11 @@ int launch_cwide(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t
     return a->dtype == ICAF_BF16 ? launch_cwide_dt<ICAF_BF16>(a, p, shape, s) : launch_cwide_dt<ICAF_F16>(a, p, shape, s);
 }
 
+#ifdef ICAF_CW_DBG
+}  // namespace icaf
+extern "C" __attribute__((visibility("default"))) int icaf_cwide_debug_clocks(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(icaf::icaf_cw_stamps), 16 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+namespace icaf {
+#endif
 }  // namespace icaf

@@ -461,6 +461,10 @@ int launch_cstream(const icaf_conv_args* a, const ConvP& p, hipStream_t s);
 int cwide_check(const icaf_conv_args* a, const ConvP& p, int shape);
 int launch_cwide(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
 const char* cwide_tag(int shape);
+// cwpers.hip
+int cwpers_check(const icaf_conv_args* a, const ConvP& p, int shape);
+int launch_cwpers(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
+const char* cwpers_tag(int shape);
 // igemm_wreg.hip
 int wreg_check(const icaf_conv_args* a, const ConvP& p, int shape);
 int launch_wreg(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
@@ -469,10 +473,11 @@ const char* wreg_tag(int shape);
 //   40 + shape: 3x3 direct convolution from an LDS halo tile (ctile.hip); 50 + shape: persistent streaming GEMM for 1x1 layers
 //   (igemm_stream.hip); 60 + shape: weight operand fed from registers (igemm_wreg.hip); an explicit request that the layer cannot
 //   satisfy is an error (the autotuner skips it), it is never chosen silently.  71: persistent 3x3 with a resident filter (cstream.hip);
-//   80 + shape: 3x3 (stride 1 / 2) from a resident halo patch with the weights streamed per wave into registers (cwide.hip).
+//   80 + shape: 3x3 (stride 1 / 2) from a resident halo patch with the weights streamed per wave into registers (cwide.hip);
+//   90 + shape: its persistent form (cwpers.hip).
 static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
     const bool dma_ok = p.x_bytes != 0;
-    if (a->tile > 40 && a->tile < 90) return a->tile;
+    if (a->tile > 40 && a->tile < 100) return a->tile;
     if (a->tile >= 1 && a->tile <= 34 && a->tile % 10 >= 1 && a->tile % 10 <= 4) {
         const int pipe = a->tile / 10;
         return (pipe != 1 && !dma_ok) ? a->tile % 10 + 10 : a->tile;
@@ -707,6 +712,7 @@ extern "C" int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s) {
     const int tile = pick_tile(a, p);
     hipStream_t hs = S(s);
     if (tile == 71) return launch_cstream(a, p, hs);        // persistent 3x3 with the filter resident in LDS (64 -> 64 channels)
+    if (tile > 90) return launch_cwpers(a, p, tile - 90, hs); // the same, persistent: double-buffered patch, rolling weight stream (cwpers.hip)
     if (tile > 80) return launch_cwide(a, p, tile - 80, hs);  // 3x3 (stride 1 / 2) from a resident halo patch, weights streamed into registers
     if (tile > 70) return fail(ICAF_ERR_ARG, "unknown tile id %d", tile);
     if (tile > 60) return launch_wreg(a, p, tile - 60, hs);
@@ -749,6 +755,12 @@ extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int b
         st = cstream_check(a, p);
         if (st) return st;
         snprintf(buf, buf_len, "cstream_%s_8x16n64", dn[a->dtype]);
+        return ICAF_OK;
+    }
+    if (tile > 90) {
+        st = cwpers_check(a, p, tile - 90);
+        if (st) return st;
+        snprintf(buf, buf_len, "cwpers_%s_%s", dn[a->dtype], cwpers_tag(tile - 90));
         return ICAF_OK;
     }
     if (tile > 80) {

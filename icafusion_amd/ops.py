@@ -244,10 +244,14 @@ def cwide_shapes(kh, kw, sh, sw, ph, pw, cin, cout):
     """Tile ids (80 + shape) of cwide.hip that are built for this 3x3 layer: resident halo patch, weights streamed into registers."""
     if (kh, kw, ph, pw) != (3, 3, 1, 1) or sh != sw or cout % 128:
         return []
+    # 80 + shape: one tile per workgroup (cwide.hip); 90 + shape: persistent, double-buffered patch (cwpers.hip)
     if sh == 1:
-        return [81, 82] if (cin == 128 and cout == 128) else []          # 8 x 16 / 8 x 8 output pixels per workgroup
+        return [81, 82, 91, 95] if (cin == 128 and cout == 128) else []  # 8 x 16 / 8 x 8 output pixels per workgroup; persistent 8 x 16 (8 waves) / 8 x 8 (4 waves, 3 per CU)
     if sh == 2:
-        return [83, 85] if cin == 64 else [84] if cin == 128 else []     # stride 2: 64 -> 128 k (8 x 16 / 8 x 8), 128 -> 128 k (8 x 8)
+        if cin == 64:
+            return [83, 85, 92, 96]                                      # stride 2, 64 -> 128 k: 8 x 16 / 8 x 8 / persistent 8 x 16 / persistent 8 x 8
+        if cin == 128:
+            return [84, 94] + ([93] if cout % 256 == 0 else [])          # stride 2, 128 -> 128 k: 8 x 8; persistent 8 x 8 with 128 / 256 channels per workgroup
     return []
 
 
@@ -268,7 +272,7 @@ def conv_candidates(a):
         t = 2 if max(a.Cout, a.Cout2) <= 64 else 1
         cands = [t, t + 20]
         if cw and a.Cout == 128 and a.Cout2 <= 128 and a.Cout2 % 32 == 0:
-            cands += cw                      # resident halo patch, weights (and the chained 1x1's) streamed into registers (cwide.hip)
+            cands += [c for c in cw if c not in (93, 95)]                    # resident halo patch, weights (and the chained 1x1's) streamed into registers (cwide.hip)
         if cs_ok and a.Cout == 64 and a.Cout2 <= 64:
             cands.append(71)                 # persistent 3x3 with the filter (and the chained 1x1) resident in LDS (cstream.hip)
     elif a.pre:                          # pre-activation term: built for tiles 128x128 / 128x64 on the LDS-DMA pipelines 0 / 2

@@ -257,6 +257,7 @@ def test_conv3x3_resident_filter_kernel(case, dt):
 CWIDE_CASES = [
     # B, H, W, use_res, groups, chain (None | (cout2, keep)): 3x3 128 -> 128 from a resident halo patch, weights streamed into registers (cwide.hip, tile id 81)
     (8, 40, 40, True, 2, None),             # Bottleneck.cv2 + shortcut at 40 x 40, both backbones: 15 tiles per image (right column half empty)
+    (64, 40, 40, True, 2, None),            # the bench's batch: the persistent form walks 3-4 tiles per workgroup
     (4, 40, 40, False, 1, None),            # head C3 (no shortcut)
     (3, 21, 27, True, 1, None),             # ragged map: partial tiles on both edges
     (1, 8, 16, False, 1, None),             # ONE tile
@@ -266,7 +267,7 @@ CWIDE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("shape", [81, 82], ids=["8x16", "8x8"])
+@pytest.mark.parametrize("shape", [81, 82, 91, 95], ids=["8x16", "8x8", "persistent", "persistent8x8"])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", CWIDE_CASES)
 def test_conv3x3_resident_patch_streamed_weights_kernel(case, dt, shape):
@@ -293,6 +294,8 @@ def test_conv3x3_resident_patch_streamed_weights_kernel(case, dt, shape):
         w2p, kp2 = stk([p0[0] for p0 in p2]), p2[0][1]
         b2p = stk([ops.pack_bias(b.to(DEV), c2) for b in b2s])
     outs = []
+    if chain and shape == 95:
+        pytest.skip("the four-wave persistent form has no chained variant")
     for tile in (shape, 28 if not chain else 21):
         shape = (G, B, H, W) if G == 2 else (B, H, W)
         y = torch.full(shape + (cout + 8,), 7.0, dtype=dt, device=DEV)[..., :cout]
@@ -325,6 +328,14 @@ CWIDE_S2_CASES = [
     (4, 80, 80, 128, 256, 2, 0, 84),         # backbone 80 -> 40, both backbones, two channel blocks
     (3, 80, 80, 128, 128, 1, 0, 84),         # head down-sampling 80 -> 40
     (2, 37, 45, 128, 128, 1, 64, 84),        # ragged, chained narrower 1x1
+    (16, 160, 160, 64, 128, 2, 128, 92),     # persistent forms: many tiles per workgroup ...
+    (3, 63, 75, 64, 128, 1, 0, 92),          # ... ragged map, fewer tiles than workgroups on some XCDs
+    (16, 80, 80, 128, 256, 2, 0, 93),        # 256 channels per workgroup
+    (2, 37, 45, 128, 512, 1, 0, 93),         # two channel blocks of 256
+    (8, 80, 80, 128, 128, 1, 0, 94),
+    (16, 160, 160, 64, 128, 2, 128, 96),     # four wavefronts, two workgroups per CU
+    (3, 63, 75, 64, 128, 1, 0, 96),
+    (2, 37, 45, 128, 128, 1, 64, 94),
 ]
 
 
