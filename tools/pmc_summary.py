@@ -24,7 +24,7 @@ def short(name):
         dt, odt, bm, bn, wm, wn, rb, ns = map(int, m.groups())
         w8 = "w8" if bm == 128 and (bm // wm) * (bn // wn) == 8 else ""          # 8-wavefront build of a 128-row tile
         return f"igemm_dma{rb}x{ns}_{_DN[dt]}_{_DN[odt]}_{bm}x{bn}{w8}"
-    m = re.match(r"icaf::igemm_stream_kernel<(\d+), (\d+), \d+>", name)          # persistent streaming GEMM (1x1 layers)
+    m = re.match(r"icaf::igemm_stream_kernel<(\d+), (\d+), \d+(?:, \d+)?>", name)   # persistent streaming GEMM
     if m:
         dt, bn = map(int, m.groups())
         return f"igemm_stream_{_DN[dt]}_128x{bn}"
@@ -34,7 +34,15 @@ def short(name):
         return f"igemm_wreg_{_DN[dt]}_128x{32 * nwv}"
     m = re.match(r"icaf::cstream_kernel<(\d+), (true|false)>", name)              # persistent 3x3, filter resident in LDS
     if m:
-        return f"cstream_{_DN[int(m.group(1))]}_8x16n64" + ("+1x1" if m.group(2) == "true" else "")
+        return f"cstream_{_DN[int(m.group(1))]}_8x16n64"                        # (with or without the chained 1x1: one name, as bench.py reports it)
+    m = re.match(r"icaf::cwide_kernel<(\d+), (\d+), (\d+), (\d+), (?:true|false)>", name)      # 3x3 from a resident halo patch, weights into registers
+    if m:
+        dt, cin, st, nsub = map(int, m.groups())
+        return f"cwide_{_DN[dt]}_8x{16 if nsub == 4 else 8}n128" + ("s2" if st == 2 else "") + ("c64" if cin == 64 else "")
+    m = re.match(r"icaf::cwpers_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (?:true|false)>", name)
+    if m:
+        dt, cin, st, tws, ncg, nw = map(int, m.groups())
+        return f"cwpers_{_DN[dt]}_8x{8 * tws}n{32 * ncg}" + ("s2" if st == 2 else "") + ("c64" if cin == 64 else "") + ("w4" if nw == 4 else "")
     if name.startswith("icaf::detect_conv_kernel<"):
         return "detect_conv+decode"
     m = re.match(r"icaf::igemm_kernel<(\d+), (\d+), (\d+), (\d+),", name)
@@ -53,7 +61,8 @@ def short(name):
                 "cross_attn_kernel": "cross_attention", "detect_decode_kernel": "detect_decode", "detect_pixel_kernel": "detect_decode", "sppf_lds_kernel": "sppf_pool",
                 "upsample_kernel": "upsample_nearest", "stem_kernel": "stem", "bneck_kernel": "bottleneck",
                 "stem2_kernel": "stem+conv3x3s2+1x1", "pool_tokens_rows_kernel": "dmff_pool_tokens",
-                "dmff_attn_mlp_kernel": "dmff_attn_mlp", "dmff_ln_qkv_kernel": "dmff_ln_qkv", "layernorm_kernel": "layernorm"}.get(m.group(1), m.group(1))
+                "dmff_attn_mlp_kernel": "dmff_attn_mlp", "dmff_ln_qkv_kernel": "dmff_ln_qkv", "layernorm_kernel": "layernorm",
+                "dmff_wide_ln_qkv_kernel": "dmff_ln_qkv", "dmff_wide_proj_mlp_kernel": "dmff_proj_mlp"}.get(m.group(1), m.group(1))
     return name[:80]
 
 
