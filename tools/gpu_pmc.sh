@@ -8,15 +8,16 @@
 mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 SUF=${PMC_NAME:+_$PMC_NAME}
+RAW=/tmp/icaf_raw; mkdir -p $RAW      # raw rocprofv3 output stays on the box (gpurun_out/ is capped at 64 MiB): only the summaries travel
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf $R/gpurun_out/pmc_$c
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o pmc -- \
-      python $R/bench.py --no-cpu-baseline --no-graph --no-overlap --depth 1 --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.err
+  rm -rf $RAW/pmc_$c
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $RAW/pmc_$c -o pmc -- \
+      python $R/bench.py --no-cpu-baseline --no-latency --no-graph --no-overlap --depth 1 --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.err
   tail -2 $R/gpurun_out/pmc_$c.err
 done
 cd $R
 W=$(python -c "import json;print(json.load(open('gpurun_out/pmc_FETCH_SIZE.json'))['config']['workload'])")
-python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE "--workload=$W" > gpurun_out/pmc_summary$SUF.json
+python tools/pmc_summary.py $RAW/pmc_FETCH_SIZE $RAW/pmc_WRITE_SIZE "--workload=$W" > gpurun_out/pmc_summary$SUF.json
 cp gpurun_out/pmc_summary$SUF.json profiles/pmc_traffic$SUF.json
 echo "pmc summary for: $W"

@@ -5,15 +5,16 @@
 mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/pmc_sq
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/pmc_sq -o pmc -- \
-    python $R/bench.py --no-cpu-baseline --no-graph --no-overlap --depth 1 --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_sq.json 2> $R/gpurun_out/pmc_sq.err
+RAW=/tmp/icaf_raw; mkdir -p $RAW
+rm -rf $RAW/pmc_sq
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $RAW/pmc_sq -o pmc -- \
+    python $R/bench.py --no-cpu-baseline --no-latency --no-graph --no-overlap --depth 1 --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_sq.json 2> $R/gpurun_out/pmc_sq.err
 tail -2 $R/gpurun_out/pmc_sq.err
 cd $R && python - <<'PY'
 import csv, glob, collections, json, sys
 sys.path.insert(0, "tools")
 from pmc_summary import short
-f = glob.glob("gpurun_out/pmc_sq/**/*counter_collection.csv", recursive=True)[0]
+f = glob.glob("/tmp/icaf_raw/pmc_sq/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(f)):
     k = short(r["Kernel_Name"]); acc[k][r["Counter_Name"]] += float(r["Counter_Value"])

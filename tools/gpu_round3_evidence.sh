@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-2 evidence, one GPU call: every GPU test; for the default workload and the per-GPU shards of BASELINE configs 3 / 4 / 5: the two
+# Round-3 evidence, one GPU call (raw profiler output stays under /tmp on the box; the test suite is a separate call): for the default workload and the per-GPU shards of BASELINE configs 3 / 4 / 5: the two
 # PMC traffic passes (installed as profiles/pmc_traffic*.json so that the bench line that follows carries roofline.traffic), the bench
 # line, rocprofv3 kernel stats of the same command; for the default workload also the SQ (MFMA busy) pass, the per-layer profiles and
 # the 16-bit parity table.  Everything lands in gpurun_out/; summaries are copied to profiles/ afterwards.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
 find gpurun_out -mindepth 1 -maxdepth 1 ! -name '.last_call.json' -exec rm -rf {} +     # the snapshot's old scratch: gpurun_out/ is capped at 64 MiB
-bash tools/gpu_tests.sh 2>&1 | tail -30
+# (the GPU test suite is its own call: tools/gpu_tests.sh)
 cd $R && bash tools/gpu_pmc.sh 2>&1 | tail -2
 cd $R && bash tools/gpu_pmc_sq.sh 2>&1 | grep "dmff\|cross_att\|128x128w8\|256x256 \|stem"
 cd $R && bash tools/gpu_bench.sh 2>&1 | grep -v "^\"\|^W2026" | tail -4
@@ -32,8 +32,6 @@ PY
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/icaf_raw/prof_$name -o bench -- python $R/bench.py --no-cpu-baseline --no-latency --tune-cache $R/profiles/tune_cache_$name.json "$@" > $R/gpurun_out/prof_bench_$name.json 2> $R/gpurun_out/prof_$name.err
   f=$(find /tmp/icaf_raw/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/prof_${name}_kernel_stats.csv && cut -c1-140 "$f" | sed -n 2,3p
 }
-cd $R && timeout 600 python bench.py --no-cpu-baseline --tune-cache gpurun_out/tune_fresh.json > gpurun_out/bench_fresh_tune.json 2>/dev/null; python -c "
-import json; d = json.load(open('gpurun_out/bench_fresh_tune.json')); print('fresh tuning:', d['value'], d['forward_only_pairs_per_s'])"
 run_cfg c3_l_bf16_b32_640 --model l --batch 32
 run_cfg c4_s_bf16_b64_512x640_loops3 --loops 3 --height 512 --width 640 --batch 64
 run_cfg c5_l_vedai_f16_b16_1280 --model l --dataset VEDAI --dtype f16 --height 1280 --width 1280 --batch 16 --conf 0.3
