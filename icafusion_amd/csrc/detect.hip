@@ -147,7 +147,7 @@ struct DetectEpi {
     float* z; float* logits; float* raw;
     int M, ny, nx; long long rows_total, row_offset; float stride; Anchors anc; FastDiv dnx, dny;
     template <int TM>
-    __device__ __forceinline__ void stage(const f32x16 (&acc)[TM], const f32x4 (&bq)[4], unsigned char* stg, int row0, int col0, int l31, int hi) const {
+    __device__ __forceinline__ void stage(const f32x16 (&acc)[TM], const f32x4 (&bq)[4], unsigned char* stg, int row0, int col0, int l31, int hi, int, int) const {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const int nl = col0 + 8 * qd + 4 * hi;

@@ -5,23 +5,73 @@
 
 namespace icaf {
 
-template <int DT, int BN, int ACT>
+template <int DT, int BN, int ACT, bool PRE = false>
 struct StoreEpi {
     using E = Elem<DT>;
     static constexpr int SO = BN * E::BYTES + 16;
     typename E::type* yg; float alpha_acc; int M, Cout, ldy;
     const typename E::type* rg; float alpha_res; int ldr;           // residual (nullptr = none); may alias yg (in-place Bottleneck chain)
+    // PRE: the pre-activation term of DMFF's fused tail / the folded up-sampling (icaf.h: icaf_conv_args.pre) — a coarse fp32 map
+    // resized (bilinear, align_corners = False; or nearest) to the output and added before the activation: the shared epilogue's
+    // expressions, fp contraction OFF (conv_common.h explains why), so the result is bit-identical to igemm's.
+    const float* pre; int pre_h, pre_w, ldpre, pre_mode, Ho, Wo;
     template <int TM>
-    __device__ __forceinline__ void stage(const f32x16 (&acc)[TM], const f32x4 (&bq)[4], unsigned char* stg, int row0, int col0, int l31, int hi) const {
+    __device__ __forceinline__ void stage(const f32x16 (&acc)[TM], const f32x4 (&bq)[4], unsigned char* stg, int row0, int col0, int l31, int hi, int m0, int n0) const {
+        const float* pt[PRE ? TM : 1][4];
+        float plx[PRE ? TM : 1], ply[PRE ? TM : 1];
+        if constexpr (PRE) {
+#pragma clang fp contract(off)
+            const float sy = (float)pre_h / (float)Ho, sx = (float)pre_w / (float)Wo;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int m = m0 + row0 + b * 32 + l31;
+                const int mm = m < M ? m : 0;
+                const int wo = mm % Wo, t = mm / Wo, ho = t % Ho, bi = t / Ho;
+                float fy = ((float)ho + 0.5f) * sy - 0.5f, fx = ((float)wo + 0.5f) * sx - 0.5f;
+                fy = fy < 0.0f ? 0.0f : fy;
+                fx = fx < 0.0f ? 0.0f : fx;
+                int y0 = (int)fy, x0 = (int)fx;
+                y0 = y0 < pre_h - 1 ? y0 : pre_h - 1;
+                x0 = x0 < pre_w - 1 ? x0 : pre_w - 1;
+                int y1 = y0 < pre_h - 1 ? y0 + 1 : y0, x1 = x0 < pre_w - 1 ? x0 + 1 : x0;
+                ply[b] = fy - (float)y0;
+                plx[b] = fx - (float)x0;
+                if (pre_mode == 1) {               // nearest: one tap with weight 1 — the sequence below returns it exactly
+                    y0 = y1 = (int)((long long)ho * pre_h / Ho);
+                    x0 = x1 = (int)((long long)wo * pre_w / Wo);
+                    ply[b] = plx[b] = 0.0f;
+                }
+                const float* base = pre + (long long)bi * pre_h * pre_w * ldpre;
+                pt[b][0] = base + (long long)(y0 * pre_w + x0) * ldpre;
+                pt[b][1] = base + (long long)(y0 * pre_w + x1) * ldpre;
+                pt[b][2] = base + (long long)(y1 * pre_w + x0) * ldpre;
+                pt[b][3] = base + (long long)(y1 * pre_w + x1) * ldpre;
+            }
+        }
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const int nl = col0 + 8 * qd + 4 * hi;                   // tile-local channel of this register quad
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
                 const int ml = row0 + b * 32 + l31;
+                float pv[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (PRE) if (n0 + nl < Cout) {
+                    const f32x4 t00 = *(const f32x4*)(pt[b][0] + n0 + nl), t01 = *(const f32x4*)(pt[b][1] + n0 + nl);
+                    const f32x4 t10 = *(const f32x4*)(pt[b][2] + n0 + nl), t11 = *(const f32x4*)(pt[b][3] + n0 + nl);
+                    {
+#pragma clang fp contract(off)
+                        const float wx0 = 1.0f - plx[b], wy0 = 1.0f - ply[b];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float top = t00[j] * wx0 + t01[j] * plx[b];
+                            const float bot = t10[j] * wx0 + t11[j] * plx[b];
+                            pv[j] = top * wy0 + bot * ply[b];
+                        }
+                    }
+                }
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, DT>(acc[b][4 * qd + j] + bq[qd][j] + 0.0f) * alpha_acc;
+                for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, DT>(acc[b][4 * qd + j] + bq[qd][j] + pv[j]) * alpha_acc;
                 u32x2 pk;
                 if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
                 else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
@@ -53,12 +103,13 @@ struct StoreEpi {
     }
 };
 
-template <int DT, int BN, int ACT, int MODE>
+template <int DT, int BN, int ACT, int MODE, bool PRE = false>
 __global__ __launch_bounds__(512) void igemm_stream_kernel(const ConvP p) {
     using E = Elem<DT>;
     const int g = blockIdx.z;
-    const StoreEpi<DT, BN, ACT> epi{(typename E::type*)p.y + g * p.y_gs, p.alpha_acc[g], p.M, p.Cout, p.ldy,
-                                    p.res ? (const typename E::type*)p.res + g * p.res_gs : nullptr, p.alpha_res[g], p.ldr};
+    const StoreEpi<DT, BN, ACT, PRE> epi{(typename E::type*)p.y + g * p.y_gs, p.alpha_acc[g], p.M, p.Cout, p.ldy,
+                                         p.res ? (const typename E::type*)p.res + g * p.res_gs : nullptr, p.alpha_res[g], p.ldr,
+                                         p.pre, p.pre_h, p.pre_w, p.ldpre, p.pre_mode, p.Ho, p.Wo};
     stream_gemm<DT, BN, MODE>(p, epi);
 }
 
@@ -71,7 +122,9 @@ int stream_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     if (shape < 1 || shape > 2) return fail(ICAF_ERR_ARG, "igemm_stream: unknown shape %d", shape);
     if (a->dtype == ICAF_F32 || a->out_dtype != a->dtype) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: 16-bit types, out dtype == dtype");
     if ((a->Cin * 2) % 128) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: Cin * 2 bytes must be a multiple of 128 (Cin = %d)", a->Cin);
-    if (a->pre || a->w2) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: no pre-activation term / chained layer");
+    if (a->w2) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: no chained layer");
+    if (a->pre && (a->act != ICAF_ACT_SILU || a->kh != 1 || a->kw != 1 || a->sh != 1 || a->sw != 1 || a->ph || a->pw || a->groups != 1))
+        return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: the pre-activation term is built for 1x1 SiLU layers (one group)");
     if (a->res && !p.vec_r) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: the residual must take 16-byte vectors");
     if (p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: operand exceeds the 2 GiB buffer-descriptor range");
     if (!p.vec_y || a->Cout % 8) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: y must take 16-byte vectors (ldy %% 8, Cout %% 8, alignment)");
@@ -104,6 +157,7 @@ static int launch_stream_cfg(const ConvP& p, int groups, hipStream_t s) {
         ICAF_LAUNCH_CHECK();
         return ICAF_OK;
     };
+    if constexpr (ACT == ICAF_ACT_SILU) { if (p.pre) return go(igemm_stream_kernel<DT, BN, ACT, 1, true>); }
     if (plain) return go(igemm_stream_kernel<DT, BN, ACT, 1>);
     return go(igemm_stream_kernel<DT, BN, ACT, 2>);
 }

@@ -28,7 +28,8 @@ namespace icaf {
 
 // EPI = epilogue policy: what happens to a finished [128 x BN] accumulator tile.
 //   EPI::SO                        staging row stride in bytes (the workgroup's staging buffer is 128 rows)
-//   epi.stage(acc, bq, stg, row0, col0, l31, hi)   this lane's accumulator quads (+ bias bq) -> staging rows row0 + b * 32 + l31
+//   epi.stage(acc, bq, stg, row0, col0, l31, hi, m0, n0)   this lane's accumulator quads (+ bias bq) -> staging rows row0 + b * 32 + l31
+//                                  (m0 / n0: first pixel / channel of the tile, for policies whose arithmetic depends on the position)
 //   epi.flush(stg, m0, n0, tid)                    staging -> global memory, after an LDS-only barrier
 // MODE 1: 1x1 / stride 1 / pad 0 — the pixel operand is a plain row-major matrix.  MODE 2: any filter with Cin * bytes a multiple of
 // 128 (a K slice lies inside ONE tap): igemm.hip's implicit-GEMM gather with a wave-uniform tap walk, restarted at every tile.
@@ -209,7 +210,7 @@ __device__ __forceinline__ void stream_gemm(const ConvP& p, const EPI& epi) {
         }
 
         // ---- epilogue: the policy stages the tile through the workgroup's own LDS buffer and writes it out ------------------------
-        epi.stage(acc, bq, stg, wm * WM, wn * WN, l31, hi);
+        epi.stage(acc, bq, stg, wm * WM, wn * WN, l31, hi, m0, n0);
         lds_barrier();                             // staged tile visible (LDS-only: the prefetched slices stay in flight)
         epi.flush(stg, m0, n0, tid);
         // (the ring barrier of the next slice separates these staging reads from the next tile's staging writes)

@@ -279,6 +279,11 @@ def conv_candidates(a):
         cands = [t + 10 * pipe for pipe in (0, 2) for t in (1, 2) if not (t == 1 and (a.out_dtype == F32 or a.Cout <= 64))]
         if a.dtype != F32 and a.out_dtype == a.dtype and a.Cout >= 128 and (a.Cin * 2) % 128 == 0:
             cands.append(28)                 # the 8-wavefront 128x128 tile carries the pre term as well
+        if (a.dtype != F32 and a.out_dtype == a.dtype and (a.Cin * 2) % 128 == 0 and a.Cout % 8 == 0 and STREAM_GEMM and a.act == ACT_SILU
+                and (a.kh, a.kw, a.sh, a.sw, a.ph, a.pw) == (1, 1, 1, 1, 0, 0) and a.groups == 1):
+            cands.append(52)                 # ... and so does the persistent streaming GEMM (1x1 SiLU layers)
+            if a.Cout > 64:
+                cands.append(51)
     for pipe in (() if (a.pre or a.w2) else CONV_PIPELINES):
         for t in (1, 2, 3, 4):
             if t == 1 and (a.out_dtype == F32 or a.Cout <= 64):

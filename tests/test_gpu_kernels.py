@@ -690,6 +690,32 @@ def test_conv2d_nearest_pre_term_is_conv_over_upsampled_concat(case, dt):
     close(from_act(y), F.silu(F.conv2d(cat, q(wt, dt), bias)), dt, f"nearest pre term {case}")
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(3, 80, 80, 256, 128, 20, 20, False), (2, 37, 45, 128, 200, 7, 9, False), (2, 40, 40, 512, 256, 16, 16, False),
+                                  (1, 20, 20, 1024, 512, 10, 10, False), (2, 22, 30, 128, 136, 11, 15, True)])
+def test_streaming_kernel_pre_term_is_bit_identical_to_igemm(case, dt):
+    """The pre-activation term (bilinear / nearest) as an epilogue policy of the persistent streaming GEMM: same bits as igemm."""
+    B, H, W, cin, cout, th, tw, nearest = case
+    x = rnd((B, cin, H, W), 131)
+    w = rnd((cout, cin, 1, 1), 132, 1.0 / math.sqrt(cin))
+    bias = rnd((cout,), 133, 0.2)
+    pre = rnd((B, cout, th, tw), 134)
+    xa = to_act(x, dt)
+    wp, kp = ops.pack_conv_weight(w.to(DEV), dt)
+    bp = ops.pack_bias(bias.to(DEV), cout)
+    pa = pre.permute(0, 2, 3, 1).contiguous().to(DEV)
+    outs = []
+    for tile in (51, 52, 1, 22):
+        y = torch.zeros((B, H, W, cout), dtype=dt, device=DEV)
+        run(ops.conv2d(xa, wp, kp, bp, y, 1, 1, 1, 1, 0, 0, cin, cout, ops.ACT_SILU, pre=pa, pre_nearest=nearest, tile=tile))
+        outs.append(y)
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+    mode = dict(mode="nearest") if nearest else dict(mode="bilinear", align_corners=False)
+    ref = F.silu(F.conv2d(q(x, dt), q(w, dt), bias) + F.interpolate(pre, size=(H, W), **mode))
+    close(from_act(outs[0]), ref, dt, f"streaming kernel + pre term {case}")
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("tile", [0, 2, 22])
 def test_conv2d_pre_activation_bilinear_term(dt, tile):
