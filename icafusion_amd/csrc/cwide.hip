@@ -25,9 +25,18 @@
 #ifndef ICAF_CW_ABL
 #define ICAF_CW_ABL 0
 #endif
-// 1 = the halo patch travels global -> registers -> LDS (buffer_load_dwordx4 + ds_write_b128) instead of by LDS-DMA
+// 1 = the halo patch travels global -> registers -> LDS (buffer_load_dwordx4 + ds_write_b128) instead of by LDS-DMA (measured: equal or
+// slower: 140 vs 131 us on the 160 -> 80 layer)
+// Tiles of look-ahead of an L2 prefetch (0 = off, the default): a workgroup touches every 128-byte line of the halo patch of the tile
+// CW_PF positions behind its own on the same XCD — whose workgroup starts a few microseconds later — so that tile's first touch of its
+// patch, the longest wait of a one-shot workgroup (phase clocks: 9-11 k cycles), would find the lines in the XCD's L2.  Measured with
+// 24 and 48 tiles of look-ahead at batch 32: no change on the 40 x 40 layers (43.7 / 44.1 vs 43.3 us), slower on the 160 -> 80 layer
+// (139 / 133 vs 129 us) — the wait is not an L2 miss.
+#ifndef ICAF_CW_PF
+#define ICAF_CW_PF 0
+#endif
 #ifndef ICAF_CW_REGPATCH
-#define ICAF_CW_REGPATCH 1
+#define ICAF_CW_REGPATCH 0
 #endif
 
 namespace icaf {
@@ -173,9 +182,32 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
     for (int bb = 0; bb < NSUB; ++bb)
         lbase[bb] = ((NSUB == 4 ? (bb >> 1) : bb) * 4 + (l31 >> 3)) * S * PITCH + (NSUB == 4 ? (bb & 1) * 8 : 0) + (l31 & 7);
 
+    // ---- L2 prefetch of a later tile's patch: one dword per 128-byte line, the values are never used (consumed by an empty asm at the
+    //      end of the kernel); PFW loads per wave, the YOUNGEST operations of the prologue: the counted wait below leaves them in flight
+    constexpr int PF_LR = (G::HWD * G::PB + 127) / 128, PF_LINES = G::HH * PF_LR, PFW = ICAF_CW_PF ? (PF_LINES + 255) / 256 : 0;
+    unsigned pfsink = 0;
+    if constexpr (ICAF_CW_PF > 0) {
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.x + g * p.x_gs), 0, p.x_bytes, 0x00020000);
+        const int q8 = gm.ntile >> 3, r8 = gm.ntile & 7, xcd = blockIdx.x & 7, mine = q8 + (xcd < r8 ? 1 : 0);
+        const bool pf_ok = (int)(blockIdx.x >> 3) + ICAF_CW_PF < mine;             // the later tile is one of this XCD's (xcd_tile's walk)
+        const int tp = tile + ICAF_CW_PF;
+        const int bp = tp / per_img, trp = tp - bp * per_img, typ = trp / gm.tiles_x;
+        const int gy0 = typ * CW_TH * S - 1, gxb = ((trp - typ * gm.tiles_x) * G::TW * S - 1) * G::PB;      // first row / first byte within an image row
+        const unsigned img_off = (unsigned)bp * (unsigned)(p.H * p.W) * (unsigned)p.ldx * (unsigned)E::BYTES;
+        const int row_bytes = p.W * p.ldx * E::BYTES;
+#pragma unroll
+        for (int i = 0; i < PFW; ++i) {
+            const int n = (wave + 4 * i) * 64 + lane, row = n / PF_LR, off = gxb + (n - row * PF_LR) * 128;
+            const int gy = gy0 + row;
+            const bool ok = pf_ok && n < PF_LINES && (unsigned)gy < (unsigned)p.H && off >= 0 && off < row_bytes;
+            pfsink ^= __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? img_off + (unsigned)(gy * row_bytes + off) : 0x80000000u, 0, 0);
+        }
+    }
+
     CW_STAMP(1);
-    wait_vmcnt<0>();                               // patch (this wave's share), residual vectors, biases, first weight slices
-    __syncthreads();
+    wait_vmcnt<PFW>();                             // patch (this wave's share), residual vectors, biases, first weight slices: all but the prefetch loads
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // (not __syncthreads(): it would drain the prefetch loads as well)
     CW_STAMP(2);
 
     // ---- K loop: KSTEPS MFMA steps x NSUB sub-tiles, weights from the register stream ----------------------------------------------
@@ -310,6 +342,7 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
             if (m >= 0 && n < p.Cout2) *(u32x4*)(y2g + (long long)m * p.ldy2 + n) = *(const u32x4*)(stg + row * CW_SO + cv * 16);
         }
     }
+    if constexpr (ICAF_CW_PF > 0) asm volatile("" ::"v"(pfsink));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
