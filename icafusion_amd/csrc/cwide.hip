@@ -70,11 +70,11 @@ template <int CIN, int STR, int NSUB> struct CwTile {
 struct CwGeom { int tiles_x, tiles_y, ntile; };
 
 // Phase clocks for timing studies (-DICAF_CW_DBG: workgroup 0 and the LAST workgroup of group 0 stamp s_memtime at their phase
-// boundaries; icaf_cwide_debug_clocks copies the 16 stamps out).  Not compiled into the product library.
+// boundaries; icaf_cwide_debug_clocks copies the 2 x 16 stamps out; 8-10: inside the prologue).  Not compiled into the product library.
 #ifdef ICAF_CW_DBG
-__device__ long long icaf_cw_stamps[16];
+__device__ long long icaf_cw_stamps[32];
 #define CW_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) \
-    icaf_cw_stamps[(blockIdx.x == 0 ? 0 : 8) + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    icaf_cw_stamps[(blockIdx.x == 0 ? 0 : 16) + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CW_STAMP(i) do {} while (0)
 #endif
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
 #pragma unroll
         for (int k = 0; k < CW_SL; ++k) wq[u][k] = wf[(u * CW_SL + k) * 64];
 
+    CW_STAMP(8);
     // ---- halo patch -> LDS (each DMA instruction fills 64 consecutive 16-byte slots) ------------------------------------------------
     {
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.x + g * p.x_gs), 0, p.x_bytes, 0x00020000);
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
         }
     }
 
+    CW_STAMP(9);
     // per-lane constants
     T* __restrict__ yg = (T*)p.y + g * p.y_gs;
     const T* __restrict__ rg = p.res ? (const T*)p.res + g * p.res_gs : nullptr;
@@ -155,27 +157,7 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
         const int gy = y0 + (NSUB == 4 ? (st >> 1) : st) * 4 + (q >> 3), gx = x0 + (NSUB == 4 ? (st & 1) * 8 : 0) + (q & 7);
         return (gy < p.Ho && gx < p.Wo) ? (b * p.Ho + gy) * p.Wo + gx : -1;
     };
-    constexpr int NIT = G::NPX * (CW_N / VEC) / 256;                 // 16-byte vectors of the tile per thread (8 / 4)
-    u32x4 rres[NIT];
-    if (rg && !(ICAF_CW_ABL & 16)) {                                 // the residual vectors of this thread's flush positions: in flight during the K loop
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
-            const int m = row_to_m(row);
-            rres[it] = *(const u32x4*)(rg + (long long)(m < 0 ? 0 : m) * p.ldr + n0 + cv * VEC);
-        }
-    }
-    f32x4 bq[4], bq2[4];
-    {
-        const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
-        const float* __restrict__ bias2 = (CHAIN && p.bias2) ? p.bias2 + g * p.bias2_gs : nullptr;
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const int n = wave * 32 + 8 * qd + 4 * hi;
-            bq[qd] = bias ? *(const f32x4*)(bias + n0 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-            bq2[qd] = bias2 ? *(const f32x4*)(bias2 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
+    CW_STAMP(10);
     // this lane's pixel of each sub-tile: row l31 >> 3, column l31 & 7; patch entry of tap (0, 0)
     int lbase[NSUB];
 #pragma unroll
@@ -209,6 +191,29 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // (not __syncthreads(): it would drain the prefetch loads as well)
     CW_STAMP(2);
+    // (the residual vectors and the biases are requested only now: in the prologue their 16 vector-memory instructions per wave sat in
+    //  front of the barrier — phase clocks: 3.3-4.2 k cycles of issue — although nothing needs them before the epilogue)
+    constexpr int NIT = G::NPX * (CW_N / VEC) / 256;                 // 16-byte vectors of the tile per thread (8 / 4)
+    u32x4 rres[NIT];
+    if (rg && !(ICAF_CW_ABL & 16)) {                                 // the residual vectors of this thread's flush positions: in flight during the K loop
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
+            const int m = row_to_m(row);
+            rres[it] = *(const u32x4*)(rg + (long long)(m < 0 ? 0 : m) * p.ldr + n0 + cv * VEC);
+        }
+    }
+    f32x4 bq[4], bq2[4];
+    {
+        const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
+        const float* __restrict__ bias2 = (CHAIN && p.bias2) ? p.bias2 + g * p.bias2_gs : nullptr;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int n = wave * 32 + 8 * qd + 4 * hi;
+            bq[qd] = bias ? *(const f32x4*)(bias + n0 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bq2[qd] = bias2 ? *(const f32x4*)(bias2 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 
     // ---- K loop: KSTEPS MFMA steps x NSUB sub-tiles, weights from the register stream ----------------------------------------------
     f32x16 acc[NSUB];
@@ -415,7 +420,7 @@ int launch_cwide(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t
 #ifdef ICAF_CW_DBG
 }  // namespace icaf
 extern "C" __attribute__((visibility("default"))) int icaf_cwide_debug_clocks(long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(icaf::icaf_cw_stamps), 16 * sizeof(long long)) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(icaf::icaf_cw_stamps), 32 * sizeof(long long)) == hipSuccess ? 0 : 1;
 }
 namespace icaf {
 #endif

@@ -23,11 +23,12 @@ for tile in (81, 82):
     for _ in range(3): l(sp)
     torch.cuda.synchronize()
     e0, e1 = ops.Event(), ops.Event(); e0.record(sp); [l(sp) for _ in range(20)]; e1.record(sp); torch.cuda.synchronize()
-    out = (C.c_longlong * 16)()
+    out = (C.c_longlong * 32)()
     assert lib().icaf_cwide_debug_clocks(out) == 0
     s = list(out)
     names = ["issue", "wait patch", "K loop", "barrier", "stage", "flush"]
-    for k, base in (("first wg", 0), ("last wg", 8)):
+    for k, base in (("first wg", 0), ("last wg", 16)):
         d = [s[base + i + 1] - s[base + i] for i in range(6)]
-        print(f"tile {tile} {k}: " + "  ".join(f"{n} {v}" for n, v in zip(names, d)) + f"  | total {s[base + 6] - s[base]} ticks; start offset vs first {s[base] - s[0]}")
-    print(f"tile {tile}: kernel {e0.elapsed_ms(e1) / 20 * 1e3:.1f} us (s_memtime ticks at 100 MHz: 10 ns each)")
+        pro = f"prologue: weights issued +{s[base + 8] - s[base]}, patch DMA issued +{s[base + 9] - s[base + 8]}, residual + bias loads issued +{s[base + 10] - s[base + 9]}, to the wait +{s[base + 1] - s[base + 10]}"
+        print(f"tile {tile} {k}: " + "  ".join(f"{n} {v}" for n, v in zip(names, d)) + f"  | total {s[base + 6] - s[base]} cycles | {pro}")
+    print(f"tile {tile}: kernel {e0.elapsed_ms(e1) / 20 * 1e3:.1f} us (s_memtime counts shader-clock cycles here)")
