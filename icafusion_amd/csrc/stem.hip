@@ -285,7 +285,11 @@ struct Stem2P {
     ConvP c;                    // w / bias / Kp: the 3x3 layer;  w2 / bias2 / y2 / ldy2 / Cout2: the 1x1;  Ho, Wo: output
 };
 
-template <int DT, bool U8>
+// PAIR (fp32 images, W % 4 == 0): a thread stages TWO horizontally adjacent space-to-depth entries — 4 consecutive image pixels = one
+// 16-byte load per (channel, row) instead of two 8-byte loads: 6 vector-memory instructions for 374 threads instead of 12 for 512.
+// (Phase clocks of the 3x3 kernels put an issued vector-memory instruction at ~200 cycles of a wave's time beside MFMA work; the
+// prefetch + commit of a tile was 19 % of this kernel.)
+template <int DT, bool U8, bool PAIR>
 __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
     using E = Elem<DT>;
     static_assert(DT != ICAF_F32, "16-bit types");
@@ -330,6 +334,45 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
         store_entry<DT, U8>(s2d, tid, v0);
         if (tid + S2_THREADS < S2_NS) store_entry<DT, U8>(s2d, tid + S2_THREADS, v1);
     };
+    // PAIR: thread -> (patch row psr, column pair pk): entries (psr, 2 pk) of the even plane and (psr, 2 pk + 1) of the odd plane
+    constexpr int S2_NPAIR = S2_SR * S2_SHALF;                             // 374
+    const int psr = tid / S2_SHALF, pk = tid - psr * S2_SHALF;
+    float4 pr[PAIR ? 6 : 1];
+    bool pin0 = false, pin1 = false;
+    auto fetch_pair = [&](const TileWalk& t) {
+        if (tid >= S2_NPAIR) return;
+        int stream, b, y0, x0;
+        decode(t, stream, b, y0, x0);
+        const int hh = q.H >> 1, hw = q.W >> 1;                               // (hw even: the host selects PAIR for W % 4 == 0 only)
+        const int gy = 2 * y0 - 2 + psr, gx = 2 * x0 - 2 + 2 * pk;            // gx even: the four pixels never straddle a 16-byte boundary
+        const bool iny = (unsigned)gy < (unsigned)hh;
+        pin0 = iny && (unsigned)gx < (unsigned)hw && 2 * pk < S2_SC;
+        pin1 = iny && (unsigned)(gx + 1) < (unsigned)hw && 2 * pk + 1 < S2_SC;
+        const int cy = min(max(gy, 0), hh - 1), cx = min(max(gx, 0), hw - 2);
+        const long long plane = (long long)q.H * q.W;
+        const unsigned off = (unsigned)(2 * cy) * (unsigned)q.W + (unsigned)(2 * cx);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* base = (const float*)q.img + ((long long)(stream * q.B + b) * 3 + c) * plane;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) pr[PAIR ? c * 2 + dy : 0] = *(const float4*)(base + off + (unsigned)(dy * q.W));
+        }
+    };
+    auto commit_pair = [&]() {
+        if (tid >= S2_NPAIR) return;
+        if constexpr (!U8) {
+            RawEntry<false> e0, e1;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float4 v = pr[PAIR ? i : 0];
+                e0.r[i] = float2{v.x, v.y};
+                e1.r[i] = float2{v.z, v.w};
+            }
+            e0.in = pin0; e1.in = pin1;
+            store_entry<DT, false>(s2d, psr * S2_SPITCH + pk, e0);
+            store_entry<DT, false>(s2d, psr * S2_SPITCH + S2_SHALF + pk, e1);
+        }
+    };
 
     // weight matrix -> LDS: `nsl` slices of `rows` rows x 128 bytes in igemm's swizzle (8 rows per DMA instruction)
     auto dma_rows = [&](const void* base, int rows, int kp, int nsl, unsigned char* dst) {
@@ -356,7 +399,7 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
     TileWalk cur_t, nxt_t;
     cur_t.init(pt, pstride, q.tiles_x, q.tiles_y);
     RawEntry<U8> v0, v1;
-    fetch(cur_t, v0, v1);
+    if constexpr (PAIR) fetch_pair(cur_t); else fetch(cur_t, v0, v1);
 
     const int fkey = (l31 >> 1) & 7;
     int foff[4];
@@ -370,7 +413,7 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
     u32x4 fw0[9];
     f32x4 b0r[4], b1r[4], b2r[4];
     int wstream = -1;
-    commit(v0, v1);
+    if constexpr (PAIR) commit_pair(); else commit(v0, v1);
     while (true) {
         int stream, b, y0, x0;
         decode(cur_t, stream, b, y0, x0);
@@ -396,7 +439,7 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
         const bool more = pn < pend;
         nxt_t = cur_t;
         nxt_t.next();
-        if (more) fetch(nxt_t, v0, v1);            // next tile's image reads stay in flight during everything below
+        if (more) { if constexpr (PAIR) fetch_pair(nxt_t); else fetch(nxt_t, v0, v1); }     // next tile's image reads stay in flight during everything below
         lds_barrier();                             // space-to-depth patch visible
 
         // ---- stage 1: stem over the halo patch ------------------------------------------------------------------
@@ -508,7 +551,7 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
                 sv[it] = *(const u32x4*)(halo + row * SO + cv * 16);
                 yoff[it] = (gy < p.Ho && gx < p.Wo && cv * 8 < p.Cout2) ? (long long)((b * p.Ho + gy) * p.Wo + gx) * p.ldy2 + cv * 8 : -1;
             }
-            if (more) commit(v0, v1);              // (every wave passed the barrier above: the staged t1 tile is consumed)
+            if (more) { if constexpr (PAIR) commit_pair(); else commit(v0, v1); }     // (every wave passed the barrier above: the staged t1 tile is consumed)
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (yoff[it] >= 0) *(u32x4*)(yg + yoff[it]) = sv[it];
@@ -576,7 +619,7 @@ extern "C" int icaf_stem(const void* img, int img_u8, int ctot, const void* w, c
     return img_u8 ? launch_stem<ICAF_F16, 64, true>(q, hs) : launch_stem<ICAF_F16, 64, false>(q, hs);
 }
 
-template <int DT, bool U8>
+template <int DT, bool U8, bool PAIR>
 static int launch_stem2(const Stem2P& q, hipStream_t s) {
     int dev = 0, cus = 256;
     ICAF_HIP(hipGetDevice(&dev));
@@ -585,10 +628,10 @@ static int launch_stem2(const Stem2P& q, hipStream_t s) {
     grid = (grid + 7) & ~7;                         // the tile walk is per XCD (8 of them)
     static std::atomic<bool> attr{false};
     if (!attr) {
-        ICAF_HIP(hipFuncSetAttribute((const void*)stem2_kernel<DT, U8>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS));
+        ICAF_HIP(hipFuncSetAttribute((const void*)stem2_kernel<DT, U8, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS));
         attr = true;
     }
-    stem2_kernel<DT, U8><<<dim3((unsigned)grid), dim3(S2_THREADS), S2_LDS, s>>>(q);
+    stem2_kernel<DT, U8, PAIR><<<dim3((unsigned)grid), dim3(S2_THREADS), S2_LDS, s>>>(q);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
@@ -622,6 +665,11 @@ extern "C" int icaf_stem2(const icaf_stem2_args* a, icaf_stream_t s) {
     q.tiles_x = (p.Wo + S2_TW - 1) / S2_TW; q.tiles_y = (p.Ho + S2_TH - 1) / S2_TH;
     q.npatch = a->nstreams * a->B * q.tiles_x * q.tiles_y;
     hipStream_t hs = S(s);
-    if (a->dtype == ICAF_BF16) return a->img_u8 ? launch_stem2<ICAF_BF16, true>(q, hs) : launch_stem2<ICAF_BF16, false>(q, hs);
-    return a->img_u8 ? launch_stem2<ICAF_F16, true>(q, hs) : launch_stem2<ICAF_F16, false>(q, hs);
+    const bool pair = !a->img_u8 && a->W % 4 == 0 && ((uintptr_t)a->img & 15) == 0;          // 16-byte image loads (stem2_kernel PAIR)
+    if (a->dtype == ICAF_BF16) {
+        if (a->img_u8) return launch_stem2<ICAF_BF16, true, false>(q, hs);
+        return pair ? launch_stem2<ICAF_BF16, false, true>(q, hs) : launch_stem2<ICAF_BF16, false, false>(q, hs);
+    }
+    if (a->img_u8) return launch_stem2<ICAF_F16, true, false>(q, hs);
+    return pair ? launch_stem2<ICAF_F16, false, true>(q, hs) : launch_stem2<ICAF_F16, false, false>(q, hs);
 }

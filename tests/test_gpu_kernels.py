@@ -843,7 +843,7 @@ def test_persistent_stem_equals_staging_plus_conv(case, dt):
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(2, 64, 256, 64, True, False), (1, 44, 72, 48, False, False), (2, 136, 130, 64, True, True),
-                                  (3, 36, 40, 64, True, True), (1, 320, 320, 64, True, False)])
+                                  (3, 36, 40, 64, True, True), (1, 320, 320, 64, True, False), (2, 52, 130, 64, False, False), (2, 100, 644, 64, True, False)])
 def test_stem2_equals_stem_then_chained_conv(case, dt):
     """icaf_stem2 (stem + 3x3/s2 conv + chained 1x1 in one persistent kernel; the two intermediate tensors stay in LDS) vs
     icaf_stem followed by icaf_conv2d with the chained 1x1: bit-identical, and close to fp32 torch.  Sizes cover tiles cut
