@@ -113,7 +113,10 @@ typedef struct icaf_conv_args {
     int out_dtype; /* y: same as dtype, or ICAF_F32 */
     float alpha_acc[2];
     float alpha_res[2];
-    int tile; /* 0 = auto; otherwise force a tile config id (tuning / tests) */
+    int tile; /* 0 = auto; otherwise force a launch configuration (tuning / tests; a configuration the layer does not satisfy is an error,
+               * never replaced silently).  1-4 (+10 / 20 / 30 per pipeline), 25 / 26 / 28 / 29: igemm.hip tiles; 40 + shape: ctile.hip;
+               * 51 / 52: igemm_stream.hip; 61 / 62: igemm_wreg.hip; 71: cstream.hip; 80 + shape: cwide.hip; 90 + shape: cwpers.hip.
+               * Every configuration of a layer produces the same bits (same K order, MFMA step, epilogue expressions). */
     /* Optional pre-activation term, bilinearly resized (align_corners=False) from a coarse fp32 map:
      *   y = alpha_res*res + alpha_acc * act( A.W + bias + bilinear(pre)[b][ho][wo][n] )
      * pre: [B][pre_h][pre_w][ldpre] fp32 (NULL = none).  This is how DMFF's tail (models/common.py:827-841:
@@ -137,7 +140,7 @@ typedef struct icaf_conv_args {
     int chain_keep; /* != 0: y IS written as well; only then may `res` be set: the chained 1x1 consumes y as stored, residual
                      * included (a Bottleneck's 3x3 + shortcut followed by the next Bottleneck's 1x1, models/common.py:193-194) */
     /* Optional second copy of the packed weights in FRAGMENT-MAJOR order (NULL = none), read by the launch configurations that feed
-     * the weight operand from registers (igemm_wreg.hip, tile ids 61 / 62): [Np / 32][Kp / 16][64 lanes][8 elements], lane
+     * the weight operand from registers (igemm_wreg.hip, cwide.hip, cwpers.hip: tile ids 61 / 62, 81-85, 91-96): [Np / 32][Kp / 16][64 lanes][8 elements], lane
      * (hi * 32 + r) of block (nb, ks) holding w[nb * 32 + r][ks * 16 + hi * 8 .. + 8] of the K-major matrix above; wf_gs = group
      * stride in elements.  16-bit types (icafusion_amd.ops.frag_weights builds it once per layer). */
     const void* wf;
