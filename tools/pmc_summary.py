@@ -24,22 +24,22 @@ def short(name):
         dt, odt, bm, bn, wm, wn, rb, ns = map(int, m.groups())
         w8 = "w8" if bm == 128 and (bm // wm) * (bn // wn) == 8 else ""          # 8-wavefront build of a 128-row tile
         return f"igemm_dma{rb}x{ns}_{_DN[dt]}_{_DN[odt]}_{bm}x{bn}{w8}"
-    m = re.match(r"icaf::igemm_stream_kernel<(\d+), (\d+), \d+(?:, \d+)?>", name)   # persistent streaming GEMM
+    m = re.match(r"icaf::igemm_stream_kernel<(\d+), (\d+)(?:, \w+)*>", name)         # persistent streaming GEMM (DT, BN, ACT, MODE, PRE)
     if m:
         dt, bn = map(int, m.groups())
         return f"igemm_stream_{_DN[dt]}_128x{bn}"
-    m = re.match(r"icaf::igemm_wreg_kernel<(\d+), (\d+), \d+, \d+>", name)     # weight operand fed from registers
+    m = re.match(r"icaf::igemm_wreg_kernel<(\d+), (\d+)(?:, \w+)*>", name)           # weight operand fed from registers
     if m:
         dt, nwv = map(int, m.groups())
         return f"igemm_wreg_{_DN[dt]}_128x{32 * nwv}"
     m = re.match(r"icaf::cstream_kernel<(\d+), (true|false)>", name)              # persistent 3x3, filter resident in LDS
     if m:
         return f"cstream_{_DN[int(m.group(1))]}_8x16n64"                        # (with or without the chained 1x1: one name, as bench.py reports it)
-    m = re.match(r"icaf::cwide_kernel<(\d+), (\d+), (\d+), (\d+), (?:true|false)>", name)      # 3x3 from a resident halo patch, weights into registers
+    m = re.match(r"icaf::cwide_kernel<(\d+), (\d+), (\d+), (\d+)(?:, \w+)*>", name)      # 3x3 from a resident halo patch, weights into registers
     if m:
         dt, cin, st, nsub = map(int, m.groups())
         return f"cwide_{_DN[dt]}_8x{16 if nsub == 4 else 8}n128" + ("s2" if st == 2 else "") + ("c64" if cin == 64 else "")
-    m = re.match(r"icaf::cwpers_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (?:true|false)>", name)
+    m = re.match(r"icaf::cwpers_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, \w+)*>", name)
     if m:
         dt, cin, st, tws, ncg, nw = map(int, m.groups())
         return f"cwpers_{_DN[dt]}_8x{8 * tws}n{32 * ncg}" + ("s2" if st == 2 else "") + ("c64" if cin == 64 else "") + ("w4" if nw == 4 else "")
