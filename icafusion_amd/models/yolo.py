@@ -520,7 +520,8 @@ class Model(HipModule):
         if plan is None:
             cap = self.plan_cache_bytes
             if cap is not None:                     # make room BEFORE allocating the new plan's buffers
-                while plans and sum(p.nbytes for p in plans.values()) > max(cap - self._plan_bytes_hint(plans), 0):
+                hint = self._plan_bytes_hint(plans, B, H, W, dt)
+                while plans and sum(p.nbytes for p in plans.values()) > max(cap - hint, 0):
                     plans.pop(next(iter(plans)))
             plan = self.build_plan(B, H, W, device, dt, u8=u8)
             if device.type == "cuda":
@@ -535,6 +536,14 @@ class Model(HipModule):
         return plan
 
     @staticmethod
-    def _plan_bytes_hint(plans):
-        """Expected size of the next plan: that of the largest cached one (shapes of one run are of one scale)."""
-        return max((p.nbytes for p in plans.values()), default=0)
+    def _plan_bytes_hint(plans, B, H, W, dt):
+        """Expected size of the plan about to be built: plan-owned buffers scale with B * H * W * element size, so the densest
+        cached plan's bytes per input element, times the new shape (a tiny plan next to a cached 40 GB one no longer evicts it).
+        Plans that somebody else still holds (a DetectionPipeline, a caller of plan_for) stay allocated after eviction: the cap
+        bounds what the CACHE pins, not the process."""
+        es = torch.empty((), dtype=dt).element_size()
+        per = 0.0
+        for key, p in plans.items():
+            pb, ph, pw, pdt = key[:4]
+            per = max(per, p.nbytes / float(pb * ph * pw * torch.empty((), dtype=pdt).element_size()))
+        return int(per * B * H * W * es)

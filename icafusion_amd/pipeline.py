@@ -31,7 +31,8 @@ class DetectionPipeline:
         self.gather = world > 1 or bool(force_gather)       # force_gather: run the all-gather even with one rank (hardware test of the RCCL path)
         self.nms_args = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic,
                              multi_label=multi_label, max_det=max_det)
-        model.static_outputs = True
+        # (the pipeline replays the plans itself and reads plan.outputs: it does not touch Model.static_outputs — a later model(rgb, ir) of the
+        #  same object still returns clones)
         # depth > 1: that many batches in flight, each with its own plan (buffers, hipGraph) and forward stream — the tails of one
         # forward (20x20 layers, DMFF, Detect: launches that leave CUs idle) overlap the full-width layers of the next
         self.depth = max(1, int(depth)) if overlap else 1         # overlap=False is the strictly sequential baseline: one batch, one stream
