@@ -2,7 +2,7 @@
 # Run the GPU test groups in separate processes (a faulting kernel poisons the HIP context of its process only).
 mkdir -p gpurun_out
 python -c "import torch;print(torch.__version__, torch.cuda.is_available(), torch.cuda.get_device_name(0))" > gpurun_out/env.log 2>&1
-for grp in "conv2d or first_layer or conv3x3 or preprocess or stem or bottleneck or chained" "sppf or pool_tokens or layernorm or axpby" "cross_attention" "detect_decode" "nms" "graph_capture"; do
+for grp in "conv2d or first_layer or conv3x3 or preprocess or stem or bottleneck or chained or streaming or from_registers or frag_weights" "sppf or pool_tokens or layernorm or axpby" "cross_attention" "detect_decode or detect_level" "nms or match_predictions" "graph_capture"; do
   name=$(echo "$grp" | tr ' ' '_')
   timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "$grp" --timeout=120 --tb=short -p no:cacheprovider > gpurun_out/k_$name.log 2>&1
   echo "== $grp: $(tail -1 gpurun_out/k_$name.log)"
