@@ -6,6 +6,7 @@ the layer signatures that cost most, re-captures the graph with every alternativ
 which the per-launch tuner is not offered) and keeps one only if the replay gets measurably faster.
 
     python tools/graph_tune.py [--model s --batch 32 --size 640 --dtype bf16 --top 24] --out profiles/tune_cache.json
+    python tools/graph_tune.py --model l --dataset VEDAI --dtype f16 --batch 16 --size 1280 --seed-cache profiles/tune_cache_c5_l_vedai_f16_b16_1280.json --out ...
 """
 import argparse
 import os
@@ -25,17 +26,25 @@ ap.add_argument("--model", default="s"); ap.add_argument("--batch", type=int, de
 ap.add_argument("--size", type=int, default=640); ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--top", type=int, default=24, help="number of layer signatures (by time) to refine")
 ap.add_argument("--eps", type=float, default=0.004, help="relative improvement required to accept a change")
+ap.add_argument("--height", type=int, default=0); ap.add_argument("--width", type=int, default=0)      # rectangular inputs (default: size x size)
+ap.add_argument("--loops", type=int, default=1, help="DMFF iterations")
+ap.add_argument("--dataset", default="kaist")
+ap.add_argument("--seed-cache", default=None, help="start from these choices (default: profiles/tune_cache.json)")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tune_graph.json"))
 a = ap.parse_args()
 dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
-cfg = yaml.safe_load(open(os.path.join(ROOT, "models", "transformer", f"yolov5{a.model}_Transfusion_kaist.yaml")))
-m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 0)); m = m.to("cuda:0"); m.compute_dtype = dt
+cfg = yaml.safe_load(open(os.path.join(ROOT, "models", "transformer", f"yolov5{a.model}_Transfusion_{a.dataset}.yaml")))
+m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 0))
+for i in (20, 21, 22):
+    m.model[i].crosstransformer[0].loops = a.loops
+m = m.to("cuda:0"); m.compute_dtype = dt
+H, W = a.height or a.size, a.width or a.size
 m.autotune = True
-seed_cache = os.path.join(ROOT, "profiles", "tune_cache.json")
+seed_cache = a.seed_cache or os.path.join(ROOT, "profiles", "tune_cache.json")
 if os.path.exists(seed_cache):
     ops.load_tune_cache(seed_cache)          # start from the committed choices
-plan = m.plan_for(a.batch, a.size, a.size, "cuda:0")
-rgb, ir = synth_images(a.batch, a.size, a.size, 0)
+plan = m.plan_for(a.batch, H, W, "cuda:0")
+rgb, ir = synth_images(a.batch, H, W, 0)
 plan.inputs[0].copy_(rgb.cuda()); plan.inputs[1].copy_(ir.cuda())
 stream = torch.cuda.Stream(); sp = stream.cuda_stream
 
