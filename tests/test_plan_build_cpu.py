@@ -57,3 +57,65 @@ def test_wider_models_keep_the_generic_launches():
     for cfg_name in ("yolov5n_Transfusion_kaist.yaml", "yolov5l_Transfusion_VEDAI.yaml"):
         n = names(Model(load_cfg(cfg_name)).eval().build_plan(1, 320, 320, "cpu", torch.bfloat16))
         assert "stem+conv3x3s2+1x1" not in n and "bottleneck+cv3" not in n
+
+
+def _dmff_launches(n):
+    """launch names of the three DMFF blocks of a plan, split at the token pooling that opens each block"""
+    idx = [i for i, x in enumerate(n) if x == "dmff_pool_tokens"]
+    blocks = []
+    for j, i in enumerate(idx):
+        end = next(k for k in range(i + 1, len(n)) if n[k].startswith("dmff_tail") or n[k] == "dmff_upsample_merge")
+        blocks.append(n[i + 1:end])
+    return blocks
+
+
+@pytest.mark.parametrize("loops", [1, 3])
+def test_dmff_block_is_at_most_three_launches_per_iteration_at_every_level(loops):
+    """16-bit yolov5s: P3 (C = 128) runs LN + QKV, attention + out-projection + LN + MLP (2 launches per iteration); P4 / P5
+    (C = 256 / 512) LN + QKV, attention, out-projection + LN + MLP (3) — VERDICT r2 #3.  fp32 keeps the seven per-layer launches."""
+    m = Model(load_cfg("yolov5s_Transfusion_kaist.yaml")).eval()
+    for i in (20, 21, 22):
+        m.model[i].crosstransformer[0].loops = loops
+    blocks = _dmff_launches(names(m.build_plan(2, 320, 320, "cpu", torch.bfloat16)))
+    assert blocks[0] == ["dmff_ln_qkv", "dmff_attn_mlp"] * loops
+    assert blocks[1] == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp"] * loops and blocks[2] == blocks[1]
+    from icafusion_amd.models.common import CrossTransformerBlock
+    try:
+        CrossTransformerBlock.fuse_wide = False                  # A/B switch: the wide levels fall back to the per-layer launches
+        plain = _dmff_launches(names(m.build_plan(2, 320, 320, "cpu", torch.bfloat16)))
+        assert plain[0] == blocks[0] and len(plain[1]) == 7 * loops and len(plain[2]) == 7 * loops
+    finally:
+        CrossTransformerBlock.fuse_wide = True
+    f32 = _dmff_launches(names(m.build_plan(2, 320, 320, "cpu", torch.float32)))
+    assert [len(b) for b in f32] == [7 * loops] * 3
+
+
+def test_fragment_major_weight_copy_layout():
+    """ops.frag_weights: [G][Np/32][Kp/16][64][8] with lane (hi * 32 + r) of block (nb, ks) = w[nb * 32 + r][ks * 16 + hi * 8 : + 8] —
+    the operand one 16-byte load per lane hands to v_mfma_f32_32x32x16 (icaf.h: icaf_conv_args.wf, the dmff_wide entry points)."""
+    from icafusion_amd import ops
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(2, 128, 96, generator=g).to(torch.bfloat16)
+    f = ops.frag_weights(w)
+    assert f.shape == (2, 4, 6, 64, 8) and f.dtype == w.dtype and f.stride(0) == w.stride(0)
+    for (gi, nb, ks, lane) in ((0, 0, 0, 0), (1, 3, 5, 63), (0, 2, 4, 37), (1, 1, 2, 31), (0, 3, 0, 32)):
+        hi, r = lane >> 5, lane & 31
+        assert torch.equal(f[gi, nb, ks, lane], w[gi, nb * 32 + r, ks * 16 + hi * 8: ks * 16 + hi * 8 + 8])
+    assert ops.frag_weights(w) is f                               # built once per packed tensor
+    w2 = torch.randn(64, 32, generator=g).to(torch.float16)
+    assert ops.frag_weights(w2).shape == (2, 2, 64, 8)
+
+
+def test_resident_patch_kernel_shape_table():
+    """ops.cwide_shapes: which cwide.hip / cwpers.hip launch configurations exist for a 3x3 layer (the tuner only offers these)."""
+    from icafusion_amd import ops
+    s = ops.cwide_shapes
+    assert s(3, 3, 1, 1, 1, 1, 128, 128) == [81, 82, 91, 95]
+    assert s(3, 3, 2, 2, 1, 1, 64, 128) == [83, 85, 92, 96] and s(3, 3, 2, 2, 1, 1, 64, 256) == [83, 85, 92, 96]
+    assert s(3, 3, 2, 2, 1, 1, 128, 128) == [84, 94] and s(3, 3, 2, 2, 1, 1, 128, 256) == [84, 94, 93]
+    for bad in ((1, 1, 1, 1, 0, 0, 128, 128), (3, 3, 1, 1, 1, 1, 128, 64), (3, 3, 1, 1, 1, 1, 256, 256), (3, 3, 1, 1, 0, 0, 128, 128),
+                (3, 3, 2, 1, 1, 1, 64, 128), (3, 3, 2, 2, 1, 1, 32, 128), (3, 3, 1, 1, 1, 1, 64, 128)):
+        assert s(*bad) == []
+    assert ops.dmff_wide_ok(256, 1024, torch.bfloat16) and ops.dmff_wide_ok(512, 2048, torch.float16)
+    assert not ops.dmff_wide_ok(128, 512, torch.bfloat16) and not ops.dmff_wide_ok(384, 1536, torch.bfloat16)
+    assert not ops.dmff_wide_ok(256, 1024, torch.float32) and not ops.dmff_wide_ok(512, 2048 + 128, torch.bfloat16)
