@@ -159,6 +159,19 @@ def test_pmc_summary_kernel_names_match_bench_names():
         "void icaf::dmff_ln_qkv_kernel<1, 128>(icaf::DmffP)": "dmff_ln_qkv",
         "void icaf::cross_attn_kernel<1, 32>(icaf::Elem<1>::type const*, icaf::Elem<1>::type*, int, int, int, int, int, float)": "cross_attention",
         "icaf::nms_walk_kernel(float const*, long long, int)": "nms_walk_kernel",
+        # round 3: the PRE flag added to igemm_stream_kernel once merged its two tiles under one name — every template tail must be tolerated
+        "void icaf::igemm_stream_kernel<1, 128, 1, 1, false>(icaf::ConvP)": "igemm_stream_bf16_128x128",
+        "void icaf::igemm_stream_kernel<1, 64, 1, 2, true>(icaf::ConvP)": "igemm_stream_bf16_128x64",
+        "void icaf::stem2_kernel<1, false, true>(icaf::Stem2P)": "stem+conv3x3s2+1x1",
+        "void icaf::cstream_kernel<1, true>(icaf::ConvP, icaf::CsGeom)": "cstream_bf16_8x16n64",
+        "void icaf::cwide_kernel<1, 128, 1, 4, false>(icaf::ConvP, icaf::CwGeom, void const*, long long)": "cwide_bf16_8x16n128",
+        "void icaf::cwide_kernel<1, 128, 1, 2, true>(icaf::ConvP, icaf::CwGeom, void const*, long long)": "cwide_bf16_8x8n128",
+        "void icaf::cwide_kernel<2, 64, 2, 2, true>(icaf::ConvP, icaf::CwGeom, void const*, long long)": "cwide_f16_8x8n128s2c64",
+        "void icaf::cwide_kernel<1, 128, 2, 2, false>(icaf::ConvP, icaf::CwGeom, void const*, long long)": "cwide_bf16_8x8n128s2",
+        "void icaf::cwpers_kernel<1, 128, 2, 1, 8, 8, false>(icaf::ConvP, icaf::CpGeom, void const*, long long)": "cwpers_bf16_8x8n256s2",
+        "void icaf::cwpers_kernel<1, 128, 1, 1, 4, 4, false>(icaf::ConvP, icaf::CpGeom, void const*, long long)": "cwpers_bf16_8x8n128w4",
+        "void icaf::dmff_wide_ln_qkv_kernel<1>(icaf::WideP)": "dmff_ln_qkv",
+        "void icaf::dmff_wide_proj_mlp_kernel<2, 2>(icaf::WideP)": "dmff_proj_mlp",
     }
     for raw, want in cases.items():
         assert mod.short(raw) == want, raw
@@ -237,3 +250,30 @@ def test_committed_tune_caches_only_name_configurations_the_tuner_would_time():
             assert ldy >= cout and ldx >= cin and M > 0 and groups in (1, 2)
             n += 1
     assert n > 150
+
+
+def test_wide_dmff_entry_points_reject_what_they_are_not_built_for():
+    """icaf_dmff_wide_*: argument checks run before any device call — a shape outside C in {256, 512}, fp32, or a hidden width that is
+    not a multiple of 256 is an error with a reason, never a silent fall-back (callers then keep the per-layer launches)."""
+    import ctypes as C
+
+    from icafusion_amd import _lib
+    from icafusion_amd._lib import DmffArgs, lib
+    a = DmffArgs()
+    buf = (C.c_char * 4096)()
+    ptr = C.cast(buf, C.c_void_p).value
+    for f in ("x", "qkv", "y", "wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2", "ln_mlp_gamma", "ln_mlp_beta"):
+        setattr(a, f, ptr)
+    for i in range(2):
+        a.ln_attn_gamma[i] = ptr; a.ln_attn_beta[i] = ptr
+    a.dtype, a.B, a.N, a.heads, a.Kp, a.Kp4, a.hidden, a.ldy = 1, 2, 16, 8, 384, 1536, 1536, 384
+    a.C = 384
+    assert lib().icaf_dmff_wide_ln_qkv(C.byref(a), None) != 0 and b"C=384" in lib().icaf_last_error()
+    assert lib().icaf_dmff_wide_proj_mlp(C.byref(a), ptr, None) != 0
+    a.C, a.Kp, a.Kp4, a.hidden, a.ldy, a.dtype = 256, 256, 1024, 1024, 256, 0          # fp32
+    assert lib().icaf_dmff_wide_proj_mlp(C.byref(a), ptr, None) != 0 and b"16-bit" in lib().icaf_last_error()
+    a.dtype, a.hidden, a.Kp4 = 1, 1152, 1152                                             # hidden % 256 != 0
+    assert lib().icaf_dmff_wide_proj_mlp(C.byref(a), ptr, None) != 0 and b"256" in lib().icaf_last_error()
+    a.hidden, a.Kp4 = 1024, 1024
+    assert lib().icaf_dmff_wide_proj_mlp(C.byref(a), None, None) != 0                    # attention output missing
+    assert _lib.IcafError
