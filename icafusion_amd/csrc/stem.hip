@@ -444,7 +444,9 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
 
         // ---- stage 1: stem over the halo patch ------------------------------------------------------------------
         {
-            for (int j = wave; j < (S2_NH + 31) / 32; j += S2_THREADS / 64) {
+            // 19 sub-tile jobs over 8 waves: three waves take a third job.  With PAIR staging the LAST waves do no image loads and no
+            // patch commits, so they are the ones to carry it (jobs dealt from the last wave down; results do not depend on the dealing)
+            for (int j = (PAIR ? S2_THREADS / 64 - 1 - wave : wave); j < (S2_NH + 31) / 32; j += S2_THREADS / 64) {
                 const int idx = (j << 5) + l31;
                 const int idc = idx < S2_NH ? idx : 0;
                 const int hy = idc / S2_PITCH, rem = idc - hy * S2_PITCH, pl = rem >= S2_HALF, i = rem - pl * S2_HALF;
