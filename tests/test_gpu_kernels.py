@@ -461,14 +461,16 @@ CTILE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("case", CTILE_CASES)
+# (a pixel wider than 256 bytes stays on igemm: the fp32 form of the 128-channel case is not generated)
+CTILE_PARAMS = [pytest.param(c, dt, id=f"case{i}-{str(dt).split('.')[-1]}") for i, c in enumerate(CTILE_CASES) for dt in DTYPES
+                if c[3] * (4 if dt == torch.float32 else 2) <= 256]
+
+
+@pytest.mark.parametrize("case,dt", CTILE_PARAMS)
 def test_conv3x3_halo_tile_kernel(case, dt):
     """ctile.hip (3x3 direct convolution from an LDS halo patch) vs torch, and BIT-EXACT vs the implicit-GEMM kernel:
     both walk K in the same order with the same MFMA step, so any difference is an addressing bug."""
     B, H, W, cin, cout, s, use_res, shape = case
-    if cin * (4 if dt == torch.float32 else 2) > 256:
-        pytest.skip("pixel wider than 256 bytes: layer stays on igemm")
     x = rnd((B, cin, H, W), 11)
     w = rnd((cout, cin, 3, 3), 12, 1.0 / math.sqrt(cin * 9))
     bias = rnd((cout,), 13, 0.2)
