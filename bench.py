@@ -36,6 +36,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: this many pairs per step over all GPUs, split contiguously "
+                    "(dist.shard_range: BASELINE config 3 = 256 -> 32/GPU on 8, config 5 = 128 -> 16/GPU); overrides --batch")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive serving measurement (pinned host uint8 batches -> device, "
+                    "overlapped with the forwards in flight; reported as `h2d_feed`, never as `value`)")
     ap.add_argument("--height", type=int, default=640)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--model", default="s", choices=["n", "s", "m", "l"])
@@ -66,14 +70,15 @@ def spawn_ranks(args):
     """`python bench.py --gpus N` with no torchrun environment: start the N ranks ourselves (one process per GPU through
     torch.distributed.run, rendezvous on 127.0.0.1) and pass rank 0's JSON line through.  The driver's own
     `python -m torch.distributed.run ... bench.py --gpus N` form sets WORLD_SIZE and never comes here."""
-    import socket
     import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # --standalone: torchrun starts its own c10d rendezvous on a port IT picks and keeps (no bind-close-reuse race on a busy host),
+    # on the loopback address (the container's hostname may not resolve)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    # (this image's host driver only supports dmabuf IPC: without the variable RCCL fails with hipIpcGetMemHandle: invalid argument.
+    #  It is exported on the GPU boxes already; a value the user set is never overridden.)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     print(f"[bench] --gpus {args.gpus} without a torchrun environment: launching {args.gpus} ranks ({' '.join(cmd[1:9])} ...)", file=sys.stderr)
     return subprocess.call(cmd, env=env)
@@ -88,16 +93,27 @@ def dry_run(args):
     dev = torch.device("cuda", local) if cuda else torch.device("cpu")
     if cuda:
         torch.cuda.set_device(local)
-    B, max_det = 4, 300
+    max_det = 300
+    G = args.global_batch
+    B = D.padded_local_batch(G, world) if G else 4
     block, det, count = D.detection_block(B, max_det, dev)
     det.fill_(float(rank + 1))
     count.fill_(rank + 1)
+    if G:                              # strong scaling: every pair carries its GLOBAL index; ranks short of B pairs leave padding rows behind
+        lo, hi = D.shard_range(G, rank, world)
+        for k in range(hi - lo):
+            det[k].fill_(float(lo + k))
+            count[k] = lo + k + 1
     det_all, count_all = D.gather_detections(det, count, block=block)
-    ok = det_all.shape[0] == world and all(int(count_all[r, 0]) == r + 1 and float(det_all[r, 0, 0, 0]) == r + 1 for r in range(world))
+    ok = det_all.shape[0] == world and all(int(count_all[r, 0]) == (r + 1 if not G else D.shard_range(G, r, world)[0] + 1) for r in range(world))
+    if G:                              # the global view: exactly G pairs, in global order, padding rows dropped
+        det_g, count_g = D.gathered_to_global(det_all, count_all, G)
+        ok = ok and det_g.shape[0] == G and all(float(det_g[i, 0, 0]) == i and int(count_g[i]) == i + 1 for i in range(G))
     if world > 1:
         tdist.barrier()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "requested_gpus": args.gpus, "gather_ok": bool(ok),
+        print(json.dumps({"dry_run": True, "n_gpus": world, "requested_gpus": args.gpus, "gather_ok": bool(ok), "global_batch": G or None,
+                          "local_batches": [D.shard_range(G, r, world)[1] - D.shard_range(G, r, world)[0] for r in range(world)] if G else None,
                           "backend": tdist.get_backend() if world > 1 else None, "device": str(dev)}))
     if world > 1:
         tdist.destroy_process_group()
@@ -149,6 +165,50 @@ def cpu_baseline(cfg, sd, args, loops):
                       f"{best_thr} threads (best of 8/16/32/64)"}
 
 
+def h2d_feed(model, args, B, H, W, dev):
+    """The serving loop fed from HOST memory, as the reference's loops are (detect_twostream.py:70-80, test.py:116-123 copy every batch
+    to the device, then forward, then NMS): pinned uint8 (B, 6, H, W) batches -> DetectionPipeline(u8=True).submit_u8 — the H2D copy
+    runs on its own stream under the forwards in flight, `/255`, the RGB / IR split and the cast happen in the first kernel.  Reported
+    beside `value`, never as it (the contract's `value` has its inputs resident in HBM)."""
+    from icafusion_amd.pipeline import DetectionPipeline
+    pipe = DetectionPipeline(model, B, H, W, dev, conf_thres=args.conf, iou_thres=args.iou, world=1, overlap=not args.no_overlap,
+                             depth=args.depth, u8=True)
+    nbuf = pipe.depth + 2
+    g = torch.Generator().manual_seed(1234)
+    host = [torch.randint(0, 256, (B, 6, H, W), dtype=torch.uint8, generator=g).pin_memory() for _ in range(nbuf)]
+    for k in range(max(args.warmup, nbuf)):
+        pipe.submit_u8(host[k % nbuf])
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    rates = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            pipe.submit_u8(host[k % nbuf])
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        rates.append(B * args.steps / (time.perf_counter() - t0))
+    # the copy alone (no forward behind it): what the link gives this buffer size
+    cs = torch.cuda.Stream(device=dev)
+    dst = pipe.plans[0].inputs[0]
+    with torch.cuda.stream(cs):
+        dst.copy_(host[0], non_blocking=True)
+    cs.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(cs):
+        for k in range(20):
+            dst.copy_(host[k % nbuf], non_blocking=True)
+    cs.synchronize()
+    copy_s = (time.perf_counter() - t0) / 20
+    nbytes = B * 6 * H * W
+    rate = sorted(rates)[1]
+    return {"pairs_per_s_with_h2d": round(rate, 2), "min": round(min(rates), 2), "max": round(max(rates), 2),
+            "host_bytes_per_batch": nbytes, "pcie_gbs_achieved_in_loop": round(rate / B * nbytes / 1e9, 2),
+            "pcie_gbs_copy_alone": round(nbytes / copy_s / 1e9, 2), "copy_alone_ms_per_batch": round(1e3 * copy_s, 3),
+            "note": f"pinned host uint8 (B,6,H,W) -> device on a copy stream, {pipe.depth} batch(es) in flight, {nbuf} rotating host buffers; "
+                    "forward from uint8 (icaf_stem2 / icaf_preprocess_u8) + NMS; median of 3 x K steps"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -185,6 +245,12 @@ def main():
     model.fold_upsample = args.fold_upsample
     model.autotune = not args.no_autotune
     B, H, W = args.batch, args.height, args.width
+    strong = args.global_batch > 0
+    if strong:                          # contiguous shards of a fixed global batch; uneven splits pad the short ranks to the longest shard
+        lo, hi = D.shard_range(args.global_batch, rank, world)
+        n_local, B = hi - lo, D.padded_local_batch(args.global_batch, world)
+    else:
+        n_local = B
     default_cache = os.path.join(ROOT, "profiles", "tune_cache.json")     # committed igemm tile choices: the same kernels
     if args.tune_cache and os.path.exists(args.tune_cache):               # run (and were profiled) from round to round;
         ops.load_tune_cache(args.tune_cache)                              # layers missing from it are tuned on the spot
@@ -197,7 +263,7 @@ def main():
     if args.tune_cache and rank == 0:
         ops.save_tune_cache(args.tune_cache)
     # inputs resident in HBM before the timed region: each rank synthesises its own shard of the global batch
-    rgb, ir = synth_images(B, H, W, seed=100 + rank)
+    rgb, ir = synth_images(B, H, W, seed=100 + rank)              # (strong scaling: rows >= n_local of a short rank are padding pairs)
     for pl in pipe.plans:
         pl.inputs[0].copy_(rgb.to(dev))
         pl.inputs[1].copy_(ir.to(dev))
@@ -232,6 +298,20 @@ def main():
             el = float(t.item())
         runs.append(el)
     elapsed = sorted(runs)[len(runs) // 2]
+    # per-rank rate (each rank's own clock around K of its steps, no barrier inside): the spread over ranks shows a slow GPU / link
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    own = n_local * args.steps / (time.perf_counter() - t0)
+    rank_rates = [own]
+    if world > 1:
+        t = torch.zeros((world,), dtype=torch.float64, device=dev)
+        t[rank] = own
+        tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
+        rank_rates = [float(v) for v in t.tolist()]
 
     # ---- forward-only rate and per-kernel HIP-event timing (instrumented pass, outside the timed region) -------
     ev0, ev1 = ops.Event(), ops.Event()
@@ -267,10 +347,25 @@ def main():
             kname = ops.conv_kernel_name(l) if l.fn is ops.lib().icaf_conv2d else name
             d = per_kernel.setdefault(kname, [0.0, 0.0, 0.0, 0])
             d[0] += ms; d[1] += flops; d[2] += nbytes; d[3] += 1
-    plan.graph = saved_graph
     total_ms = sum(v[0] for v in per_kernel.values()) / reps
     dom = max(per_kernel.items(), key=lambda kv: kv[1][0])
     dname, (dms, dflops, dbytes, dn) = dom
+    # the same kernel's launch duration WITH a second forward in flight (what a rocprofv3 kernel trace of the default, overlapped run
+    # shows): plan 1 replays as graphs on its own stream while plan 0 is timed launch by launch
+    over_us = None
+    if pipe.depth > 1:
+        osp = pipe.fwd_streams[1].cuda_stream
+        acc_ms, acc_n = 0.0, 0
+        for _ in range(reps):
+            for _ in range(12):
+                pipe.plans[1].run(osp)
+            for l, (name, ms, flops, nbytes) in zip(plan.launches, plan.timed_run(sp)):
+                kname = ops.conv_kernel_name(l) if l.fn is ops.lib().icaf_conv2d else name
+                if kname == dname:
+                    acc_ms += ms; acc_n += 1
+            torch.cuda.synchronize()
+        over_us = round(1e3 * acc_ms / max(acc_n, 1), 2)
+    plan.graph = saved_graph
     # which roof bounds the dominant kernel: its algorithmic intensity against the ridge of the chip (dense MFMA peak /
     # HBM peak = 312 FLOP/B for the 16-bit types).  Both fractions are reported.
     tflops = dflops / (dms * 1e-3) / 1e12 if dflops else 0.0
@@ -287,7 +382,8 @@ def main():
                  "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / PEAK_TFLOPS[args.dtype], 4),
                  "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)})
     roof.update({"traffic": None, "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_traffic*.json)",
-                 "algorithmic_bytes_per_launch": round(dbytes / dn), "avg_launch_us": round(1e3 * dms / dn, 2), "launches_per_step": dn // reps,
+                 "algorithmic_bytes_per_launch": round(dbytes / dn), "avg_launch_us": round(1e3 * dms / dn, 2),
+                 "avg_launch_us_with_second_forward_in_flight": over_us, "launches_per_step": dn // reps,
                  "share_of_forward_kernel_time": round(dms / reps / total_ms, 3)})
     att = per_kernel.get("cross_attention")
     kernels = {k: {"ms_per_step": round(v[0] / reps, 4), "launches": v[3] // reps,
@@ -295,18 +391,25 @@ def main():
                    "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1)} for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
 
     if rank == 0:
-        pairs = B * world * args.steps
+        pairs = (args.global_batch if strong else B * world) * args.steps
         value = pairs / elapsed
         gf = GFLOP_PER_PAIR.get((args.model, H, W))
         out = {
             "metric": "RGB/IR image-pairs/sec (two-stream forward + NMS)", "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "repeats": len(runs), "value_min": round(pairs / max(runs), 2), "value_max": round(pairs / min(runs), 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{yaml_name[:-5]} + DMFF(loops={args.loops}) {args.dtype}, batch {B}/GPU, "
                                    f"{H}x{W} synthetic RGB/IR pairs, seeded random weights, NMS conf {args.conf} iou {args.iou}",
-                       "global_batch": B * world, "parallelism": f"dp{world} (pairs sharded, one all-gather of detections)",
+                       "global_batch": args.global_batch if strong else B * world,
+                       "local_batches": [D.shard_range(args.global_batch, r, world)[1] - D.shard_range(args.global_batch, r, world)[0]
+                                         for r in range(world)] if strong else [B] * world,
+                       "parallelism": f"dp{world} (pairs sharded, one all-gather of detections)",
+                       "world_size_of_process_group": tdist.get_world_size() if world > 1 else 1,
+                       "backend": tdist.get_backend() if world > 1 else None,
                        "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap, "batches_in_flight": pipe.depth},
+            "per_rank_pairs_per_s": {"min": round(min(rank_rates), 2), "max": round(max(rank_rates), 2),
+                                     "note": "each rank's own clock around K steps of its shard (value = all ranks, max-over-ranks time)"},
             "forward_only_pairs_per_s": round(B / (fwd_tp_ms * 1e-3), 2),       # same batches-in-flight as `value`, no NMS
             "forward_ms_per_batch": round(fwd_ms, 3),                            # latency of ONE forward (one plan replayed back to back)
             "forward_only_pairs_per_s_one_in_flight": round(B / (fwd_ms * 1e-3), 2),
@@ -352,17 +455,36 @@ def main():
             out["latency_b1"] = {"forward_plus_nms_ms_median": round(lat[len(lat) // 2], 4), "p90_ms": round(lat[int(len(lat) * 0.9)], 4),
                                  "forward_graph_ms_device": round(l0.elapsed_ms(l1) / 50, 4), "launches_per_forward": len(lp.plan.launches),
                                  "note": "batch 1, depth 1, hipGraph replay + device NMS on one stream, synchronised per step"}
+        if world == 1 and not args.no_h2d:
+            out["h2d_feed"] = h2d_feed(model, args, B, H, W, dev)
         # PMC counters cannot be read from inside this process: the committed summaries of tools/gpu_pmc.sh (same command line, one
         # file per workload: profiles/pmc_traffic*.json) supply the dominant kernel's HBM bytes
         import glob
         for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic*.json"))):
             pm = json.load(open(tf))
-            k = pm.get("kernels", {}).get(dname)
+            pk = pm.get("kernels", {})
+            k = pk.get(dname)
             if pm.get("workload") == out["config"]["workload"] and k \
                     and "fetch_bytes_corrected" in k and "write_bytes_uncorrected" in k:
                 roof["traffic"] = round(k["fetch_bytes_corrected"] + k["write_bytes_uncorrected"])
                 roof["traffic_detail"] = {"fetch_bytes": round(k["fetch_bytes_corrected"]),
                                           "write_bytes": round(k["write_bytes_uncorrected"]), "source": os.path.basename(tf)}
+                # whole forward: counter bytes per dispatch of every kernel name x its launches per forward (a name's counter mean is over
+                # exactly these launches, so the product is the name's exact total); names without counters are listed, not guessed
+                tot, missing = 0.0, []
+                for name, v in per_kernel.items():
+                    c = pk.get(name)
+                    if c and "fetch_bytes_corrected" in c:
+                        tot += (c["fetch_bytes_corrected"] + c["write_bytes_uncorrected"]) * (v[3] // reps)
+                    else:
+                        missing.append(name)
+                fr = out["forward_roofline"]
+                fr["traffic"] = round(tot)
+                fr["traffic_unit"] = "HBM bytes per forward (PMC bytes per dispatch x launches, all kernels)"
+                fr["traffic_gbs"] = round(tot / (fwd_tp_ms * 1e-3) / 1e9, 1)
+                fr["traffic_hbm_frac"] = round(tot / (fwd_tp_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+                fr["traffic_over_algorithmic"] = round(tot / (sum(v[2] for v in per_kernel.values()) / reps), 3)
+                fr["traffic_kernels_without_counters"] = missing
                 break
         if world == 1 and not args.no_cpu_baseline:
             fused = Model(cfg).eval()

@@ -303,11 +303,7 @@ static int launch_cstream_cfg(const ConvP& p, int groups, hipStream_t s) {
     ICAF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     int grid = (cus / groups) & ~7;                // one workgroup per CU (161 KB of LDS), the groups side by side; 8 XCDs
     if (grid < 8) grid = 8;
-    static std::atomic<bool> attr{false};
-    if (!attr) {
-        ICAF_HIP(hipFuncSetAttribute((const void*)cstream_kernel<DT, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS));
-        attr = true;
-    }
+    ICAF_LDS_OPTIN((cstream_kernel<DT, CHAIN>), CS_LDS);
     cstream_kernel<DT, CHAIN><<<dim3((unsigned)grid, 1, (unsigned)groups), dim3(512), CS_LDS, s>>>(p, gm);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;

@@ -423,11 +423,7 @@ static int launch_ctile_cfg(const ConvP& p, int groups, hipStream_t s) {
     void (*kern)(const ConvP, const int, const int, const int, const int, const int);
     if constexpr (FUSE1) kern = bneck_kernel<DT, TH, TW, BN, ICAF_ACT_SILU, CHAIN3>;
     else kern = ctile_kernel<DT, TH, TW, BN, ICAF_ACT_SILU, S>;
-    static std::atomic<int> attr_bytes{0};                      // per instantiation: largest dynamic LDS size enabled so far
-    if (lds > 64 * 1024 && lds > attr_bytes) {
-        ICAF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_bytes = lds;
-    }
+    ICAF_LDS_OPTIN(kern, lds);                                  // per instantiation and device: largest dynamic LDS size enabled so far
     kern<<<dim3((unsigned)q.mtiles, 1, (unsigned)groups), dim3(NTHREADS), lds, s>>>(q, lsp, lcin, tiles_x, tiles_x * tiles_y, halo_bytes);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;

@@ -384,11 +384,7 @@ static int launch_cwide_cfg(const icaf_conv_args* a, const ConvP& p, hipStream_t
     gm.tiles_x = (p.Wo + G::TW - 1) / G::TW;
     gm.tiles_y = (p.Ho + CW_TH - 1) / CW_TH;
     gm.ntile = p.B * gm.tiles_x * gm.tiles_y;
-    static std::atomic<bool> attr{false};
-    if (!attr) {
-        ICAF_HIP(hipFuncSetAttribute((const void*)cwide_kernel<DT, CIN, STR, NSUB, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        attr = true;
-    }
+    ICAF_LDS_OPTIN((cwide_kernel<DT, CIN, STR, NSUB, CHAIN>), G::LDS);
     cwide_kernel<DT, CIN, STR, NSUB, CHAIN><<<dim3((unsigned)gm.ntile, (unsigned)(a->Cout / CW_N), (unsigned)a->groups), dim3(256), G::LDS, s>>>(p, gm, a->wf, a->wf_gs);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;

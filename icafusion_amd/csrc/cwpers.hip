@@ -355,11 +355,7 @@ static int launch_cwpers_cfg(const icaf_conv_args* a, const ConvP& p, hipStream_
     ICAF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     int grid = (cus * (NW == 8 ? 1 : G::WGPC) / (a->groups * nblk)) & ~7;    // the groups and channel blocks side by side; 8 XCDs
     if (grid < 8) grid = 8;
-    static std::atomic<bool> attr{false};
-    if (!attr) {
-        ICAF_HIP(hipFuncSetAttribute((const void*)cwpers_kernel<DT, CIN, STR, TWS, NCG, NW, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr = true;
-    }
+    ICAF_LDS_OPTIN((cwpers_kernel<DT, CIN, STR, TWS, NCG, NW, CHAIN>), lds_bytes);
     cwpers_kernel<DT, CIN, STR, TWS, NCG, NW, CHAIN><<<dim3((unsigned)grid, (unsigned)nblk, (unsigned)a->groups), dim3(G::THREADS), lds_bytes, s>>>(p, gm, a->wf, a->wf_gs);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;

@@ -219,11 +219,7 @@ static int launch_detect_conv(const ConvP& p, const DetectEpi<NA, NO>& epi, hipS
     ICAF_HIP(hipGetDevice(&dev));
     ICAF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int grid = cus & ~7;                     // one workgroup per CU, 8 XCDs; workgroups beyond the pixel tiles exit at once
-    static std::atomic<bool> attr{false};
-    if (!attr) {
-        ICAF_HIP(hipFuncSetAttribute((const void*)detect_conv_kernel<DT, NA, NO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
-    }
+    ICAF_LDS_OPTIN((detect_conv_kernel<DT, NA, NO>), LDS);
     detect_conv_kernel<DT, NA, NO><<<dim3((unsigned)grid, 1, 1), dim3(512), LDS, s>>>(q, epi);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;

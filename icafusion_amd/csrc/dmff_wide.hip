@@ -451,25 +451,10 @@ static int wide_fill(const icaf_dmff_args* a, WideP& p, const char* who) {
     return ICAF_OK;
 }
 
-template <class K>
-static int wide_attr(K kern, size_t lds, const char* who) {
-    if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "%s: %zu bytes of LDS exceed 160 KiB", who, lds);
-    ICAF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    return ICAF_OK;
-}
-
 template <int DT>
 static int launch_wide_ln_qkv(const WideP& p, hipStream_t s) {
     const size_t lds = (size_t)WROWS * (p.C * 2 + 16);
-    static std::atomic<bool> attr_set[ICAF_MAX_DEVICES];
-    int dev = 0;
-    ICAF_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= ICAF_MAX_DEVICES) return fail(ICAF_ERR_UNSUPPORTED, "device ordinal %d", dev);
-    if (!attr_set[dev]) {
-        int st = wide_attr(dmff_wide_ln_qkv_kernel<DT>, lds, "icaf_dmff_wide_ln_qkv");
-        if (st) return st;
-        attr_set[dev] = true;
-    }
+    ICAF_LDS_OPTIN((dmff_wide_ln_qkv_kernel<DT>), lds);        // (size checked on EVERY call, attribute raised per device as needed)
     const long long work = ((p.rows + WROWS - 1) / WROWS) * (p.C / WPASS);
     hipLaunchKernelGGL((dmff_wide_ln_qkv_kernel<DT>), dim3((unsigned)(8 * ((work + 3) / 4))), dim3(WT), lds, s, p);
     ICAF_LAUNCH_CHECK();
@@ -483,15 +468,7 @@ static size_t wide_proj_mlp_lds(int C, int hid) {
 template <int DT, int NPW>
 static int launch_wide_proj_mlp(const WideP& p, hipStream_t s) {
     const size_t lds = wide_proj_mlp_lds(p.C, p.hid);
-    static std::atomic<bool> attr_set[ICAF_MAX_DEVICES];
-    int dev = 0;
-    ICAF_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= ICAF_MAX_DEVICES) return fail(ICAF_ERR_UNSUPPORTED, "device ordinal %d", dev);
-    if (!attr_set[dev]) {
-        int st = wide_attr(dmff_wide_proj_mlp_kernel<DT, NPW>, lds, "icaf_dmff_wide_proj_mlp");
-        if (st) return st;
-        attr_set[dev] = true;
-    }
+    ICAF_LDS_OPTIN((dmff_wide_proj_mlp_kernel<DT, NPW>), lds);
     const long long ntiles = (p.rows + WROWS - 1) / WROWS;
     hipLaunchKernelGGL((dmff_wide_proj_mlp_kernel<DT, NPW>), dim3((unsigned)(8 * ((ntiles + 3) / 4))), dim3(WT), lds, s, p);
     ICAF_LAUNCH_CHECK();

@@ -192,4 +192,22 @@ __host__ __device__ __forceinline__ void fd_divmod(unsigned int n, FastDiv f, un
 
 constexpr int ICAF_MAX_DEVICES = 64;      // per-device one-time kernel attribute flags (hipFuncSetAttribute is per device)
 
+// One-time opt-in of ONE kernel instantiation to `bytes` of dynamic LDS, per DEVICE: hipFuncSetAttribute is per device, and a process may
+// drive several GPUs (tests, one process per node).  Expands to a function-local static flag array, i.e. one per template / lambda
+// instantiation of the enclosing launcher.  With GROW the largest size enabled so far is tracked instead of a flag (launchers whose LDS
+// size depends on the launch).
+#define ICAF_LDS_OPTIN(kern, bytes)                                                                                                  \
+    do {                                                                                                                             \
+        static std::atomic<int> _icaf_lds[icaf::ICAF_MAX_DEVICES];                                                                   \
+        int _dev = 0;                                                                                                                \
+        ICAF_HIP(hipGetDevice(&_dev));                                                                                               \
+        if (_dev < 0 || _dev >= icaf::ICAF_MAX_DEVICES) return icaf::fail(ICAF_ERR_UNSUPPORTED, "device ordinal %d", _dev);          \
+        const int _want = (int)(bytes);                                                                                              \
+        if (_want > 160 * 1024) return icaf::fail(ICAF_ERR_UNSUPPORTED, "%d bytes of LDS exceed the 160 KiB of a CU", _want);        \
+        if (_want > 64 * 1024 && _want > _icaf_lds[_dev]) {                                                                          \
+            ICAF_HIP(hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, _want));                   \
+            _icaf_lds[_dev] = _want;                                                                                                 \
+        }                                                                                                                            \
+    } while (0)
+
 }  // namespace icaf

@@ -510,24 +510,13 @@ static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
     return (long long)p.K * eb >= 256 ? t + 20 : t;
 }
 
-template <typename KernelT>
-static int set_lds_attr(KernelT kernel, int bytes) {
-    if (bytes > 64 * 1024) ICAF_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    return ICAF_OK;
-}
-
 template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE, bool PRE = false, bool CHAIN = false>
 static int launch_dma_mode(const ConvP& q, dim3 grid, hipStream_t s) {
     constexpr int ring_only = NS * (BM + BN) * RB, stage_out = TileLds<DT, ODT, BM, BN>::OUT_BYTES;
     constexpr int ring0 = ring_only > stage_out ? ring_only : stage_out;
     constexpr int ring = CHAIN ? (ring0 + 1023) / 1024 * 1024 + BN * BN * 2 : ring0;      // + the chained layer's weights
     static_assert(ring <= 160 * 1024, "LDS capacity");
-    static std::atomic<bool> attr_done{false};     // one flag per instantiation (one process drives one GPU)
-    if (!attr_done) {
-        int st = set_lds_attr(igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE, PRE, CHAIN>, ring);
-        if (st) return st;
-        attr_done = true;
-    }
+    ICAF_LDS_OPTIN((igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE, PRE, CHAIN>), ring);
     igemm_dma_kernel<DT, ODT, BM, BN, WM, WN, ACT, RB, NS, MODE, PRE, CHAIN><<<grid, dim3((BM / WM) * (BN / WN) * 64), ring, s>>>(q);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;

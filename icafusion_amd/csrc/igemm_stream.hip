@@ -118,6 +118,15 @@ __global__ __launch_bounds__(512) void igemm_stream_kernel(const ConvP p) {
 // ---------------------------------------------------------------------------------------------------------------
 const char* stream_tag(int shape) { return shape == 1 ? "128x128" : shape == 2 ? "128x64" : "?"; }
 
+// workgroups of the persistent grid per XCD for `groups` side-by-side groups on the current device (grid = 8 * wgx)
+static int stream_grid(int groups, int* wgx) {
+    int dev = 0, cus = 256;
+    ICAF_HIP(hipGetDevice(&dev));
+    ICAF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    *wgx = ((cus / (groups > 0 ? groups : 1)) & ~7) >> 3;
+    return ICAF_OK;
+}
+
 int stream_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     if (shape < 1 || shape > 2) return fail(ICAF_ERR_ARG, "igemm_stream: unknown shape %d", shape);
     if (a->dtype == ICAF_F32 || a->out_dtype != a->dtype) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: 16-bit types, out dtype == dtype");
@@ -129,6 +138,13 @@ int stream_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     if (p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: operand exceeds the 2 GiB buffer-descriptor range");
     if (!p.vec_y || a->Cout % 8) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: y must take 16-byte vectors (ldy %% 8, Cout %% 8, alignment)");
     if (shape == 1 && a->Cout <= 64) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream 128x128: Cout = %d <= 64 (use 128x64)", a->Cout);
+    // the persistent grid is one workgroup per CU; an XCD's workgroups are dealt over the channel tiles, so the tile count must divide
+    // them (checked HERE, not only at launch: icaf_conv2d_kernel_name and the tuner's cache validation see the same verdict)
+    int wgx = 0;
+    const int st = stream_grid(a->groups, &wgx);
+    if (st) return st;
+    const int ntiles = (p.Cout + (shape == 1 ? 128 : 64) - 1) / (shape == 1 ? 128 : 64);
+    if (wgx < ntiles || wgx % ntiles) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: %d channel tiles do not divide the %d workgroups of an XCD", ntiles, wgx);
     return ICAF_OK;
 }
 
@@ -139,20 +155,17 @@ static int launch_stream_cfg(const ConvP& p, int groups, hipStream_t s) {
     q.mtiles = (p.M + 127) / 128;
     q.ntiles = (p.Cout + BN - 1) / BN;
     q.nchunks = p.K / 64;                          // 128-byte slices of a 16-bit type (K = kh * kw * Cin is a multiple of 64)
-    int dev = 0, cus = 256;
+    int dev = 0, wgx = 0;
     ICAF_HIP(hipGetDevice(&dev));
-    ICAF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    int grid = (cus / groups) & ~7;                // one workgroup per CU (LDS), the groups (RGB / IR stream) side by side; 8 XCDs
-    const int wgx = grid >> 3;
+    if (dev < 0 || dev >= ICAF_MAX_DEVICES) return fail(ICAF_ERR_UNSUPPORTED, "device ordinal %d", dev);
+    int st = stream_grid(groups, &wgx);            // one workgroup per CU (LDS), the groups (RGB / IR stream) side by side; 8 XCDs
+    if (st) return st;
+    const int grid = wgx << 3;
     if (wgx < q.ntiles || wgx % q.ntiles) return fail(ICAF_ERR_UNSUPPORTED, "igemm_stream: %d channel tiles do not divide the %d workgroups of an XCD", q.ntiles, wgx);
     // (fewer pixel tiles than pixel slots: the surplus workgroups find their range empty and exit)
     const bool plain = q.kh == 1 && q.kw == 1 && q.sh == 1 && q.sw == 1 && q.ph == 0 && q.pw == 0;
     auto go = [&](auto kern) -> int {
-        static std::atomic<bool> attr{false};      // one flag per instantiation (one process drives one GPU)
-        if (!attr) {
-            ICAF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            attr = true;
-        }
+        ICAF_LDS_OPTIN(kern, LDS);               // per instantiation AND per device
         kern<<<dim3((unsigned)grid, 1, (unsigned)groups), dim3(512), LDS, s>>>(q);
         ICAF_LAUNCH_CHECK();
         return ICAF_OK;

@@ -217,11 +217,7 @@ static int launch_wreg_mode(const icaf_conv_args* a, const ConvP& p, int groups,
     dim3 grid((unsigned)(q.mtiles * q.ntiles), 1, (unsigned)groups);
     const bool plain = q.kh == 1 && q.kw == 1 && q.sh == 1 && q.sw == 1 && q.ph == 0 && q.pw == 0;
     auto go = [&](auto kern) -> int {
-        static std::atomic<bool> attr{false};      // (one flag per instantiation: the lambda is instantiated per kernel type)
-        if (LDS > 64 * 1024 && !attr) {
-            ICAF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            attr = true;
-        }
+        ICAF_LDS_OPTIN(kern, LDS);               // (one flag array per instantiation: the lambda is instantiated per kernel type)
         kern<<<grid, dim3(NWV * 64), LDS, s>>>(q, a->wf, a->wf_gs);
         ICAF_LAUNCH_CHECK();
         return ICAF_OK;

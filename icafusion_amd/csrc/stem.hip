@@ -579,11 +579,7 @@ static int launch_stem(const StemP& q, hipStream_t s) {
     int grid = cus * (per_cu < 1 ? 1 : per_cu);
     if (grid > q.npatch) grid = q.npatch;
     grid = (grid + 7) & ~7;                         // the patch walk is per XCD (8 of them)
-    static std::atomic<bool> attr{false};
-    if (lds > 64 * 1024 && !attr) {
-        ICAF_HIP(hipFuncSetAttribute((const void*)stem_kernel<DT, BN, U8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    ICAF_LDS_OPTIN((stem_kernel<DT, BN, U8>), lds);
     stem_kernel<DT, BN, U8><<<dim3((unsigned)grid), dim3(NTHREADS), lds, s>>>(q);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
@@ -628,11 +624,7 @@ static int launch_stem2(const Stem2P& q, hipStream_t s) {
     ICAF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     int grid = cus < q.npatch ? cus : q.npatch;     // 122 KiB of LDS: one workgroup per CU
     grid = (grid + 7) & ~7;                         // the tile walk is per XCD (8 of them)
-    static std::atomic<bool> attr{false};
-    if (!attr) {
-        ICAF_HIP(hipFuncSetAttribute((const void*)stem2_kernel<DT, U8, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS));
-        attr = true;
-    }
+    ICAF_LDS_OPTIN((stem2_kernel<DT, U8, PAIR>), S2_LDS);
     stem2_kernel<DT, U8, PAIR><<<dim3((unsigned)grid), dim3(S2_THREADS), S2_LDS, s>>>(q);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;

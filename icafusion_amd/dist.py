@@ -34,6 +34,28 @@ def shard_range(global_batch, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def padded_local_batch(global_batch, world):
+    """Pairs per rank of a STATIC plan that can hold any rank's shard: the longest shard, ceil(global_batch / world).  The collective
+    needs equally sized blocks, so a rank whose shard is one pair shorter runs that slot as padding (gathered_to_global drops it)."""
+    return -(-global_batch // world)
+
+
+def gathered_to_global(det_all, count_all, global_batch):
+    """Rank-major gathered blocks (world, B_pad, max_det, 6) / (world, B_pad) of a contiguously sharded global batch -> the
+    (global_batch, max_det, 6) / (global_batch,) tensors in global pair order: rank r contributes its first shard_range(r) rows.
+    Even splits (global_batch % world == 0) return views; uneven ones allocate (index_select)."""
+    world, bpad = count_all.shape[0], count_all.shape[1]
+    if global_batch == world * bpad:
+        return flatten_gathered(det_all, count_all)
+    rows = []
+    for r in range(world):
+        lo, hi = shard_range(global_batch, r, world)
+        rows.extend(r * bpad + k for k in range(hi - lo))
+    idx = torch.tensor(rows, dtype=torch.long, device=count_all.device)
+    det, count = flatten_gathered(det_all, count_all)
+    return det.index_select(0, idx), count.index_select(0, idx)
+
+
 def detection_block(B, max_det, device):
     """ONE allocation holding a rank's NMS output: [B][max_det][6] fp32 detections followed by [B] int32 counts (stored in the
     same fp32 storage, bit for bit).  The NMS kernels write straight into the two views, and the block is what travels through the

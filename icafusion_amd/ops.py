@@ -7,6 +7,7 @@ PyTorch only provides device memory and streams here — none of its operators r
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -99,7 +100,7 @@ def pack_conv_weight(w4d, dt, cin_pad=None):
     return pack_matrix(w.reshape(co, -1).contiguous(), dt)
 
 
-_FRAG_CACHE = {}
+_FRAG_CACHE = {}              # id(packed tensor) -> (weakref to it, fragment-major copy); entries die with the packed tensor
 CWIDE = os.environ.get("ICAF_CWIDE", "1") != "0"               # A/B switch: resident-patch / streamed-weights 3x3 kernel (cwide.hip) as a tuner candidate
 CSTREAM = os.environ.get("ICAF_CSTREAM", "1") != "0"           # A/B switch: persistent resident-filter 3x3 kernel as a tuner candidate
 WREG_GEMM = os.environ.get("ICAF_WREG_GEMM", "1") != "0"       # A/B switch: weights-from-registers kernels as tuner candidates
@@ -109,9 +110,9 @@ def frag_weights(w_packed):
     """Second copy of packed 16-bit weights ([Np][Kp] or stacked [G][Np][Kp]) in FRAGMENT-MAJOR order for the kernels that feed
     the weight operand from registers (igemm_wreg.hip; icaf.h: icaf_conv_args.wf): [G][Np / 32][Kp / 16][64][8], lane (hi * 32 + r) of
     block (nb, ks) = w[nb * 32 + r][ks * 16 + hi * 8 : + 8].  Built once per packed tensor (plan-build time), cached by storage."""
-    key = (w_packed.data_ptr(), tuple(w_packed.shape), w_packed.dtype)
+    key = id(w_packed)
     hit = _FRAG_CACHE.get(key)
-    if hit is not None:
+    if hit is not None and hit[0]() is w_packed:
         return hit[1]
     w = w_packed if w_packed.dim() == 3 else w_packed[None]
     G, np_, kp = w.shape
@@ -120,7 +121,10 @@ def frag_weights(w_packed):
     f = f.reshape(G, np_ // 32, kp // 16, 64, 8)
     if w_packed.dim() == 2:
         f = f[0]
-    _FRAG_CACHE[key] = (w_packed, f)                 # (the packed tensor is kept alive with its copy: the key is its address)
+    # The copy lives exactly as long as the packed tensor it mirrors: HipModule.invalidate() / .to() / load_state_dict drop the module's
+    # packed tensors, and the finaliser then drops the copy (a strong reference here pinned every old pack in device memory forever).
+    _FRAG_CACHE[key] = (weakref.ref(w_packed), f)
+    weakref.finalize(w_packed, _FRAG_CACHE.pop, key, None)
     return f
 
 
@@ -305,7 +309,7 @@ def conv_candidates(a):
         cands.append(71)
     if cw and not a.w2:
         cands += cw
-    if a.wf and not a.pre and not a.w2:
+    if a.wf and WREG_GEMM and not a.pre and not a.w2:
         cands.append(61)                     # weights fed from registers (igemm_wreg.hip): 128 x 128 ...
         if a.Cout > 128:
             cands.append(62)                 # ... and 128 x 256
@@ -324,10 +328,16 @@ def autotune_conv(launch, stream_ptr, reps=3, context=()):
     own previous run); timing a layer against itself back to back ranks the candidates wrongly at the margin."""
     a = launch.keep[0]
     sig = _conv_signature(a)
-    if sig in _TUNE_CACHE:
-        a.tile = _TUNE_CACHE[sig]
-        return a.tile
     cands = conv_candidates(a)
+    if sig in _TUNE_CACHE:
+        # A cached id is only as good as the state it was tuned under: the signature does not encode whether the fragment-major
+        # weights exist (ICAF_WREG_GEMM / ICAF_CWIDE), which A/B switches are set, or the device's CU count (the persistent
+        # streaming GEMM needs its channel tiles to divide an XCD's workgroups).  The entry is applied only if it is still a candidate
+        # for THIS launch and the library's own check for that configuration accepts it; otherwise it is dropped and the launch re-tuned.
+        if tile_valid(launch, _TUNE_CACHE[sig], cands):
+            a.tile = _TUNE_CACHE[sig]
+            return a.tile
+        del _TUNE_CACHE[sig]
     best, best_ms = 0, float("inf")
     e0, e1 = Event(), Event()
     for c in cands:
@@ -355,6 +365,21 @@ def autotune_conv(launch, stream_ptr, reps=3, context=()):
     a.tile = best
     _TUNE_CACHE[sig] = best
     return best
+
+
+def tile_valid(launch, tile, cands=None):
+    """Is launch configuration `tile` usable for this recorded conv launch — a candidate for its arguments AND accepted by the
+    library's check of that configuration (icaf_conv2d_kernel_name runs the same *_check functions the launch runs)?"""
+    a = launch.keep[0]
+    if tile not in (conv_candidates(a) if cands is None else cands):
+        return False
+    saved = a.tile
+    a.tile = tile
+    try:
+        buf = C.create_string_buffer(256)
+        return lib().icaf_conv2d_kernel_name(launch.args[0], buf, 256) == 0
+    finally:
+        a.tile = saved
 
 
 def save_tune_cache(path):

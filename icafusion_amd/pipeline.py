@@ -26,8 +26,12 @@ from .utils.general import nms_device
 
 class DetectionPipeline:
     def __init__(self, model, batch, height, width, device, conf_thres=0.25, iou_thres=0.45, classes=None,
-                 agnostic=False, multi_label=False, max_det=300, world=1, overlap=True, force_gather=False, depth=1):
+                 agnostic=False, multi_label=False, max_det=300, world=1, overlap=True, force_gather=False, depth=1, u8=False):
+        """u8=True: the plans take the dataloader's uint8 (B, 6, H, W) RGB+IR batch (Model.forward_u8: `/255`, split and cast in the
+        staging kernel, reference test.py:116-123) — `submit_u8` then feeds them from (pinned) host memory with the H2D copy on its own
+        stream, overlapped with the forwards in flight."""
         self.model, self.device, self.world = model, torch.device(device), world
+        self.u8 = bool(u8)
         self.gather = world > 1 or bool(force_gather)       # force_gather: run the all-gather even with one rank (hardware test of the RCCL path)
         self.nms_args = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic,
                              multi_label=multi_label, max_det=max_det)
@@ -36,7 +40,9 @@ class DetectionPipeline:
         # depth > 1: that many batches in flight, each with its own plan (buffers, hipGraph) and forward stream — the tails of one
         # forward (20x20 layers, DMFF, Detect: launches that leave CUs idle) overlap the full-width layers of the next
         self.depth = max(1, int(depth)) if overlap else 1         # overlap=False is the strictly sequential baseline: one batch, one stream
-        self.plans = [model.plan_for(batch, height, width, self.device, slot=s) for s in range(self.depth)]
+        self.plans = [model.plan_for(batch, height, width, self.device, u8=self.u8, slot=s) for s in range(self.depth)]
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.u8 else None
+        self.copied = [torch.cuda.Event() for _ in range(self.depth)]
         self.plan = self.plans[0]
         self.z = self.plan.outputs[0]
         self.fwd_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
@@ -85,9 +91,31 @@ class DetectionPipeline:
                 t.record_stream(fs)                                # on the caller's stream) before the copy has read it
         return self.step()
 
+    def submit_u8(self, img6):
+        """One uint8 (B, 6, H, W) batch — pinned host memory (the reference's dataloader output, test.py:116) or a device tensor — into
+        the next step's staging buffer and through the pipeline.  The copy runs on the pipeline's COPY stream: it waits only for the
+        previous forward of the SAME slot (which read the buffer), so with depth >= 2 the H2D transfer of batch n + 1 overlaps the forward
+        of batch n; the slot's forward stream then waits for the copy.  The host buffer must stay untouched until the copy has run
+        (`pipe.copied[slot].synchronize()`, or simply rotate >= depth + 1 pinned buffers)."""
+        assert self.u8, "DetectionPipeline(u8=True) takes uint8 batches"
+        d = self.n % self.depth
+        cs, fs = self.copy_stream, self.fwd_streams[d]
+        cs.wait_stream(fs)                                        # the slot's previous forward has consumed its staging buffer
+        if img6.is_cuda:
+            cs.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(cs):
+            self.plans[d].inputs[0].copy_(img6, non_blocking=True)
+        if img6.is_cuda:
+            img6.record_stream(cs)
+        self.copied[d].record(cs)
+        fs.wait_event(self.copied[d])
+        return self.step()
+
     def step(self):
-        """Enqueue one batch: forward replay, then NMS (+ gather) on the second stream.  Returns (det, count[, all])
-        device tensors that are valid once the nms stream has drained (see synchronize())."""
+        """Enqueue one batch: forward replay, then NMS (+ gather) on the second stream.  Returns (det, count) device tensors, valid once
+        the nms stream has drained (see synchronize()) — ALWAYS rank-major: det (world, B, max_det, 6) fp32, count (world, B) int32, i.e.
+        global batch order for contiguous shards (dist.flatten_gathered gives the (world * B, ...) form).  Without a gather (one rank)
+        the leading axis has length 1 and the tensors are views of the slot's NMS output block."""
         if self.depth > 1:
             return self._step_deep()
         i = (self.n & 1) if self.overlap else 0
@@ -101,7 +129,7 @@ class DetectionPipeline:
             self.snap_done[i].record(fs)
             ns.wait_event(self.snap_done[i])
         det, count, keep = nms_device(self.zbuf[i], stream_ptr=ns.cuda_stream, runner=self.runners[i], **self.nms_args)
-        out = (det, count)
+        out = (det[None], count[None])
         if self.gather:
             with torch.cuda.stream(ns):
                 out = D.gather_detections(det, count, out=self.gathered[i], force_collective=True, block=self.runners[i].block)
@@ -122,7 +150,7 @@ class DetectionPipeline:
         self.fwd_done[d].record(fs)
         ns.wait_event(self.fwd_done[d])
         det, count, keep = nms_device(plan.outputs[0], stream_ptr=ns.cuda_stream, runner=self.deep_runners[d], **self.nms_args)
-        out = (det, count)
+        out = (det[None], count[None])
         if self.gather:
             with torch.cuda.stream(ns):
                 out = D.gather_detections(det, count, out=self.deep_gathered[d], force_collective=True, block=self.deep_runners[d].block)
@@ -137,8 +165,8 @@ class DetectionPipeline:
         self.nms_stream.synchronize()
 
     def __call__(self, rgb, ir):
-        """Convenience: copy one batch in, run it, wait, return list of (n, 6) detections per image."""
-        det, count = self.submit(rgb, ir)[:2]
+        """Convenience: copy one batch in, run it, wait, return list of (n, 6) detections per image (all ranks' images, global order)."""
+        det, count = self.submit(rgb, ir)
         self.synchronize()
-        det, count = det.reshape(-1, det.shape[-2], 6), count.reshape(-1)
+        det, count = D.flatten_gathered(det, count)
         return [det[k, :n].clone() for k, n in enumerate(count.tolist())]

@@ -40,7 +40,7 @@ def test_pipeline_steps_equal_sequential_forward_plus_nms(overlap):
     for rgb, ir in batches:
         pipe.inputs[0].copy_(rgb.to(DEV)); pipe.inputs[1].copy_(ir.to(DEV))
         torch.cuda.current_stream().synchronize()
-        got.append(pipe.step()[:2])
+        got.append(tuple(t[0] for t in pipe.step()))                # (world = 1: drop the rank axis)
         if len(got) >= 2 and overlap:                        # step n-1's tensors must survive step n being enqueued
             pipe.synchronize()
             det, count = got[-2]
@@ -74,7 +74,7 @@ def test_pipeline_with_several_batches_in_flight(depth):
     batches = [synth_images(B, H, W, seed=60 + k) for k in range(6)]
     outs = []
     for rgb, ir in batches:
-        outs.append(pipe.submit(rgb.to(DEV), ir.to(DEV))[:2])                     # copies on the slot's forward stream, no host sync
+        outs.append(tuple(t[0] for t in pipe.submit(rgb.to(DEV), ir.to(DEV))))    # copies on the slot's forward stream, no host sync; rank axis dropped
     pipe.synchronize()
     m.static_outputs = False
     ref = build("yolov5s_Transfusion_FLIR.yaml", torch.bfloat16)                  # an independent model instance, one batch at a time
