@@ -54,7 +54,19 @@ def demangle(names):
         return dict(zip(names, r.stdout.splitlines()))
     except Exception:
         return {n: n for n in names}
-PER_FILE = {"detect.hip": ["-ffp-contract=off"], "nms.hip": ["-ffp-contract=off"]}
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs instead of AGPRs (gfx950: one unified register file).  Kernels whose MFMA results
+# feed VALU arithmetic directly (softmax, GELU) otherwise pay one v_accvgpr_read per accumulator element and tile — the attention loop
+# spent 32 of ~118 issue slots per score tile on them (attn_core.h) — and AGPR-allocated accumulators round the register budget up.
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+PER_FILE = {"detect.hip": ["-ffp-contract=off"], "nms.hip": ["-ffp-contract=off"],
+            "dmff.hip": VGPR_FORM, "dmff_fused.hip": VGPR_FORM}
+_VF = os.environ.get("ICAF_VGPR_FORM", "")             # A/B builds (tools/build_variant.py): "all" = the whole library in that form, "none" = no file
+if _VF == "all":
+    PER_FILE = {f: [x for x in PER_FILE.get(f, []) if x not in VGPR_FORM] + VGPR_FORM
+                for f in ("api.hip", "cstream.hip", "ctile.hip", "cwide.hip", "cwpers.hip", "detect.hip", "dmff.hip", "dmff_fused.hip", "dmff_wide.hip",
+                          "igemm.hip", "igemm_stream.hip", "igemm_wreg.hip", "nms.hip", "pool.hip", "stem.hip")}
+elif _VF == "none":
+    PER_FILE = {f: [x for x in v if x not in VGPR_FORM] for f, v in PER_FILE.items()}
 EXPORT = "-fvisibility=default"
 
 

@@ -6,6 +6,7 @@
 // The Linear layers around them (QKV / out-proj / MLP) run on the implicit-GEMM kernel (igemm.hip) with the
 // LearnableCoefficient mixes folded into its epilogue.
 #include "icaf_common.h"
+#include "attn_core.h"
 
 namespace icaf {
 
@@ -254,44 +255,21 @@ template <int DT> __device__ __forceinline__ int vt_phys(int key) {
     }
 }
 
-template <int DT> __device__ __forceinline__ u32x4 pack_p(const f32x16& s, int st);
-template <> __device__ __forceinline__ u32x4 pack_p<ICAF_F32>(const f32x16& s, int st) {
-    u32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(s[4 * st + e]);
-    return v;
-}
-template <> __device__ __forceinline__ u32x4 pack_p<ICAF_BF16>(const f32x16& s, int st) {
-    u32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-        v[e] = pack2_bf16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
-    return v;
-}
-template <> __device__ __forceinline__ u32x4 pack_p<ICAF_F16>(const f32x16& s, int st) {
-    u32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-        v[e] = pack2_f16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
-    return v;
-}
-
 template <int DT, int DKP>
 __global__ __launch_bounds__(256) void cross_attn_kernel(const typename Elem<DT>::type* __restrict__ qkv,
                                                          typename Elem<DT>::type* __restrict__ out, int B, int N, int C, int DK,
                                                          int NP, float scale_l2e, int xq) {
     using E = Elem<DT>;
     using T = typename E::type;
+    using AC = AttnCore<DT, DKP>;
     constexpr int VEC = E::VEC, EB = E::BYTES;
-    constexpr int KSTEP = 2 * VEC;              // reduction elements consumed per mma_step
-    constexpr int QSTEPS = DKP / KSTEP;         // steps over d for S^T = K Q^T
-    constexpr int TD = (DKP + 31) / 32;         // 32-row d tiles of O^T
-    constexpr int PSTEPS = 32 / KSTEP;          // steps over the 32 keys of a tile for O^T += V^T P^T
+    constexpr int KSTEP = AC::KSTEP, QSTEPS = AC::QSTEPS, TD = AC::TD;
     constexpr int KS = DKP * EB + 16;           // K row stride (bytes), odd multiple of 16 -> conflict-free b128 reads
     const int VS = NP * EB + 16;                // V^T row stride (bytes)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;
     unsigned char* Vt = smem + (size_t)NP * KS;
+    unsigned char* ones = Vt + (size_t)DKP * VS;                   // (AC::FREE only) one all-ones row: the softmax denominator's V^T row
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     // XCD-aware placement (xq > 0: one-dimensional grid of xq * heads * 2B workgroups, xq = query splits, 2B % 8 == 0): all heads and query
@@ -335,6 +313,10 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const typename Elem<DT>
                 *(unsigned short*)(Vt + (size_t)(v * 8 + j) * VS + pk * 2) = (unsigned short)((vvv[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
         }
     }
+    if constexpr (AC::FREE) {
+        const u32x4 of = ones_frag<DT>();
+        for (int i = tid; i * 16 < NP * EB; i += 256) *(u32x4*)(ones + i * 16) = of;
+    }
     __syncthreads();
 
     const int nqt = NP >> 5;
@@ -349,68 +331,9 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const typename Elem<DT>
             if (qok && off < DK) v = *(const u32x4*)(qbase + q * row3 + off);
             qf[st] = v;
         }
-        float m = -INFINITY, l = 0.0f;
         f32x16 o[TD];
-#pragma unroll
-        for (int td = 0; td < TD; ++td)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[td][r] = 0.0f;
-
-        for (int kt = 0; kt < nqt; ++kt) {
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-#pragma unroll
-            for (int st = 0; st < QSTEPS; ++st) {
-                const u32x4 kf = *(const u32x4*)(Ks + (size_t)(kt * 32 + l31) * KS + st * 32 + hi * 16);
-                mma_step<DT>(s, kf, qf[st]);
-            }
-            // Softmax bookkeeping in the UNSCALED score domain (scale > 0, so the max commutes): p = exp2(s*c - m*c) is one
-            // FMA + one exp2 per score.  Only the last key tile can contain padding keys, and the running maximum stops
-            // moving after the first few tiles, so the -inf masking and the rescale of O sit behind wave-uniform branches.
-            if (kt == nqt - 1 && NP != N) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    s[r] = key < N ? s[r] : -INFINITY;
-                }
-            }
-            float tmax = s[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float m_new = fmaxf(m, tmax);
-            const float mc = m_new * scale_l2e;
-            float psum = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_l2e, -mc));
-                s[r] = pv;
-                psum += pv;
-            }
-            if (!__all(m_new == m)) {                  // rare after the first tiles: rescale the running sum and O
-                const float alpha = __builtin_amdgcn_exp2f((m - m_new) * scale_l2e);
-                l *= alpha;
-#pragma unroll
-                for (int td = 0; td < TD; ++td)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
-                m = m_new;
-            }
-            l += psum;
-#pragma unroll
-            for (int st = 0; st < PSTEPS; ++st) {
-                const u32x4 pf = pack_p<DT>(s, st);
-#pragma unroll
-                for (int td = 0; td < TD; ++td) {
-                    int drow = td * 32 + l31;
-                    drow = drow < DKP ? drow : DKP - 1;
-                    const u32x4 vf = *(const u32x4*)(Vt + (size_t)drow * VS + (size_t)(kt * 32 + st * KSTEP + hi * VEC) * EB);
-                    mma_step<DT>(o[td], vf, pf);
-                }
-            }
-        }
-        l += __shfl_xor(l, 32);
+        float l;
+        AC::template run<KS>(Ks, Vt, VS, ones, qf, nqt, N, scale_l2e, o, l);
         const float inv = 1.0f / l;
         if (qok) {
             T* orow = out + ((long long)(dir * B + b) * N + q) * C + (long long)h * DK;
@@ -496,7 +419,7 @@ static int launch_attn(const void* qkv, void* out, int B, int N, int C, int DK, 
     using T = typename Elem<DT>::type;
     constexpr int EB = Elem<DT>::BYTES;
     const int NP = (N + 31) & ~31;
-    const size_t lds = (size_t)NP * (DKP * EB + 16) + (size_t)DKP * ((size_t)NP * EB + 16);
+    const size_t lds = (size_t)NP * (DKP * EB + 16) + (size_t)(DKP + (AttnCore<DT, DKP>::ones_row() ? 1 : 0)) * ((size_t)NP * EB + 16);
     if (lds > 160 * 1024) return fail(ICAF_ERR_UNSUPPORTED, "icaf_cross_attention: %zu bytes of LDS needed (N=%d, dk=%d) exceed 160 KiB", lds, N, DK);
     static std::atomic<bool> attr_set[ICAF_MAX_DEVICES];          // per instantiation and per device
     int dev = 0;

@@ -23,6 +23,7 @@
 // (tests/test_gpu_dmff_fused.py); the fp32 model path uses the per-layer launches unless CrossTransformerBlock.fuse_fp32 is set.
 #include "icaf_common.h"
 #include "conv_common.h"
+#include "attn_core.h"
 
 namespace icaf {
 
@@ -315,16 +316,6 @@ template <int DT> __device__ __forceinline__ int vt_phys16(int key) {
         return (key & ~15) + (((k16 >> 2) & 1) << 3) + (k16 & 3) + ((k16 >> 3) << 2);
     }
 }
-template <int DT> __device__ __forceinline__ u32x4 pack_p16(const f32x16& s, int st) {
-    u32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if constexpr (DT == ICAF_F32) v[e] = __float_as_uint(s[4 * st + e]);
-        else if constexpr (DT == ICAF_BF16) v[e] = pack2_bf16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
-        else v[e] = pack2_f16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
-    }
-    return v;
-}
 // one 16-byte vector of a V row (channels v * VEC ...) -> VEC rows of V^T at (permuted) key column pk
 template <int DT> __device__ __forceinline__ void scatter_vt(unsigned char* Vt, int VS, int v, int pk, const u32x4& vvv) {
     if constexpr (DT == ICAF_F32) {
@@ -348,8 +339,9 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32 && DT != ICAF_F32) ? 2 :
     constexpr bool DMA = attn_mlp_dma<DT, NP2, SLB>();     // C >= 256: weight slices by LDS-DMA, DMFF_NSD-stage ring (WSD)
     using D = WSD<DT == ICAF_F32 ? ICAF_BF16 : DT, DMFF_NSD>;
     constexpr int RING_BYTES = DMA ? D::BYTES : Ring<SLB>::BYTES;
+    using AC = AttnCore<DT, DKP>;                          // the attention inner loop shared with cross_attn_kernel (attn_core.h)
     constexpr int VEC = E::VEC, EB = E::BYTES;
-    constexpr int KSTEP = 2 * VEC, QSTEPS = DKP / KSTEP, TD = (DKP + 31) / 32, PSTEPS = 32 / KSTEP;
+    constexpr int KSTEP = AC::KSTEP, QSTEPS = AC::QSTEPS, TD = AC::TD;
     // K row stride: 32-byte rows (dk <= 16) are read as ONE contiguous kilobyte per b128 wave read — no padding needed, and the
     // 13 KB it saves at N = 400 lets two workgroups share a CU (2 waves / SIMD); wider rows keep the odd-multiple-of-16 stride
     constexpr int KS = DKP * EB == 32 ? 32 : DKP * EB + 16;
@@ -361,7 +353,7 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32 && DT != ICAF_F32) ? 2 :
     const size_t hb_bytes = (size_t)TMROWS * SH;
     unsigned char* T0 = smem;                        // attention output -> later the LayerNorm'ed MLP input
     unsigned char* U = smem + tile_bytes;            // union: {K, V^T of two heads}  |  {H = hidden chunk, weight ring, LayerNorm partial sums}
-    const size_t kv_head = (size_t)NP * KS + (size_t)DKP * VS;
+    const size_t kv_head = (size_t)NP * KS + (size_t)(DKP + (AC::ones_row() ? 1 : 0)) * VS;      // (+ the all-ones V^T row: softmax denominator by MFMA)
     unsigned char* Hb = U;
     unsigned char* ring = U + hb_bytes;
     float* red = (float*)(ring + RING_BYTES);        // [2][64] row partial sums of the two column halves
@@ -427,6 +419,13 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32 && DT != ICAF_F32) ? 2 :
             }
         };
         if (pre) { load_round(0); store_round(); }
+        if constexpr (AC::ones_row()) {                       // written once: the staging of later rounds never touches it
+            const u32x4 of = ones_frag<DT>();
+            for (int hh = 0; hh < 2; ++hh) {
+                unsigned char* orow = U + hh * kv_head + (size_t)NP * KS + (size_t)DKP * VS;
+                for (int i = tid; i * 16 < NP * EB; i += FT) *(u32x4*)(orow + i * 16) = of;
+            }
+        }
         for (int h0 = 0; h0 < p.heads; h0 += 2) {
             if (!pre) {
                 if (h0) __syncthreads();                   // previous round's K / V^T are free again
@@ -462,64 +461,9 @@ __global__ __launch_bounds__(FT, (NP2 == 1 && DKP <= 32 && DT != ICAF_F32) ? 2 :
                     if (qok && off < DK) v = *(const u32x4*)(qb + (long long)q * row3 + (long long)h * DK + off);
                     qf[st] = v;
                 }
-                float m = -INFINITY, l = 0.0f;
                 f32x16 o[TD];
-#pragma unroll
-                for (int td = 0; td < TD; ++td)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[td][r] = 0.0f;
-                for (int kt = 0; kt < nkt; ++kt) {
-                    f32x16 s;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-#pragma unroll
-                    for (int st = 0; st < QSTEPS; ++st) {
-                        const u32x4 kf = *(const u32x4*)(Ks + (size_t)(kt * 32 + l31) * KS + st * 32 + hi * 16);
-                        mma_step<DT>(s, kf, qf[st]);
-                    }
-                    if (kt == nkt - 1 && NP != N) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            s[r] = key < N ? s[r] : -INFINITY;
-                        }
-                    }
-                    float tmax = s[0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-                    const float m_new = fmaxf(m, tmax);
-                    const float mc = m_new * p.scale_l2e;
-                    float psum = 0.0f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.scale_l2e, -mc));
-                        s[r] = pv;
-                        psum += pv;
-                    }
-                    if (!__all(m_new == m)) {
-                        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * p.scale_l2e);
-                        l *= alpha;
-#pragma unroll
-                        for (int td = 0; td < TD; ++td)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
-                        m = m_new;
-                    }
-                    l += psum;
-#pragma unroll
-                    for (int st = 0; st < PSTEPS; ++st) {
-                        const u32x4 pf = pack_p16<DT>(s, st);
-#pragma unroll
-                        for (int td = 0; td < TD; ++td) {
-                            int drow = td * 32 + l31;
-                            drow = drow < DKP ? drow : DKP - 1;
-                            const u32x4 vf = *(const u32x4*)(Vt + (size_t)drow * VS + (size_t)(kt * 32 + st * KSTEP + hi * VEC) * EB);
-                            mma_step<DT>(o[td], vf, pf);
-                        }
-                    }
-                }
-                l += __shfl_xor(l, 32);
+                float l;
+                AC::template run<KS>(Ks, Vt, VS, Vt + (size_t)DKP * VS, qf, nkt, N, p.scale_l2e, o, l);
                 const float inv = qok ? 1.0f / l : 0.0f;
                 unsigned char* orow = T0 + (size_t)(qt * 32 + l31) * SA + (size_t)h * DK * EB;
 #pragma unroll
@@ -729,7 +673,8 @@ static size_t attn_mlp_lds(int C, int N, int dkp, int eb) {      // (eb = 4: alw
     const int NP = (N + 31) & ~31;
     const size_t tile = (size_t)TMROWS * (C * eb + 16), hb = (size_t)TMROWS * (128 * eb + 16);
     const size_t ks = dkp * eb == 32 ? 32 : dkp * eb + 16;
-    const size_t kv2 = 2 * ((size_t)NP * ks + (size_t)dkp * (NP * eb + 16));
+    const bool ones = eb == 2 && dkp % 32 == 16;                            // AttnCore<>::ones_row(): one all-ones V^T row per head
+    const size_t kv2 = 2 * ((size_t)NP * ks + (size_t)(dkp + (ones ? 1 : 0)) * (NP * eb + 16));
     const bool dma = eb == 2 && slice_bytes(C) == 128 && C > 128;         // = attn_mlp_dma<>() of the instantiation dispatch_np2 picks
     const size_t ring = dma ? (size_t)DMFF_NSD * 128 * 128 : (eb == 4 || slice_bytes(C) == 128) ? Ring<128>::BYTES : Ring<64>::BYTES;
     const size_t chain = hb + ring + 2 * 64 * sizeof(float);

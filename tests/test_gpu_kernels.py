@@ -1018,6 +1018,30 @@ def test_cross_attention_softmax_spike():
     close(out[0].cpu(), ref, torch.float32, "spiked softmax")
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C", [128, 256, 384, 512])
+def test_cross_attention_late_spikes_in_16_bit(C, dt):
+    """The 16-bit attention loop (attn_core.h) defers the running maximum until a tile exceeds it by 2^6 in the exponent domain, takes the
+    softmax denominator out of the matrix pipe (d_k = 16 / 48: a ones row of V^T; d_k = 32: an extra MFMA) and rescales O — and with it
+    the denominator — on the cold path.  Keys that dominate LATE in the key order, by less and by much more than the deferral slack,
+    in the last (partly padded) key tile as well, exercise every one of those paths (d_k = 16, 32, 48, 64)."""
+    B, N, heads = 2, 300, 8
+    dk = C // heads
+    qkv = rnd((2, B * N, 3 * C), 47, 0.4)
+    qkv[:, :, :C] = qkv[:, :, :C].abs() + 0.3                     # positive queries: a large positive key raises every score of its column
+    for key, amp in ((40, 1.2), (131, 3.0), (222, 7.0), (297, 12.0)):   # growing spikes: below the slack, around it, far above it
+        qkv[0, key, C:2 * C] = amp
+        qkv[1, N + key, C:2 * C] = amp * 0.9
+    qg = qkv.to(DEV).to(dt).contiguous()
+    out = torch.zeros((2, B * N, C), dtype=dt, device=DEV)
+    run(ops.cross_attention(qg, out, B, N, heads))
+    f = q(qkv, dt).reshape(2, B, N, 3, heads, dk)
+    for d in range(2):
+        qq, kk, vv = (f[1 - d, :, :, 0].permute(0, 2, 1, 3), f[d, :, :, 1].permute(0, 2, 1, 3), f[d, :, :, 2].permute(0, 2, 1, 3))
+        ref = (torch.softmax(qq @ kk.transpose(-1, -2) / math.sqrt(dk), -1) @ vv).permute(0, 2, 1, 3).reshape(B * N, C)
+        close(out[d].float().cpu(), ref, dt, f"late spikes dir {d} C={C}", factor=2)
+
+
 @pytest.mark.parametrize("path", ["pixel", "element"])
 @pytest.mark.parametrize("nc", [1, 3, 9])
 def test_detect_decode(nc, path, monkeypatch):

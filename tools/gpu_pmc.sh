@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $RAW/pmc_$c
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $RAW/pmc_$c -o pmc -- \
-      python $R/bench.py --no-cpu-baseline --no-latency --no-graph --no-overlap --depth 1 --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.err
+      python $R/bench.py --no-cpu-baseline --no-latency --no-h2d --no-graph --no-overlap --depth 1 --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.err
   tail -2 $R/gpurun_out/pmc_$c.err
 done
 cd $R

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 RAW=/tmp/icaf_raw; mkdir -p $RAW
 rm -rf $RAW/pmc_sq
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $RAW/pmc_sq -o pmc -- \
-    python $R/bench.py --no-cpu-baseline --no-latency --no-graph --no-overlap --depth 1 --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_sq.json 2> $R/gpurun_out/pmc_sq.err
+    python $R/bench.py --no-cpu-baseline --no-latency --no-h2d --no-graph --no-overlap --depth 1 --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_sq.json 2> $R/gpurun_out/pmc_sq.err
 tail -2 $R/gpurun_out/pmc_sq.err
 cd $R && python - <<'PY'
 import csv, glob, collections, json, sys
@@ -29,3 +29,37 @@ for k, c in acc.items():
 json.dump({"method": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY; mfma_util = MFMA_BUSY / (SQ_BUSY / 32 * 1024)", "kernels": out}, open("gpurun_out/pmc_sq_summary.json", "w"), indent=1, sort_keys=True)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_util"]): print(f"{k:42s} {v}")
 PY
+# Second pass (SQ_INSTS=1): instruction mix per kernel — what bounds the MFMA-busy fraction from above.  With VALU arithmetic and MFMAs
+# of one SIMD perfectly overlapped, the pipe can be busy at most MFMA_cycles / max(MFMA_cycles, VALU_issue_cycles) of the time:
+#   mfma_cycles_per_simd = MFMA_BUSY / 1024;  valu_issue_cycles_per_simd = 4 * SQ_ACTIVE_INST_VALU / 1024  (quad-cycles -> cycles)
+if [ "${SQ_INSTS:-0}" = "1" ]; then
+cd /tmp
+rm -rf $RAW/pmc_sq2
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $RAW/pmc_sq2 -o pmc -- \
+    python $R/bench.py --no-cpu-baseline --no-latency --no-h2d --no-graph --no-overlap --depth 1 --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_sq2.json 2> $R/gpurun_out/pmc_sq2.err
+tail -2 $R/gpurun_out/pmc_sq2.err
+cd $R && python - <<'PY'
+import csv, glob, collections, json, sys
+sys.path.insert(0, "tools")
+from pmc_summary import short
+f = glob.glob("/tmp/icaf_raw/pmc_sq2/**/*counter_collection.csv", recursive=True)[0]
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for r in csv.DictReader(open(f)):
+    k = short(r["Kernel_Name"]); acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Counter_Name"] == "SQ_BUSY_CYCLES": n[k] += 1
+out = {}
+for k, c in acc.items():
+    if k.startswith("at::") or k.startswith("__") or "rocprim" in k or not c["SQ_BUSY_CYCLES"]: continue
+    simd_cycles = c["SQ_BUSY_CYCLES"] / 32 * 1024
+    mf, va = c["SQ_VALU_MFMA_BUSY_CYCLES"], 4.0 * c["SQ_ACTIVE_INST_VALU"]
+    out[k] = {"dispatches": n[k], "insts_valu": c["SQ_INSTS_VALU"] / n[k], "insts_mfma": c["SQ_INSTS_MFMA"] / n[k], "insts_trans_f32": c["SQ_INSTS_VALU_TRANS_F32"] / n[k],
+              "insts_lds": c["SQ_INSTS_LDS"] / n[k], "insts_salu": c["SQ_INSTS_SALU"] / n[k],
+              "valu_per_mfma": round(c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"], 2) if c["SQ_INSTS_MFMA"] else None,
+              "mfma_util": round(mf / simd_cycles, 4), "valu_issue_frac": round(va / simd_cycles, 4),
+              "mfma_util_ceiling_if_valu_fully_overlapped": round(mf / max(mf, va), 4) if mf else 0.0}
+json.dump({"method": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES; "
+                     "per dispatch means; valu_issue_frac = 4 * ACTIVE_INST_VALU / (SQ_BUSY / 32 * 1024); ceiling = MFMA_BUSY / max(MFMA_BUSY, 4 * ACTIVE_INST_VALU)", "kernels": out},
+          open("gpurun_out/pmc_sq_insts.json", "w"), indent=1, sort_keys=True)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_util"]): print(f"{k:42s} valu/mfma {v['valu_per_mfma']} mfma {v['mfma_util']} valu_issue {v['valu_issue_frac']} ceiling {v['mfma_util_ceiling_if_valu_fully_overlapped']}")
+PY
+fi

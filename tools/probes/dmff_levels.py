@@ -10,12 +10,13 @@ from icafusion_amd.models.common import CrossTransformerBlock
 from icafusion_amd.synth import synth_tensor
 
 ops.load_tune_cache(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "tune_cache.json"))
-for C, N, B in ((128, 400, 32), (256, 256, 32), (512, 100, 32)):
+LEVELS = {"s": ((128, 400, 32), (256, 256, 32), (512, 100, 32)), "l": ((256, 400, 32), (512, 256, 32), (1024, 100, 32))}
+for C, N, B in LEVELS[sys.argv[1] if len(sys.argv) > 1 else "s"]:
     blk = CrossTransformerBlock(C, C, C, 8, 4, 0.1, 0.1).eval()
     blk.load_state_dict({k: synth_tensor("b." + k, v.shape, seed=1) for k, v in blk.state_dict().items()})
     blk = blk.to("cuda:0")
     for mode, (fb, mc, wide) in (("per-layer", (False, 128, False)), ("two", (True, 512, False)), ("three", (True, 128, True))):
-        if mode == "three" and C < 256:
+        if (mode == "three" and not ops.dmff_wide_ok(C, 4 * C, torch.bfloat16)) or (mode == "two" and C > 512):
             continue
         blk.fuse_block, blk.fuse_max_c, blk.fuse_wide = fb, mc, wide
         blk.invalidate()
