@@ -92,6 +92,8 @@ SIGNATURES = {
     "icaf_dmff_attn_mlp": (_i, [C.POINTER(DmffArgs), _p]),
     "icaf_dmff_wide_ln_qkv": (_i, [C.POINTER(DmffArgs), _p]),
     "icaf_dmff_wide_proj_mlp": (_i, [C.POINTER(DmffArgs), _p, _p]),
+    "icaf_dmff_wide_proj_mlp_split": (_i, [C.POINTER(DmffArgs), _p, _p, _i, _p]),
+    "icaf_dmff_wide_reduce": (_i, [C.POINTER(DmffArgs), _p, _i, _p]),
     "icaf_dmff_attn_mlp_lds_bytes": (_i, [_i, _i, _i, _i, C.POINTER(_sz)]),
     "icaf_dmff_upsample_merge": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_detect_decode": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _ll, _ll, _f, C.POINTER(_f), _p]),

@@ -20,6 +20,15 @@
 //   * LDS traffic per 32 KB of weights: 64 KB of token-fragment reads (8 waves x 8 b128 reads), against 128 + 32 KB before.
 // Rounding points are those of the per-layer launches (activations rounded to the storage type between layers, fp32 accumulate,
 // two-pass LayerNorm statistics on the rounded values); only fp32 summation orders differ.
+//
+// Round 4 — hidden split (icaf_dmff_wide_proj_mlp_split): at P5 of yolov5s (C = 512, 100 tokens x 32 images) there are only 100 tiles
+// of 64 rows for 256 CUs, and every workgroup streams all 4.7 MB of its modality's weights, which do not stay in a 4 MB L2: PMC showed
+// 106 MB fetched per launch for 56.6 MB of distinct bytes and 53 GB/s per CU, the latency of the fabric.  With KS = 2 / 4 a tile is
+// shared by KS workgroups, each owning 1/KS of the hidden columns (its slices of W1 and W2 — the XCDs of a modality are dealt over
+// the hidden slices, so an XCD's L2 holds W_o + ONE slice: 2.6 MB at KS = 2); every one repeats the cheap front (out-projection +
+// LayerNorm: 1/9 of the FLOPs), writes its fc2 partial sums in fp32, and a second, tiny launch (dmff_wide_reduce_kernel) adds the
+// partials in FIXED order (deterministic, no atomics, no in-kernel fences: the agent-scope release / acquire of round 3's one-launch
+// attempt emptied the L2 of the very weights being streamed) and applies bias + coefficient mix.
 #include "icaf_common.h"
 #include "conv_common.h"
 
@@ -28,6 +37,7 @@ namespace icaf {
 struct WideP {
     const void* x;            // tokens [2][rows][C]: LN + QKV input / residual of the attention mix
     const void* att;          // proj_mlp: attention output [2][rows][C]
+    float* part;              // hidden split: fc2 partial sums [KS][2][rows][C] fp32
     void* qkv;                // ln_qkv: [2][rows][3C]
     void* y;                  // proj_mlp: element (g, row, c) at y + g * y_gs + row * ldy + c
     const void* wqkv; const float* bqkv;      // FRAGMENT-MAJOR weights [2][Np/32][Kp/16][64][8]; biases fp32 [2][Np]
@@ -126,6 +136,14 @@ __device__ __forceinline__ void wide_tile_layernorm(unsigned char* tile, int S, 
 // workgroup id -> (modality, index): XCDs 0-3 take modality 0, XCDs 4-7 modality 1 (hardware deals consecutive ids round-robin
 // over the 8 XCDs), so an XCD's L2 holds ONE modality's weights — at C = 512 that is 4.7 of the 9.4 MB of a block
 __device__ __forceinline__ void wide_place(int bid, int& g, int& idx) { g = (bid & 7) >> 2; idx = (bid >> 3) * 4 + (bid & 3); }
+// ... and with the hidden columns split KS ways, the 4 XCDs of a modality are dealt over the hidden slices: an XCD's L2 holds W_o and
+// ONE slice of W1 / W2
+template <int KS> __device__ __forceinline__ void wide_place_ks(int bid, int& g, int& ks, int& idx) {
+    const int x = bid & 7, per = 4 / KS;            // XCDs per (modality, slice)
+    g = x >> 2;
+    ks = (x & 3) / per;
+    idx = (bid >> 3) * per + (x & 3) % per;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm + QKV projection: a workgroup = 64 token rows x 768 output channels (three passes) of one modality.
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(WT) void dmff_wide_ln_qkv_kernel(const WideP p) {
 // ---------------------------------------------------------------------------------------------------------------
 // out-projection + LayerNorm + MLP: a workgroup = 64 token rows of one modality.  grid = 8 * ceil(tiles / 4)
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT, int NPW>          // NPW = C / 256 passes per C-wide product
+template <int DT, int NPW, int KS = 1>          // NPW = C / 256 passes per C-wide product; KS = workgroups sharing a tile (hidden split)
 __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
     using E = Elem<DT>;
     using T = typename E::type;
@@ -221,11 +239,12 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntiles = (int)((p.rows + WROWS - 1) / WROWS);
-    int g, tile_i;
-    wide_place(blockIdx.x, g, tile_i);
+    int g, tile_i, ksl = 0;
+    if constexpr (KS == 1) wide_place(blockIdx.x, g, tile_i);
+    else wide_place_ks<KS>(blockIdx.x, g, ksl, tile_i);
     if (tile_i >= ntiles) return;
     const long long r0 = (long long)tile_i * WROWS;
-    const int ks_row = p.Kp / 16, ks_row4 = p.Kp4 / 16, nsl = C / (16 * WSL), nchunk = p.hid / WPASS;
+    const int ks_row = p.Kp / 16, ks_row4 = p.Kp4 / 16, nsl = C / (16 * WSL), nchunk = p.hid / WPASS / KS, chunk0 = ksl * nchunk;
     constexpr int NSL2 = WPASS / (16 * WSL);                       // slices of an fc2 pass over one hidden chunk (4)
 
     // the wave's stream: NPW out-projection passes, then per hidden chunk one fc1 pass and NPW fc2 passes
@@ -237,8 +256,8 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
         if (s < NPW) { c.base = wof + (long long)(s * 8 + wn) * ks_row * 64; c.left = nsl; return; }
         const int m = s - NPW, chunk = m / (1 + NPW), r = m - chunk * (1 + NPW);
         if (chunk >= nchunk) { c.left = 0; return; }
-        if (r == 0) { c.base = w1f + (long long)(chunk * 8 + wn) * ks_row * 64; c.left = nsl; }
-        else { c.base = w2f + ((long long)((r - 1) * 8 + wn) * ks_row4 + chunk * (WPASS / 16)) * 64; c.left = NSL2; }
+        if (r == 0) { c.base = w1f + (long long)((chunk0 + chunk) * 8 + wn) * ks_row * 64; c.left = nsl; }
+        else { c.base = w2f + ((long long)((r - 1) * 8 + wn) * ks_row4 + (chunk0 + chunk) * (WPASS / 16)) * 64; c.left = NSL2; }
     };
     WCursor cur; cur.seg = 0; next(cur);
     u32x4 wq[WDEPTH][WSL];
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
             *(u32x4*)(T0 + (size_t)row * SA + v * 16) = *(const u32x4*)(att + r * C + v * VEC);
         }
         const float* b1 = p.b1 + g * p.b1_gs;
-        for (int i = tid; i < p.hid; i += WT) b1s[i] = b1[i];
+        for (int i = tid; i < p.hid / KS; i += WT) b1s[i] = b1[chunk0 * WPASS + i];
     }
     lds_barrier();
 
@@ -272,7 +291,7 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
     }
 
     // ---- out-projection + coefficient mix: x_att = c_res * x + c_acc * (att W_o^T + b), rounded to the storage type, in registers ----
-    constexpr bool PARK = NPW >= 2;
+    constexpr bool PARK = NPW >= 2 || KS > 1;          // (hidden split: the reduce launch reads x_att from the output rows)
     typename Quad<DT>::type xatt[NPW][2][4];
     {
         const float* bias = p.bo + g * p.bo_gs;
@@ -369,7 +388,7 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
                     *(typename Quad<DT>::type*)(T0 + (size_t)(t * 32 + l31) * SA + n * EB) = pack4<DT>(o[0], o[1], o[2], o[3]);
                     // C = 512: x_att is needed once more, as the residual of the final mix — parked in the workgroup's own rows of the
                     // output tensor (read back by the same lane) instead of holding 32 more registers through the MLP (spills otherwise)
-                    if constexpr (PARK) { if (rok[t]) *(typename Quad<DT>::type*)(yrow[t] + n) = xatt[i][t][q]; }
+                    if constexpr (PARK) { if (rok[t] && ksl == 0) *(typename Quad<DT>::type*)(yrow[t] + n) = xatt[i][t][q]; }
                 }
             }
         lds_barrier();
@@ -405,7 +424,19 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
         for (int i = 0; i < NPW; ++i) wpass<DT>(acc2[i], Hb, SH, NSL2, wq, cur, next);
     }
     // ---- output: x' = c_res2 * x_att + c_acc2 * (mlp + b2) ----
-    {
+    if constexpr (KS > 1) {                            // hidden split: this workgroup's share of the fc2 sums, fp32; dmff_wide_reduce_kernel finishes
+        float* part = p.part + ((long long)(ksl * 2 + g) * p.rows) * C;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = i * WPASS + wn * 32 + 8 * q + 4 * hi;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (rok[t])
+                        *(f32x4*)(part + (r0 + t * 32 + l31) * C + n) = f32x4{acc2[i][t][4 * q], acc2[i][t][4 * q + 1], acc2[i][t][4 * q + 2], acc2[i][t][4 * q + 3]};
+            }
+    } else {
         const float* b2 = p.b2 + g * p.b2_gs;
         const float ca = p.c_acc_m[g], cr = p.c_res_m[g];
 #pragma unroll
@@ -427,6 +458,36 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
     }
 }
 
+// y = c_res2 * x_att + c_acc2 * (sum_ks part[ks] + b2): x_att was parked in y by the ks = 0 workgroups; the partial sums are added in
+// slice order (a fixed association: the result does not depend on which workgroup finished first).  One thread = 4 channels of one row.
+template <int DT, int KS>
+__global__ __launch_bounds__(256) void dmff_wide_reduce_kernel(const WideP p) {
+    using T = typename Elem<DT>::type;
+    const int C = p.C, nq = C >> 2;
+    const long long total = 2 * p.rows * nq;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int qn = (int)(idx % nq);
+        const long long gr = idx / nq;
+        const int g = (int)(gr / p.rows);
+        const long long row = gr - (long long)g * p.rows;
+        const int n = qn * 4;
+        f32x4 sum = *(const f32x4*)(p.part + ((long long)g * p.rows + row) * C + n);
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
+            const f32x4 v = *(const f32x4*)(p.part + ((long long)(k * 2 + g) * p.rows + row) * C + n);
+            sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+        }
+        const f32x4 bv = *(const f32x4*)(p.b2 + g * p.b2_gs + n);
+        T* y = (T*)p.y + g * p.y_gs + row * p.ldy + n;
+        float rv[4], v[4];
+        unpack4<DT>(*(const typename Quad<DT>::type*)y, rv);
+        const float ca = p.c_acc_m[g], cr = p.c_res_m[g];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (sum[j] + bv[j]) * ca);
+        *(typename Quad<DT>::type*)y = pack4<DT>(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -436,7 +497,7 @@ static int wide_fill(const icaf_dmff_args* a, WideP& p, const char* who) {
     if (a->B < 1 || a->N < 1) return fail(ICAF_ERR_ARG, "%s: bad B/N", who);
     if (a->C != 256 && a->C != 512) return fail(ICAF_ERR_UNSUPPORTED, "%s: C=%d (built for 256 and 512: 256-channel passes, K slices in fours)", who, a->C);
     if (a->Kp < a->C || a->Kp % 64) return fail(ICAF_ERR_ARG, "%s: Kp=%d", who, a->Kp);
-    p.x = a->x; p.qkv = a->qkv; p.y = a->y; p.att = nullptr;
+    p.x = a->x; p.qkv = a->qkv; p.y = a->y; p.att = nullptr; p.part = nullptr;
     p.wqkv = a->wqkv; p.bqkv = a->bqkv; p.wo = a->wo; p.bo = a->bo; p.w1 = a->w1; p.b1 = a->b1; p.w2 = a->w2; p.b2 = a->b2;
     p.ln_a_g[0] = a->ln_attn_gamma[0]; p.ln_a_g[1] = a->ln_attn_gamma[1]; p.ln_a_b[0] = a->ln_attn_beta[0]; p.ln_a_b[1] = a->ln_attn_beta[1];
     p.ln_m_g = a->ln_mlp_gamma; p.ln_m_b = a->ln_mlp_beta;
@@ -475,6 +536,33 @@ static int launch_wide_proj_mlp(const WideP& p, hipStream_t s) {
     return ICAF_OK;
 }
 
+template <int DT, int NPW, int KS>
+static int launch_wide_proj_mlp_split(const WideP& p, hipStream_t s) {
+    const size_t lds = wide_proj_mlp_lds(p.C, p.hid / KS);
+    ICAF_LDS_OPTIN((dmff_wide_proj_mlp_kernel<DT, NPW, KS>), lds);
+    const long long ntiles = (p.rows + WROWS - 1) / WROWS, per = 4 / KS;
+    hipLaunchKernelGGL((dmff_wide_proj_mlp_kernel<DT, NPW, KS>), dim3((unsigned)(8 * ((ntiles + per - 1) / per))), dim3(WT), lds, s, p);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+template <int DT>
+static int dispatch_wide_split(const WideP& p, int ksplit, hipStream_t s) {
+    if (p.C == 256) return ksplit == 2 ? launch_wide_proj_mlp_split<DT, 1, 2>(p, s) : launch_wide_proj_mlp_split<DT, 1, 4>(p, s);
+    return ksplit == 2 ? launch_wide_proj_mlp_split<DT, 2, 2>(p, s) : launch_wide_proj_mlp_split<DT, 2, 4>(p, s);
+}
+
+template <int DT>
+static int launch_wide_reduce(const WideP& p, int ksplit, hipStream_t s) {
+    const long long items = 2 * p.rows * (p.C / 4);
+    long long blocks = (items + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (ksplit == 2) hipLaunchKernelGGL((dmff_wide_reduce_kernel<DT, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((dmff_wide_reduce_kernel<DT, 4>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
 }  // namespace icaf
 
 using namespace icaf;
@@ -498,4 +586,28 @@ extern "C" int icaf_dmff_wide_proj_mlp(const icaf_dmff_args* a, const void* att,
     p.att = att;
     if (a->dtype == ICAF_BF16) return a->C == 256 ? launch_wide_proj_mlp<ICAF_BF16, 1>(p, S(s)) : launch_wide_proj_mlp<ICAF_BF16, 2>(p, S(s));
     return a->C == 256 ? launch_wide_proj_mlp<ICAF_F16, 1>(p, S(s)) : launch_wide_proj_mlp<ICAF_F16, 2>(p, S(s));
+}
+
+extern "C" int icaf_dmff_wide_proj_mlp_split(const icaf_dmff_args* a, const void* att, float* partial, int ksplit, icaf_stream_t s) {
+    WideP p;
+    int st = wide_fill(a, p, "icaf_dmff_wide_proj_mlp_split");
+    if (st) return st;
+    if (!att || !partial || !a->y || !a->wo || !a->bo || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ln_mlp_gamma || !a->ln_mlp_beta) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp_split: null pointer");
+    if (ksplit != 2 && ksplit != 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp_split: ksplit %d (2 or 4)", ksplit);
+    if (a->hidden % (WPASS * ksplit) || a->Kp4 < a->hidden || a->Kp4 % 64) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp_split: hidden width %d must be a multiple of %d", a->hidden, WPASS * ksplit);
+    if (a->ldy < a->C || a->ldy % 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp_split: ldy=%d", a->ldy);
+    p.att = att;
+    p.part = partial;
+    return a->dtype == ICAF_BF16 ? dispatch_wide_split<ICAF_BF16>(p, ksplit, S(s)) : dispatch_wide_split<ICAF_F16>(p, ksplit, S(s));
+}
+
+extern "C" int icaf_dmff_wide_reduce(const icaf_dmff_args* a, const float* partial, int ksplit, icaf_stream_t s) {
+    WideP p;
+    int st = wide_fill(a, p, "icaf_dmff_wide_reduce");
+    if (st) return st;
+    if (!partial || !a->y || !a->b2) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_reduce: null pointer");
+    if (ksplit != 2 && ksplit != 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_reduce: ksplit %d (2 or 4)", ksplit);
+    if (a->ldy < a->C || a->ldy % 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_reduce: ldy=%d", a->ldy);
+    p.part = const_cast<float*>(partial);
+    return a->dtype == ICAF_BF16 ? launch_wide_reduce<ICAF_BF16>(p, ksplit, S(s)) : launch_wide_reduce<ICAF_F16>(p, ksplit, S(s));
 }

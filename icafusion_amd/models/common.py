@@ -777,11 +777,16 @@ class CrossTransformerBlock(HipModule):
             coef = dict(co=co, hidden=hid)
             qkv = plan.tokens(2, rows, 3 * C)
             att = plan.tokens(2, rows, C)
+            cus = ops.device_info()["cu_count"] if plan.device.type == "cuda" else 256
+            ks = ops.dmff_wide_ksplit(rows, C, hid, cus)           # few tiles, weights beyond an XCD's L2: hidden columns split over ks workgroups
+            part = plan.empty((ks, 2, rows, C), torch.float32) if ks > 1 else None
             for it in range(nloops):
                 plan.add(ops.dmff_wide_ln_qkv(tok, qkv, p, ln, coef, p["eps"], B, N, self.crossatt.h))
                 plan.add(ops.cross_attention(qkv, att, B, N, self.crossatt.h))
                 nxt = final_out if (final_out is not None and it == nloops - 1) else plan.tokens(2, rows, C)
-                plan.add(ops.dmff_wide_proj_mlp(tok, att, nxt, p, ln, coef, p["eps"], B, N, self.crossatt.h))
+                ls = ops.dmff_wide_proj_mlp(tok, att, nxt, p, ln, coef, p["eps"], B, N, self.crossatt.h, partial=part, ksplit=ks)
+                for l in (ls if isinstance(ls, list) else [ls]):
+                    plan.add(l)
                 tok = nxt
             return tok
         for it in range(nloops):

@@ -641,8 +641,28 @@ def dmff_wide_ln_qkv(x, qkv, packs, ln, coef, eps, B, N, heads, name="dmff_ln_qk
                   nbytes=2 * (rows * Cc * es + 3 * Cc * Cc * es + rows * 3 * Cc * es))
 
 
-def dmff_wide_proj_mlp(x, att, y, packs, ln, coef, eps, B, N, heads, name="dmff_proj_mlp"):
-    """Out-projection + LayerNorm + MLP of one block iteration as one launch behind cross_attention (icaf_dmff_wide_proj_mlp)."""
+DMFF_KSPLIT = int(os.environ.get("ICAF_DMFF_KSPLIT", "0"))       # A/B switch: 0 = automatic, 1 = never split the hidden columns, 2 / 4 = force
+
+
+def dmff_wide_ksplit(rows, C_, hidden, cu_count=256):
+    """Hidden-column split of icaf_dmff_wide_proj_mlp_split for this level: 1 (one workgroup per 64-row tile) unless the tiles of both
+    modalities leave at least half of the CUs idle AND a modality's weights (9 C^2 16-bit elements) overflow an XCD's 4 MB L2 — P5 of
+    yolov5s at batch 32: 100 tiles for 256 CUs, 4.7 MB per modality."""
+    if DMFF_KSPLIT:
+        return DMFF_KSPLIT if hidden % (256 * DMFF_KSPLIT) == 0 else 1
+    wgs = 2 * (-(-rows // 64))
+    if 9 * C_ * C_ * 2 <= 3 * 2 ** 20:
+        return 1
+    for ks in (4, 2):
+        if wgs * ks <= cu_count and hidden % (256 * ks) == 0:
+            return ks
+    return 1
+
+
+def dmff_wide_proj_mlp(x, att, y, packs, ln, coef, eps, B, N, heads, name="dmff_proj_mlp", partial=None, ksplit=1):
+    """Out-projection + LayerNorm + MLP of one block iteration as one launch behind cross_attention (icaf_dmff_wide_proj_mlp); with
+    ksplit > 1 (partial: fp32 (ksplit, 2, rows, C) scratch) the hidden columns are split over ksplit workgroups per tile and a second
+    small launch reduces the partial sums: returns the LIST [icaf_dmff_wide_proj_mlp_split, icaf_dmff_wide_reduce]."""
     rows, Cc = x.shape[1], x.shape[2]
     assert att.shape == (2, rows, Cc) and att.is_contiguous() and att.dtype == x.dtype
     wp = _wide_packs(packs)
@@ -650,6 +670,15 @@ def dmff_wide_proj_mlp(x, att, y, packs, ln, coef, eps, B, N, heads, name="dmff_
     es, hid = x.element_size(), coef["hidden"]
     flops = 2.0 * 2 * rows * (Cc * Cc + 2 * Cc * hid)
     nbytes = 2 * (3 * rows * Cc * es + (Cc * Cc + 2 * Cc * hid) * es)
+    if ksplit > 1:
+        assert partial is not None and partial.dtype == torch.float32 and partial.is_contiguous() and partial.shape == (ksplit, 2, rows, Cc)
+        flops += 2.0 * 2 * rows * Cc * Cc * (ksplit - 1)                         # the repeated out-projection
+        nbytes += partial.numel() * 4
+        main = Launch(lib().icaf_dmff_wide_proj_mlp_split, (C.byref(a), att.data_ptr(), partial.data_ptr(), int(ksplit)),
+                      keep=(a, x, att, y, wp, packs, ln, partial), name=name, flops=flops, nbytes=nbytes)
+        red = Launch(lib().icaf_dmff_wide_reduce, (C.byref(a), partial.data_ptr(), int(ksplit)), keep=(a, y, partial, wp, packs),
+                     name=name + "_reduce", nbytes=partial.numel() * 4 + 2 * 2 * rows * Cc * es)
+        return [main, red]
     return Launch(lib().icaf_dmff_wide_proj_mlp, (C.byref(a), att.data_ptr()), keep=(a, x, att, y, wp, packs, ln), name=name, flops=flops, nbytes=nbytes)
 
 

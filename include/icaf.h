@@ -274,6 +274,14 @@ int icaf_dmff_attn_mlp(const icaf_dmff_args* a, icaf_stream_t s);
  * same *_gs strides): each wavefront streams its MFMA weight operands straight from L2 into registers.  hidden % 256 == 0. */
 int icaf_dmff_wide_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s);
 int icaf_dmff_wide_proj_mlp(const icaf_dmff_args* a, const void* att, icaf_stream_t s);
+/* The same step with the MLP's hidden columns split over `ksplit` (2 or 4) workgroups per 64-row tile — for levels with fewer tiles
+ * than CUs and more weight bytes than an XCD's L2 (P5: 100 tokens x 32 images at C = 512): every workgroup repeats out-projection +
+ * LayerNorm (:682-685, :745-750), runs Linear(C, 4C) -> GELU -> Linear(4C, C) (:704-709) over ITS hidden slice, parks x_att in y and
+ * writes fp32 partial sums into partial [ksplit][2][B*N][C].  icaf_dmff_wide_reduce (the next launch on the stream) adds them in slice
+ * order (deterministic: no atomics, no in-kernel fences) and applies bias + the coefficient mix (:751-752) in place on y.  Same operands
+ * and fragment-major weight layout as icaf_dmff_wide_proj_mlp; hidden % (256 * ksplit) == 0. */
+int icaf_dmff_wide_proj_mlp_split(const icaf_dmff_args* a, const void* att, float* partial, int ksplit, icaf_stream_t s);
+int icaf_dmff_wide_reduce(const icaf_dmff_args* a, const float* partial, int ksplit, icaf_stream_t s);
 int icaf_dmff_attn_mlp_lds_bytes(int C, int N, int heads, int dtype, size_t* bytes);
 
 /* ---- NMS (utils/general.py:518-607 + torchvision.ops.nms semantics) ----------------------------------------

@@ -82,7 +82,7 @@ def test_wide_block_three_launches_vs_oracle_and_per_layer_launches(shape, dtype
     ref = torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
     wide, names_w = run_block(blk, tok, B, N, dtype, True, max_c=128)
     plain, names_p = run_block(blk, tok, B, N, dtype, False)
-    assert names_w == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp"] * loops and len(names_p) == 7 * loops
+    assert [n for n in names_w if n != "dmff_proj_mlp_reduce"] == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp"] * loops and len(names_p) == 7 * loops
     scale = ref.abs().max().item()
     e_w, e_p = (wide - ref).abs().max().item() / scale, (plain - ref).abs().max().item() / scale
     m_w, m_p = (wide - ref).abs().mean().item() / scale, (plain - ref).abs().mean().item() / scale
@@ -91,6 +91,34 @@ def test_wide_block_three_launches_vs_oracle_and_per_layer_launches(shape, dtype
     assert e_w <= 1.5 * e_p + 1e-4 and m_w <= 1.25 * m_p + 1e-5
     ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     assert (wide - plain).abs().max().item() / scale <= 24 * ulp
+
+
+@pytest.mark.parametrize("ksplit", [1, 2, 4])
+@pytest.mark.parametrize("shape", [(512, 8, 100, 3, 1), (256, 8, 77, 2, 2), (512, 16, 130, 2, 2)])
+def test_wide_block_hidden_split_equals_unsplit(shape, ksplit, monkeypatch):
+    """icaf_dmff_wide_proj_mlp_split + icaf_dmff_wide_reduce: the MLP's hidden columns over 2 / 4 workgroups per tile, fp32 partial
+    sums added in slice order.  Against the fp32 oracle the error is the unsplit launch's; the two 16-bit results agree to rounding
+    (only the fp32 association of the fc2 sum differs); the result is bit-stable from run to run (no atomics, no arrival order)."""
+    from icafusion_amd import ops
+    C, heads, N, B, loops = shape
+    blk, sd = make_block(C, heads, loops, seed=C + N)
+    blk = blk.to(DEV)
+    g = np.random.default_rng(C * 1000 + N + 2)
+    tok = torch.from_numpy(g.normal(0.2, 0.8, (2, B * N, C)).astype(np.float32))
+    tq = tok.to(torch.bfloat16).float()
+    rv, ri = oracle.cross_transformer(tq[0].reshape(B, N, C), tq[1].reshape(B, N, C), sd, "b", heads, loops)
+    ref = torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
+    monkeypatch.setattr(ops, "DMFF_KSPLIT", 1)
+    base, _ = run_block(blk, tok, B, N, torch.bfloat16, True, max_c=128)
+    monkeypatch.setattr(ops, "DMFF_KSPLIT", ksplit)
+    got, names_k = run_block(blk, tok, B, N, torch.bfloat16, True, max_c=128)
+    again, _ = run_block(blk, tok, B, N, torch.bfloat16, True, max_c=128)
+    assert ("dmff_proj_mlp_reduce" in names_k) == (ksplit > 1)
+    assert torch.equal(got, again)
+    scale = ref.abs().max().item()
+    e_k, e_b = (got - ref).abs().max().item() / scale, (base - ref).abs().max().item() / scale
+    print(f"C={C} N={N} ksplit={ksplit}: max err {e_k:.3e} (unsplit {e_b:.3e}), vs unsplit {(got - base).abs().max().item() / scale:.3e}")
+    assert e_k <= 1.25 * e_b + 1e-4 and (got - base).abs().max().item() / scale <= 4 * 2.0 ** -8
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

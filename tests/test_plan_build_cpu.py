@@ -70,15 +70,21 @@ def _dmff_launches(n):
 
 
 @pytest.mark.parametrize("loops", [1, 3])
-def test_dmff_block_is_at_most_three_launches_per_iteration_at_every_level(loops):
+def test_dmff_block_launch_structure_at_every_level(loops):
     """16-bit yolov5s: P3 (C = 128) runs LN + QKV, attention + out-projection + LN + MLP (2 launches per iteration); P4 / P5
-    (C = 256 / 512) LN + QKV, attention, out-projection + LN + MLP (3) — VERDICT r2 #3.  fp32 keeps the seven per-layer launches."""
+    (C = 256 / 512) LN + QKV, attention, out-projection + LN + MLP (3) — VERDICT r2 #3; P5, whose few 64-row tiles leave most CUs idle
+    and whose weights overflow an XCD's L2, splits the MLP's hidden columns over several workgroups per tile and adds a small
+    reduce launch (VERDICT r3 #1c).  fp32 keeps the seven per-layer launches."""
     m = Model(load_cfg("yolov5s_Transfusion_kaist.yaml")).eval()
     for i in (20, 21, 22):
         m.model[i].crosstransformer[0].loops = loops
     blocks = _dmff_launches(names(m.build_plan(2, 320, 320, "cpu", torch.bfloat16)))
     assert blocks[0] == ["dmff_ln_qkv", "dmff_attn_mlp"] * loops
-    assert blocks[1] == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp"] * loops and blocks[2] == blocks[1]
+    assert blocks[1] == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp"] * loops
+    assert blocks[2] == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp", "dmff_proj_mlp_reduce"] * loops
+    from icafusion_amd import ops
+    assert ops.dmff_wide_ksplit(32 * 100, 512, 2048, 256) == 2 and ops.dmff_wide_ksplit(2 * 100, 512, 2048, 256) == 4      # P5: batch 32 / batch 2
+    assert ops.dmff_wide_ksplit(32 * 256, 256, 1024, 256) == 1 and ops.dmff_wide_ksplit(32 * 256, 512, 2048, 256) == 1     # P4 of yolov5s / yolov5l: one tile per CU
     from icafusion_amd.models.common import CrossTransformerBlock
     try:
         CrossTransformerBlock.fuse_wide = False                  # A/B switch: the wide levels fall back to the per-layer launches

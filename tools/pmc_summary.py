@@ -62,7 +62,8 @@ def short(name):
                 "upsample_kernel": "upsample_nearest", "stem_kernel": "stem", "bneck_kernel": "bottleneck",
                 "stem2_kernel": "stem+conv3x3s2+1x1", "pool_tokens_rows_kernel": "dmff_pool_tokens",
                 "dmff_attn_mlp_kernel": "dmff_attn_mlp", "dmff_ln_qkv_kernel": "dmff_ln_qkv", "layernorm_kernel": "layernorm",
-                "dmff_wide_ln_qkv_kernel": "dmff_ln_qkv", "dmff_wide_proj_mlp_kernel": "dmff_proj_mlp"}.get(m.group(1), m.group(1))
+                "dmff_wide_ln_qkv_kernel": "dmff_ln_qkv", "dmff_wide_proj_mlp_kernel": "dmff_proj_mlp",
+                "dmff_wide_reduce_kernel": "dmff_proj_mlp_reduce"}.get(m.group(1), m.group(1))
     return name[:80]
 
 
