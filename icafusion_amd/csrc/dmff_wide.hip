@@ -53,11 +53,22 @@ struct WideP {
     float c_res_a[2], c_acc_a[2], c_res_m[2], c_acc_m[2];
 };
 
-constexpr int WT = 512;              // threads per workgroup (8 wavefronts)
 constexpr int WROWS = 64;            // token rows per workgroup
-constexpr int WPASS = 256;           // output channels per pass (8 waves x 32)
-constexpr int WSL = 4;               // MFMA K steps per slice (64 K elements)
 constexpr int WDEPTH = 4;            // slices in flight per wave (register ring; every pass is a multiple of it)
+// Geometry of a build: NW wavefronts per workgroup, wave w owning output channels [32 w, 32 w + 32) of a pass of 32 NW channels, and
+// SL MFMA K steps (16 elements each) per slice of the weight stream.
+//   wide levels (C = 256 / 512):  NW = 8, SL = 4  -> 256-channel passes, 64-element slices
+//   C = 128 (P3 of yolov5s):      NW = 4, SL = 2  -> 128-channel passes, 32-element slices (a pass over K = 128 is again 4 slices)
+template <int NW_, int SL_> struct WG {
+    static constexpr int NW = NW_, SL = SL_;
+    static constexpr int WT = 64 * NW;           // threads per workgroup
+    static constexpr int WPASS = 32 * NW;        // output channels per pass
+    static constexpr int KSL = 16 * SL;          // K elements per slice
+    static constexpr int NSL2 = WPASS / KSL;     // slices of an fc2 pass over one hidden chunk
+    static constexpr int TPR = WT / WROWS;       // threads per row in the tile LayerNorm
+};
+using WG8 = WG<8, 4>;
+using WG4 = WG<4, 2>;
 
 // One wave's weight stream.  A SEGMENT is one pass's fragments for this wave's 32 channels: n slices of WSL consecutive K steps,
 // 64 lanes x 16 bytes each, contiguous in the fragment-major copy.  `next` yields the segment after the current one.
@@ -66,7 +77,7 @@ struct WCursor {
     int left, seg;
 };
 
-template <class NEXT>
+template <int WSL, class NEXT>
 __device__ __forceinline__ void wfetch(u32x4 (&w)[WSL], WCursor& c, const NEXT& next) {
     if (c.left == 0) return;                         // end of the kernel's stream (wave-uniform)
 #pragma unroll
@@ -76,7 +87,7 @@ __device__ __forceinline__ void wfetch(u32x4 (&w)[WSL], WCursor& c, const NEXT& 
 }
 
 // acc[t] += W[32 wn + i][k] * A[32 t + j][k] over the next n slices (n % WDEPTH == 0) of the wave's stream; A: LDS tile, row stride SA
-template <int DT, class NEXT>
+template <int DT, int WSL, class NEXT>
 __device__ __forceinline__ void wpass(f32x16 (&acc)[2], const unsigned char* A, int SA, int n, u32x4 (&wq)[WDEPTH][WSL], WCursor& c, const NEXT& next) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const unsigned char* a0 = A + (size_t)l31 * SA + hi * 16;
@@ -92,39 +103,41 @@ __device__ __forceinline__ void wpass(f32x16 (&acc)[2], const unsigned char* A, 
                 mma_step<DT>(acc[0], wq[u][k], x0);
                 mma_step<DT>(acc[1], wq[u][k], x1);
             }
-            wfetch(wq[u], c, next);
+            wfetch<WSL>(wq[u], c, next);
             __builtin_amdgcn_sched_barrier(0);             // (left alone the scheduler hoists the token-fragment reads of all four slices: 128 registers)
         }
     }
 }
 
-// LayerNorm of the 64 rows of an LDS tile in place: 8 threads per row, two-pass statistics in fp32 on the stored values
+// LayerNorm of the 64 rows of an LDS tile in place: TPR (8 or 4) threads per row, two-pass statistics in fp32 on the stored values
 // (the arithmetic of layernorm_kernel, dmff.hip).
-template <int DT>
+template <int DT, int TPR>
 __device__ __forceinline__ void wide_tile_layernorm(unsigned char* tile, int S, int C, const float* __restrict__ gam, const float* __restrict__ bet, float eps) {
     using E = Elem<DT>;
-    const int tid = threadIdx.x, row = tid >> 3, part = tid & 7;
+    const int tid = threadIdx.x, row = tid / TPR, part = tid % TPR;
     const int nv = C / E::VEC;
     unsigned char* r = tile + (size_t)row * S;
     float s = 0.0f;
-    for (int v = part; v < nv; v += 8) {
+    for (int v = part; v < nv; v += TPR) {
         float t[E::VEC];
         unpack16<DT>(*(const u32x4*)(r + v * 16), t);
 #pragma unroll
         for (int j = 0; j < E::VEC; ++j) s += t[j];
     }
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    if constexpr (TPR == 8) s += __shfl_xor(s, 4);
     const float mean = s / (float)C;
     float q = 0.0f;
-    for (int v = part; v < nv; v += 8) {
+    for (int v = part; v < nv; v += TPR) {
         float t[E::VEC];
         unpack16<DT>(*(const u32x4*)(r + v * 16), t);
 #pragma unroll
         for (int j = 0; j < E::VEC; ++j) { const float d = t[j] - mean; q += d * d; }
     }
-    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
+    if constexpr (TPR == 8) q += __shfl_xor(q, 4);
     const float rstd = 1.0f / sqrtf(q / (float)C + eps);
-    for (int v = part; v < nv; v += 8) {
+    for (int v = part; v < nv; v += TPR) {
         float t[E::VEC], o[E::VEC];
         unpack16<DT>(*(const u32x4*)(r + v * 16), t);
 #pragma unroll
@@ -146,11 +159,11 @@ template <int KS> __device__ __forceinline__ void wide_place_ks(int bid, int& g,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LayerNorm + QKV projection: a workgroup = 64 token rows x 768 output channels (three passes) of one modality.
-// grid = 8 * ceil(tiles * C / 256 / 4)
+// LayerNorm + QKV projection: a workgroup = 64 token rows x three passes (768 output channels with eight wavefronts, 384 with
+// four) of one modality.  grid = 8 * ceil(tiles * C / WPASS / 4)
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(WT) void dmff_wide_ln_qkv_kernel(const WideP p) {
+template <int DT, class G = WG8>
+__global__ __launch_bounds__(G::WT) void dmff_wide_ln_qkv_kernel(const WideP p) {
     using E = Elem<DT>;
     using T = typename E::type;
     constexpr int VEC = E::VEC, EB = E::BYTES;
@@ -159,30 +172,30 @@ __global__ __launch_bounds__(WT) void dmff_wide_ln_qkv_kernel(const WideP p) {
     unsigned char* tile = smem;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ngrp = C / WPASS;                                    // column groups of 768 channels
+    const int ngrp = C / G::WPASS;                                    // column groups of 768 channels
     const int ntiles = (int)((p.rows + WROWS - 1) / WROWS);
     int g, idx;
     wide_place(blockIdx.x, g, idx);
     if (idx >= ntiles * ngrp) return;
     const int tile_i = idx / ngrp, grp = idx - tile_i * ngrp;
     const long long r0 = (long long)tile_i * WROWS;
-    const int ks_row = p.Kp / 16, nsl = C / (16 * WSL);
+    const int ks_row = p.Kp / 16, nsl = C / G::KSL;
 
     const u32x4* wf = (const u32x4*)((const T*)p.wqkv + g * p.wqkv_gs) + lane;
     auto next = [&](WCursor& c) {
         if (c.seg >= 3) { c.left = 0; return; }
-        c.base = wf + (long long)((grp * 3 + c.seg) * 8 + wn) * ks_row * 64;
+        c.base = wf + (long long)((grp * 3 + c.seg) * G::NW + wn) * ks_row * 64;
         c.left = nsl;
     };
     WCursor cur; cur.seg = 0; next(cur);
-    u32x4 wq[WDEPTH][WSL];
+    u32x4 wq[WDEPTH][G::SL];
 #pragma unroll
-    for (int u = 0; u < WDEPTH; ++u) wfetch(wq[u], cur, next);      // the first weight slices travel while the tokens are normalised
+    for (int u = 0; u < WDEPTH; ++u) wfetch<G::SL>(wq[u], cur, next);      // the first weight slices travel while the tokens are normalised
 
     {
         const T* xg = (const T*)p.x + g * p.x_gs;
         const int nv = C / VEC;
-        for (int i = tid; i < WROWS * nv; i += WT) {               // raw tokens -> LDS (rows beyond the tensor: clamped, never stored)
+        for (int i = tid; i < WROWS * nv; i += G::WT) {               // raw tokens -> LDS (rows beyond the tensor: clamped, never stored)
             const int row = i / nv, v = i - row * nv;
             long long r = r0 + row;
             r = r < p.rows ? r : p.rows - 1;
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(WT) void dmff_wide_ln_qkv_kernel(const WideP p) {
         }
     }
     lds_barrier();
-    wide_tile_layernorm<DT>(tile, SA, C, p.ln_a_g[g], p.ln_a_b[g], p.eps_a);
+    wide_tile_layernorm<DT, G::TPR>(tile, SA, C, p.ln_a_g[g], p.ln_a_b[g], p.eps_a);
     lds_barrier();
 
     const float* bias = p.bqkv + g * p.bqkv_gs;
@@ -202,8 +215,8 @@ __global__ __launch_bounds__(WT) void dmff_wide_ln_qkv_kernel(const WideP p) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        wpass<DT>(acc, tile, SA, nsl, wq, cur, next);
-        const int nb = (grp * 3 + j) * WPASS + wn * 32;
+        wpass<DT, G::SL>(acc, tile, SA, nsl, wq, cur, next);
+        const int nb = (grp * 3 + j) * G::WPASS + wn * 32;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const long long row = r0 + t * 32 + l31;
@@ -223,18 +236,19 @@ __global__ __launch_bounds__(WT) void dmff_wide_ln_qkv_kernel(const WideP p) {
 // ---------------------------------------------------------------------------------------------------------------
 // out-projection + LayerNorm + MLP: a workgroup = 64 token rows of one modality.  grid = 8 * ceil(tiles / 4)
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT, int NPW, int KS = 1>          // NPW = C / 256 passes per C-wide product; KS = workgroups sharing a tile (hidden split)
-__global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
+template <int DT, int NPW, int KS = 1, class G = WG8>          // NPW = C / WPASS passes per C-wide product; KS = workgroups sharing a tile (hidden split)
+__global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
     using E = Elem<DT>;
     using T = typename E::type;
     constexpr int VEC = E::VEC, EB = E::BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int C = p.C, SA = C * EB + 16;
+    constexpr int WPASS = G::WPASS, WT = G::WT, NSL2 = G::NSL2;
     constexpr int SH = WPASS * EB + 16;
     unsigned char* T0 = smem;                                      // attention output -> later the LayerNorm'ed MLP input
     unsigned char* Hb = T0 + (size_t)WROWS * SA;                   // hidden chunk [64][256]
-    float* red = (float*)(Hb + (size_t)WROWS * SH);                // [8][64] row partial sums of the eight channel groups
-    float* b1s = red + 8 * 64;                                     // fc1 bias (hid floats)
+    float* red = (float*)(Hb + (size_t)WROWS * SH);                // [NW][64] row partial sums of the channel groups
+    float* b1s = red + G::NW * 64;                                     // fc1 bias (hid floats)
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,8 +258,7 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
     else wide_place_ks<KS>(blockIdx.x, g, ksl, tile_i);
     if (tile_i >= ntiles) return;
     const long long r0 = (long long)tile_i * WROWS;
-    const int ks_row = p.Kp / 16, ks_row4 = p.Kp4 / 16, nsl = C / (16 * WSL), nchunk = p.hid / WPASS / KS, chunk0 = ksl * nchunk;
-    constexpr int NSL2 = WPASS / (16 * WSL);                       // slices of an fc2 pass over one hidden chunk (4)
+    const int ks_row = p.Kp / 16, ks_row4 = p.Kp4 / 16, nsl = C / G::KSL, nchunk = p.hid / WPASS / KS, chunk0 = ksl * nchunk;
 
     // the wave's stream: NPW out-projection passes, then per hidden chunk one fc1 pass and NPW fc2 passes
     const u32x4* wof = (const u32x4*)((const T*)p.wo + g * p.wo_gs) + lane;
@@ -253,16 +266,16 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
     const u32x4* w2f = (const u32x4*)((const T*)p.w2 + g * p.w2_gs) + lane;
     auto next = [&](WCursor& c) {
         const int s = c.seg;
-        if (s < NPW) { c.base = wof + (long long)(s * 8 + wn) * ks_row * 64; c.left = nsl; return; }
+        if (s < NPW) { c.base = wof + (long long)(s * G::NW + wn) * ks_row * 64; c.left = nsl; return; }
         const int m = s - NPW, chunk = m / (1 + NPW), r = m - chunk * (1 + NPW);
         if (chunk >= nchunk) { c.left = 0; return; }
-        if (r == 0) { c.base = w1f + (long long)((chunk0 + chunk) * 8 + wn) * ks_row * 64; c.left = nsl; }
-        else { c.base = w2f + ((long long)((r - 1) * 8 + wn) * ks_row4 + (chunk0 + chunk) * (WPASS / 16)) * 64; c.left = NSL2; }
+        if (r == 0) { c.base = w1f + (long long)((chunk0 + chunk) * G::NW + wn) * ks_row * 64; c.left = nsl; }
+        else { c.base = w2f + ((long long)((r - 1) * G::NW + wn) * ks_row4 + (chunk0 + chunk) * (WPASS / 16)) * 64; c.left = NSL2; }
     };
     WCursor cur; cur.seg = 0; next(cur);
-    u32x4 wq[WDEPTH][WSL];
+    u32x4 wq[WDEPTH][G::SL];
 #pragma unroll
-    for (int u = 0; u < WDEPTH; ++u) wfetch(wq[u], cur, next);      // the first weight slices travel while the tile is loaded
+    for (int u = 0; u < WDEPTH; ++u) wfetch<G::SL>(wq[u], cur, next);      // the first weight slices travel while the tile is loaded
 
     {
         const T* att = (const T*)p.att + (long long)g * p.rows * C;
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-            wpass<DT>(acc, T0, SA, nsl, wq, cur, next);
+            wpass<DT, G::SL>(acc, T0, SA, nsl, wq, cur, next);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
         }
     }
     // ---- the block's shared LayerNorm over x_att, from registers: row sums = this lane's channels + the other lane half (shuffle) +
-    //      the other seven channel groups (LDS); the normalised tile overwrites T0 — every wave has passed a barrier after its last
+    //      the other channel groups (LDS); the normalised tile overwrites T0 — every wave has passed a barrier after its last
     //      out-projection read by then ----
     {
         float mean[2], rstd[2];
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
         for (int t = 0; t < 2; ++t) {
             float s = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) s += red[w * 64 + t * 32 + l31];
+            for (int w = 0; w < G::NW; ++w) s += red[w * 64 + t * 32 + l31];
             mean[t] = s / (float)C;
         }
         lds_barrier();
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
         for (int t = 0; t < 2; ++t) {
             float s = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) s += red[w * 64 + t * 32 + l31];
+            for (int w = 0; w < G::NW; ++w) s += red[w * 64 + t * 32 + l31];
             rstd[t] = 1.0f / sqrtf(s / (float)C + p.eps_m);
         }
 #pragma unroll
@@ -407,7 +420,7 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        wpass<DT>(acc, T0, SA, nsl, wq, cur, next);
+        wpass<DT, G::SL>(acc, T0, SA, nsl, wq, cur, next);
         lds_barrier();                                             // every wave is done with the previous chunk's H
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
             }
         lds_barrier();
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) wpass<DT>(acc2[i], Hb, SH, NSL2, wq, cur, next);
+        for (int i = 0; i < NPW; ++i) wpass<DT, G::SL>(acc2[i], Hb, SH, NSL2, wq, cur, next);
     }
     // ---- output: x' = c_res2 * x_att + c_acc2 * (mlp + b2) ----
     if constexpr (KS > 1) {                            // hidden split: this workgroup's share of the fc2 sums, fp32; dmff_wide_reduce_kernel finishes
@@ -495,7 +508,7 @@ static int wide_fill(const icaf_dmff_args* a, WideP& p, const char* who) {
     if (!a || !a->x) return fail(ICAF_ERR_ARG, "%s: null pointer", who);
     if (a->dtype != ICAF_BF16 && a->dtype != ICAF_F16) return fail(ICAF_ERR_UNSUPPORTED, "%s: 16-bit types only (dtype %d)", who, a->dtype);
     if (a->B < 1 || a->N < 1) return fail(ICAF_ERR_ARG, "%s: bad B/N", who);
-    if (a->C != 256 && a->C != 512) return fail(ICAF_ERR_UNSUPPORTED, "%s: C=%d (built for 256 and 512: 256-channel passes, K slices in fours)", who, a->C);
+    if (a->C != 128 && a->C != 256 && a->C != 512) return fail(ICAF_ERR_UNSUPPORTED, "%s: C=%d (built for 128 [four wavefronts, 128-channel passes] and 256 / 512 [eight, 256-channel passes])", who, a->C);
     if (a->Kp < a->C || a->Kp % 64) return fail(ICAF_ERR_ARG, "%s: Kp=%d", who, a->Kp);
     p.x = a->x; p.qkv = a->qkv; p.y = a->y; p.att = nullptr; p.part = nullptr;
     p.wqkv = a->wqkv; p.bqkv = a->bqkv; p.wo = a->wo; p.bo = a->bo; p.w1 = a->w1; p.b1 = a->b1; p.w2 = a->w2; p.b2 = a->b2;
@@ -512,36 +525,37 @@ static int wide_fill(const icaf_dmff_args* a, WideP& p, const char* who) {
     return ICAF_OK;
 }
 
-template <int DT>
+template <int DT, class G>
 static int launch_wide_ln_qkv(const WideP& p, hipStream_t s) {
     const size_t lds = (size_t)WROWS * (p.C * 2 + 16);
-    ICAF_LDS_OPTIN((dmff_wide_ln_qkv_kernel<DT>), lds);        // (size checked on EVERY call, attribute raised per device as needed)
-    const long long work = ((p.rows + WROWS - 1) / WROWS) * (p.C / WPASS);
-    hipLaunchKernelGGL((dmff_wide_ln_qkv_kernel<DT>), dim3((unsigned)(8 * ((work + 3) / 4))), dim3(WT), lds, s, p);
+    ICAF_LDS_OPTIN((dmff_wide_ln_qkv_kernel<DT, G>), lds);        // (size checked on EVERY call, attribute raised per device as needed)
+    const long long work = ((p.rows + WROWS - 1) / WROWS) * (p.C / G::WPASS);
+    hipLaunchKernelGGL((dmff_wide_ln_qkv_kernel<DT, G>), dim3((unsigned)(8 * ((work + 3) / 4))), dim3(G::WT), lds, s, p);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
 
+template <class G>
 static size_t wide_proj_mlp_lds(int C, int hid) {
-    return (size_t)WROWS * (C * 2 + 16) + (size_t)WROWS * (WPASS * 2 + 16) + 8 * 64 * sizeof(float) + (size_t)hid * sizeof(float);
+    return (size_t)WROWS * (C * 2 + 16) + (size_t)WROWS * (G::WPASS * 2 + 16) + G::NW * 64 * sizeof(float) + (size_t)hid * sizeof(float);
 }
 
-template <int DT, int NPW>
+template <int DT, int NPW, class G>
 static int launch_wide_proj_mlp(const WideP& p, hipStream_t s) {
-    const size_t lds = wide_proj_mlp_lds(p.C, p.hid);
-    ICAF_LDS_OPTIN((dmff_wide_proj_mlp_kernel<DT, NPW>), lds);
+    const size_t lds = wide_proj_mlp_lds<G>(p.C, p.hid);
+    ICAF_LDS_OPTIN((dmff_wide_proj_mlp_kernel<DT, NPW, 1, G>), lds);
     const long long ntiles = (p.rows + WROWS - 1) / WROWS;
-    hipLaunchKernelGGL((dmff_wide_proj_mlp_kernel<DT, NPW>), dim3((unsigned)(8 * ((ntiles + 3) / 4))), dim3(WT), lds, s, p);
+    hipLaunchKernelGGL((dmff_wide_proj_mlp_kernel<DT, NPW, 1, G>), dim3((unsigned)(8 * ((ntiles + 3) / 4))), dim3(G::WT), lds, s, p);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
 
 template <int DT, int NPW, int KS>
 static int launch_wide_proj_mlp_split(const WideP& p, hipStream_t s) {
-    const size_t lds = wide_proj_mlp_lds(p.C, p.hid / KS);
-    ICAF_LDS_OPTIN((dmff_wide_proj_mlp_kernel<DT, NPW, KS>), lds);
+    const size_t lds = wide_proj_mlp_lds<WG8>(p.C, p.hid / KS);
+    ICAF_LDS_OPTIN((dmff_wide_proj_mlp_kernel<DT, NPW, KS, WG8>), lds);
     const long long ntiles = (p.rows + WROWS - 1) / WROWS, per = 4 / KS;
-    hipLaunchKernelGGL((dmff_wide_proj_mlp_kernel<DT, NPW, KS>), dim3((unsigned)(8 * ((ntiles + per - 1) / per))), dim3(WT), lds, s, p);
+    hipLaunchKernelGGL((dmff_wide_proj_mlp_kernel<DT, NPW, KS, WG8>), dim3((unsigned)(8 * ((ntiles + per - 1) / per))), dim3(WG8::WT), lds, s, p);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
@@ -550,6 +564,17 @@ template <int DT>
 static int dispatch_wide_split(const WideP& p, int ksplit, hipStream_t s) {
     if (p.C == 256) return ksplit == 2 ? launch_wide_proj_mlp_split<DT, 1, 2>(p, s) : launch_wide_proj_mlp_split<DT, 1, 4>(p, s);
     return ksplit == 2 ? launch_wide_proj_mlp_split<DT, 2, 2>(p, s) : launch_wide_proj_mlp_split<DT, 2, 4>(p, s);
+}
+
+template <int DT>
+static int dispatch_wide_ln_qkv(const WideP& p, hipStream_t s) {
+    return p.C == 128 ? launch_wide_ln_qkv<DT, WG4>(p, s) : launch_wide_ln_qkv<DT, WG8>(p, s);
+}
+
+template <int DT>
+static int dispatch_wide_proj_mlp(const WideP& p, hipStream_t s) {
+    if (p.C == 128) return launch_wide_proj_mlp<DT, 1, WG4>(p, s);
+    return p.C == 256 ? launch_wide_proj_mlp<DT, 1, WG8>(p, s) : launch_wide_proj_mlp<DT, 2, WG8>(p, s);
 }
 
 template <int DT>
@@ -573,7 +598,7 @@ extern "C" int icaf_dmff_wide_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s) {
     if (st) return st;
     if (!a->qkv || !a->wqkv || !a->bqkv || !a->ln_attn_gamma[0] || !a->ln_attn_gamma[1] || !a->ln_attn_beta[0] || !a->ln_attn_beta[1])
         return fail(ICAF_ERR_ARG, "icaf_dmff_wide_ln_qkv: null pointer");
-    return a->dtype == ICAF_BF16 ? launch_wide_ln_qkv<ICAF_BF16>(p, S(s)) : launch_wide_ln_qkv<ICAF_F16>(p, S(s));
+    return a->dtype == ICAF_BF16 ? dispatch_wide_ln_qkv<ICAF_BF16>(p, S(s)) : dispatch_wide_ln_qkv<ICAF_F16>(p, S(s));
 }
 
 extern "C" int icaf_dmff_wide_proj_mlp(const icaf_dmff_args* a, const void* att, icaf_stream_t s) {
@@ -581,11 +606,11 @@ extern "C" int icaf_dmff_wide_proj_mlp(const icaf_dmff_args* a, const void* att,
     int st = wide_fill(a, p, "icaf_dmff_wide_proj_mlp");
     if (st) return st;
     if (!att || !a->y || !a->wo || !a->bo || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ln_mlp_gamma || !a->ln_mlp_beta) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp: null pointer");
-    if (a->hidden % WPASS || a->hidden < WPASS || a->Kp4 < a->hidden || a->Kp4 % 64) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp: hidden width %d must be a multiple of 256", a->hidden);
+    const int wpass = a->C == 128 ? WG4::WPASS : WG8::WPASS;
+    if (a->hidden % wpass || a->hidden < wpass || a->Kp4 < a->hidden || a->Kp4 % 64) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp: hidden width %d must be a multiple of %d", a->hidden, wpass);
     if (a->ldy < a->C || a->ldy % 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp: ldy=%d", a->ldy);
     p.att = att;
-    if (a->dtype == ICAF_BF16) return a->C == 256 ? launch_wide_proj_mlp<ICAF_BF16, 1>(p, S(s)) : launch_wide_proj_mlp<ICAF_BF16, 2>(p, S(s));
-    return a->C == 256 ? launch_wide_proj_mlp<ICAF_F16, 1>(p, S(s)) : launch_wide_proj_mlp<ICAF_F16, 2>(p, S(s));
+    return a->dtype == ICAF_BF16 ? dispatch_wide_proj_mlp<ICAF_BF16>(p, S(s)) : dispatch_wide_proj_mlp<ICAF_F16>(p, S(s));
 }
 
 extern "C" int icaf_dmff_wide_proj_mlp_split(const icaf_dmff_args* a, const void* att, float* partial, int ksplit, icaf_stream_t s) {
@@ -594,7 +619,8 @@ extern "C" int icaf_dmff_wide_proj_mlp_split(const icaf_dmff_args* a, const void
     if (st) return st;
     if (!att || !partial || !a->y || !a->wo || !a->bo || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ln_mlp_gamma || !a->ln_mlp_beta) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp_split: null pointer");
     if (ksplit != 2 && ksplit != 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp_split: ksplit %d (2 or 4)", ksplit);
-    if (a->hidden % (WPASS * ksplit) || a->Kp4 < a->hidden || a->Kp4 % 64) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp_split: hidden width %d must be a multiple of %d", a->hidden, WPASS * ksplit);
+    if (a->C == 128) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp_split: C = 128 has no hidden split (its weights are 0.3 MB)");
+    if (a->hidden % (WG8::WPASS * ksplit) || a->Kp4 < a->hidden || a->Kp4 % 64) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp_split: hidden width %d must be a multiple of %d", a->hidden, WG8::WPASS * ksplit);
     if (a->ldy < a->C || a->ldy % 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp_split: ldy=%d", a->ldy);
     p.att = att;
     p.part = partial;

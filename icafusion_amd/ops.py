@@ -621,9 +621,11 @@ def dmff_attn_mlp(x, qkv, y, packs, ln, coef, eps, B, N, heads, name="dmff_attn_
 
 
 def dmff_wide_ok(C_, hidden, dt):
-    """The wide-level block kernels (dmff_wide.hip) cover this shape: C = 256 / 512, 16-bit types, hidden a multiple of 256."""
-    lds = 64 * (C_ * 2 + 16) + 64 * (256 * 2 + 16) + 8 * 64 * 4 + hidden * 4
-    return dt in (torch.bfloat16, torch.float16) and C_ in (256, 512) and hidden % 256 == 0 and lds <= 160 * 1024
+    """The three-launch block kernels (dmff_wide.hip) cover this shape: C = 128 (four wavefronts, 128-channel passes) / 256 / 512 (eight,
+    256-channel passes), 16-bit types, hidden a multiple of the pass width."""
+    wpass = 128 if C_ == 128 else 256
+    lds = 64 * (C_ * 2 + 16) + 64 * (wpass * 2 + 16) + 8 * 64 * 4 + hidden * 4
+    return dt in (torch.bfloat16, torch.float16) and C_ in (128, 256, 512) and hidden % wpass == 0 and lds <= 160 * 1024
 
 
 def _wide_packs(packs):

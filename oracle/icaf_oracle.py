@@ -147,7 +147,7 @@ def pooled_tokens(x, va, ha, w1, w2, pos):
 
 
 def layer_norm(x, w, b):
-    if x.dtype != torch.float32:              # 16-bit mode (OracleModel dtype=): what nn.LayerNorm itself does for a .half() model
+    if x.dtype not in (torch.float32, torch.float64):              # 16-bit mode (OracleModel dtype=): what nn.LayerNorm itself does for a .half() model
         return F.layer_norm(x, (x.shape[-1],), w, b, LN_EPS)
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
@@ -159,44 +159,53 @@ def linear(x, sd, pre):
 
 
 def gelu_erf(x):
-    if x.dtype != torch.float32:
+    if x.dtype not in (torch.float32, torch.float64):
         return F.gelu(x)
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
-def cross_attention(v, i, sd, pre, heads):
+def cross_attention(v, i, sd, pre, heads, store=None):
     """models/common.py:641-687.  Note the crossing: the IR queries attend to the RGB keys/values to produce
-    out_vis (:670,:682) and the RGB queries attend to the IR keys/values to produce out_ir (:671,:684)."""
+    out_vis (:670,:682) and the RGB queries attend to the IR keys/values to produce out_ir (:671,:684).
+    store (optional): applied wherever a 16-bit implementation writes a tensor to memory — the normalised tokens, q / k / v, the
+    attention output (see cross_transformer)."""
+    st = store or (lambda t: t)
     bsz, n, c = v.shape
     dk = c // heads
-    vn = layer_norm(v, sd[pre + ".LN1.weight"], sd[pre + ".LN1.bias"])
-    inn = layer_norm(i, sd[pre + ".LN2.weight"], sd[pre + ".LN2.bias"])
+    vn = st(layer_norm(v, sd[pre + ".LN1.weight"], sd[pre + ".LN1.bias"]))
+    inn = st(layer_norm(i, sd[pre + ".LN2.weight"], sd[pre + ".LN2.bias"]))
 
     def split(t):
         return t.reshape(bsz, n, heads, dk).permute(0, 2, 1, 3)            # (B, h, N, dk)
 
-    q_v, k_v, v_v = (split(linear(vn, sd, f"{pre}.{nm}_proj_vis")) for nm in ("que", "key", "val"))
-    q_i, k_i, v_i = (split(linear(inn, sd, f"{pre}.{nm}_proj_ir")) for nm in ("que", "key", "val"))
+    q_v, k_v, v_v = (split(st(linear(vn, sd, f"{pre}.{nm}_proj_vis"))) for nm in ("que", "key", "val"))
+    q_i, k_i, v_i = (split(st(linear(inn, sd, f"{pre}.{nm}_proj_ir"))) for nm in ("que", "key", "val"))
     scale = 1.0 / math.sqrt(dk)
     a_v = torch.softmax(torch.einsum("bhqd,bhkd->bhqk", q_i, k_v) * scale, -1)
     a_i = torch.softmax(torch.einsum("bhqd,bhkd->bhqk", q_v, k_i) * scale, -1)
-    o_v = torch.einsum("bhqk,bhkd->bhqd", a_v, v_v).permute(0, 2, 1, 3).reshape(bsz, n, c)
-    o_i = torch.einsum("bhqk,bhkd->bhqd", a_i, v_i).permute(0, 2, 1, 3).reshape(bsz, n, c)
+    o_v = st(torch.einsum("bhqk,bhkd->bhqd", a_v, v_v).permute(0, 2, 1, 3).reshape(bsz, n, c))
+    o_i = st(torch.einsum("bhqk,bhkd->bhqd", a_i, v_i).permute(0, 2, 1, 3).reshape(bsz, n, c))
     return linear(o_v, sd, pre + ".out_proj_vis"), linear(o_i, sd, pre + ".out_proj_ir")
 
 
-def cross_transformer(v, i, sd, pre, heads, loops):
-    """models/common.py:737-759: parameter-shared loop; ONE LN2 normalises both modalities before their MLPs."""
+def cross_transformer(v, i, sd, pre, heads, loops, store=None):
+    """models/common.py:737-759: parameter-shared loop; ONE LN2 normalises both modalities before their MLPs.
+    store (optional; tests/test_gpu_dmff_fused.py): a function applied at every point where a 16-bit implementation STORES a tensor
+    (normalised tokens, q / k / v, attention output, x_att, the MLP's normalised input, the hidden activations, the block's output).
+    With float64 tensors / parameters and store = round-trip through bf16 / f16 this is the reference's arithmetic evaluated exactly,
+    with the storage roundings of the HIP kernels and nothing else: what remains between it and a kernel is the kernel's own
+    arithmetic error (fp32 accumulation order, exp2 / erf approximations, the rounding of the attention probabilities)."""
+    st = store or (lambda t: t)
     co = [sd[f"{pre}.coefficient{k}.bias"] for k in range(1, 9)]
     ln_w, ln_b = sd[pre + ".LN2.weight"], sd[pre + ".LN2.bias"]
     for _ in range(loops):
-        o_v, o_i = cross_attention(v, i, sd, pre + ".crossatt", heads)
-        va = co[0] * v + co[1] * o_v
-        ia = co[2] * i + co[3] * o_i
-        hv = linear(gelu_erf(linear(layer_norm(va, ln_w, ln_b), sd, pre + ".mlp_vis.0")), sd, pre + ".mlp_vis.2")
-        hi = linear(gelu_erf(linear(layer_norm(ia, ln_w, ln_b), sd, pre + ".mlp_ir.0")), sd, pre + ".mlp_ir.2")
-        v = co[4] * va + co[5] * hv
-        i = co[6] * ia + co[7] * hi
+        o_v, o_i = cross_attention(v, i, sd, pre + ".crossatt", heads, store)
+        va = st(co[0] * v + co[1] * o_v)
+        ia = st(co[2] * i + co[3] * o_i)
+        hv = linear(st(gelu_erf(linear(st(layer_norm(va, ln_w, ln_b)), sd, pre + ".mlp_vis.0"))), sd, pre + ".mlp_vis.2")
+        hi = linear(st(gelu_erf(linear(st(layer_norm(ia, ln_w, ln_b)), sd, pre + ".mlp_ir.0"))), sd, pre + ".mlp_ir.2")
+        v = st(co[4] * va + co[5] * hv)
+        i = st(co[6] * ia + co[7] * hi)
     return v, i
 
 

@@ -69,9 +69,11 @@ def test_fused_block_vs_oracle_and_per_layer_launches(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", [(256, 8, 256, 2, 1), (512, 8, 100, 3, 1), (256, 8, 400, 1, 2), (512, 8, 64, 1, 1), (256, 4, 77, 3, 3), (512, 16, 130, 2, 2)])
+@pytest.mark.parametrize("shape", [(256, 8, 256, 2, 1), (512, 8, 100, 3, 1), (256, 8, 400, 1, 2), (512, 8, 64, 1, 1), (256, 4, 77, 3, 3), (512, 16, 130, 2, 2),
+                                   (128, 8, 400, 3, 1), (128, 8, 77, 2, 3), (128, 4, 130, 1, 2)])
 def test_wide_block_three_launches_vs_oracle_and_per_layer_launches(shape, dtype):
-    """C = 256 / 512 (what the plan runs at P4 / P5): icaf_dmff_wide_ln_qkv + icaf_cross_attention + icaf_dmff_wide_proj_mlp per iteration."""
+    """C = 256 / 512 (what the plan runs at P4 / P5) and C = 128 (the four-wavefront build): icaf_dmff_wide_ln_qkv + icaf_cross_attention +
+    icaf_dmff_wide_proj_mlp per iteration."""
     C, heads, N, B, loops = shape
     blk, sd = make_block(C, heads, loops, seed=C + N)
     blk = blk.to(DEV)
@@ -80,7 +82,7 @@ def test_wide_block_three_launches_vs_oracle_and_per_layer_launches(shape, dtype
     tq = tok.to(dtype).float()
     rv, ri = oracle.cross_transformer(tq[0].reshape(B, N, C), tq[1].reshape(B, N, C), sd, "b", heads, loops)
     ref = torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
-    wide, names_w = run_block(blk, tok, B, N, dtype, True, max_c=128)
+    wide, names_w = run_block(blk, tok, B, N, dtype, True, max_c=64)
     plain, names_p = run_block(blk, tok, B, N, dtype, False)
     assert [n for n in names_w if n != "dmff_proj_mlp_reduce"] == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp"] * loops and len(names_p) == 7 * loops
     scale = ref.abs().max().item()
@@ -91,6 +93,52 @@ def test_wide_block_three_launches_vs_oracle_and_per_layer_launches(shape, dtype
     assert e_w <= 1.5 * e_p + 1e-4 and m_w <= 1.25 * m_p + 1e-5
     ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     assert (wide - plain).abs().max().item() / scale <= 24 * ulp
+
+
+def rounded_reference(tok, sd, heads, loops, dtype, B, N, C):
+    """oracle.cross_transformer in float64 with the storage roundings of a 16-bit implementation and nothing else: parameters of the
+    Linear layers rounded to the storage type (the packed weights), LayerNorm parameters / biases / coefficients in fp32 as the kernels
+    hold them, every stored tensor round-tripped through the type."""
+    def rt(t):
+        return t.to(dtype).double()
+    sd64 = {}
+    for k, v in sd.items():
+        is_w = k.endswith(".weight") and v.dim() == 2
+        sd64[k] = rt(v.float()) if is_w else v.double()
+    tq = rt(tok)
+    rv, ri = oracle.cross_transformer(tq[0].reshape(B, N, C), tq[1].reshape(B, N, C), sd64, "b", heads, loops, store=rt)
+    return torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
+
+
+# (max, mean) of |kernel - rounded_reference| / max|ref|: PROVISIONAL until the first GPU run prints the measured values
+ABS_BOUND = {torch.bfloat16: (4.0e-2, 1.2e-3), torch.float16: (6.0e-3, 1.6e-4)}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(256, 8, 256, 2, 1), (512, 8, 100, 3, 1), (512, 8, 64, 1, 2), (128, 8, 400, 2, 1), (256, 4, 77, 3, 3)])
+def test_wide_block_against_the_oracle_in_absolute_terms(shape, dtype):
+    """VERDICT r3 #5 / next #6a: the three-launch kernels (what the bench runs at P4 / P5) held to oracle.cross_transformer DIRECTLY, not to
+    their per-layer siblings: the oracle evaluated in float64 with exactly the storage roundings of a 16-bit implementation
+    (rounded_reference) leaves only the kernels' own arithmetic error, which is bounded in absolute terms (fractions of max|ref|);
+    the distance to the unrounded fp32 oracle is printed beside it."""
+    C, heads, N, B, loops = shape
+    blk, sd = make_block(C, heads, loops, seed=C + N)
+    blk = blk.to(DEV)
+    g = np.random.default_rng(C * 1000 + N + 3)
+    tok = torch.from_numpy(g.normal(0.2, 0.8, (2, B * N, C)).astype(np.float32))
+    ref_r = rounded_reference(tok, sd, heads, loops, dtype, B, N, C)
+    tq = tok.to(dtype).float()
+    rv, ri = oracle.cross_transformer(tq[0].reshape(B, N, C), tq[1].reshape(B, N, C), sd, "b", heads, loops)
+    ref = torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
+    wide, names_w = run_block(blk, tok, B, N, dtype, True, max_c=64)
+    assert "dmff_proj_mlp" in names_w and "cross_attention" in names_w
+    scale = ref.abs().max().item()
+    d = (wide.double() - ref_r).abs()
+    e_max, e_mean = d.max().item() / scale, d.mean().item() / scale
+    e_fp32 = (wide - ref).abs().max().item() / scale
+    print(f"C={C} N={N} B={B} loops={loops} {dtype}: vs float64 oracle with storage roundings max {e_max:.3e} mean {e_mean:.3e} | vs fp32 oracle max {e_fp32:.3e}")
+    assert torch.isfinite(wide).all()
+    assert e_max <= ABS_BOUND[dtype][0] and e_mean <= ABS_BOUND[dtype][1]
 
 
 @pytest.mark.parametrize("ksplit", [1, 2, 4])

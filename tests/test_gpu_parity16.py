@@ -65,3 +65,20 @@ def test_16bit_map50_within_a_tenth_of_the_fp32_oracle(dtype):
     assert rec["map50_oracle_fp32"] > 50.0
     assert abs(rec["map50_delta_reference16"]) <= 0.1, f"recipe not separated: the reference in {dtype} moves mAP@50 by {rec['map50_delta_reference16']}"
     assert abs(rec["map50_delta"]) <= 0.1, f"{dtype}: mAP@50 {rec['map50_hip16']} vs fp32 oracle {rec['map50_oracle_fp32']}"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_16bit_map_on_ten_pixel_objects_where_box_error_counts(dtype):
+    """the recipe above plants 30-60 pixel boxes, which no 16-bit box error can push across IoU 0.5.  RECIPES["p3_small"]
+    plants at the P3 DMFF block and reads out on the P3 level's smallest anchor: ~10 x 10 pixel objects, for which two pixels of error cost a
+    third of the IoU.  That the metric now depends on localisation is shown by the reference itself: evaluated in bf16 (boxes decoded INTO a
+    bf16 tensor: a 2-4 pixel grid beyond x = 256) it keeps mAP@50 but loses several points of mAP@.5:.95.  The HIP path (16-bit features,
+    fp32 Detect decode) must keep mAP@50 within 0.1 AND may not lose more mAP@.5:.95 than the reference's own 16-bit mode does."""
+    rec = parity16.measure_map(dtype, recipe="p3_small")
+    _record(rec)
+    box = rec["object_box_px"]
+    assert rec["objects"] >= 1000 and 8.0 <= box["w_median"] <= 16.0 and 8.0 <= box["h_median"] <= 16.0
+    assert rec["map50_oracle_fp32"] > 50.0
+    assert abs(rec["map50_delta"]) <= 0.1, f"{dtype}: mAP@50 {rec['map50_hip16']} vs fp32 oracle {rec['map50_oracle_fp32']} on 10-pixel objects"
+    assert rec["map_delta"] >= min(rec["map_delta_reference16"], 0.0) - 0.5, \
+        f"{dtype}: mAP@.5:.95 moves by {rec['map_delta']} (HIP) vs {rec['map_delta_reference16']} (the reference in {dtype})"

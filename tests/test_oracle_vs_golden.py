@@ -230,3 +230,19 @@ def test_planted_detector_recipe_is_separated(dtype):
     for st in rec["fit"][1:]:                              # P4 / P5: a clear gap between planted cells and background
         assert st["planted_cells_min"] - st["background_max"] > 0.5
     assert abs(rec["map50_delta_reference16"]) <= 0.1, rec
+
+
+def test_small_object_recipe_depends_on_box_accuracy():
+    """RECIPES["p3_small"] of tools/parity16.py (10 x 10 pixel objects at the P3 level): separated scores at a non-trivial mAP, and a metric
+    that DOES move with localisation error — the reference evaluated in bf16 (boxes decoded into a bf16 tensor) keeps mAP@50 but loses more
+    than two points of mAP@.5:.95.  The GPU test holds the HIP path to this recipe (tests/test_gpu_parity16.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity16
+    rec = parity16.measure_map("bf16", B=4, hip=False, recipe="p3_small")
+    box = rec["object_box_px"]
+    assert rec["objects"] >= 300 and 8.0 <= box["w_median"] <= 16.0 and 8.0 <= box["h_median"] <= 16.0 and box["max"] <= 16.0
+    assert 50.0 < rec["map50_oracle_fp32"] < 95.0
+    assert rec["fit"][0]["planted_cells_min"] - rec["fit"][0]["background_max"] > 0.5
+    assert abs(rec["map50_delta_reference16"]) <= 0.1 and rec["map_delta_reference16"] < -2.0, rec

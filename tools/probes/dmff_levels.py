@@ -15,7 +15,7 @@ for C, N, B in LEVELS[sys.argv[1] if len(sys.argv) > 1 else "s"]:
     blk = CrossTransformerBlock(C, C, C, 8, 4, 0.1, 0.1).eval()
     blk.load_state_dict({k: synth_tensor("b." + k, v.shape, seed=1) for k, v in blk.state_dict().items()})
     blk = blk.to("cuda:0")
-    for mode, (fb, mc, wide) in (("per-layer", (False, 128, False)), ("two", (True, 512, False)), ("three", (True, 128, True))):
+    for mode, (fb, mc, wide) in (("per-layer", (False, 128, False)), ("two", (True, 512, False)), ("three", (True, 64, True))):
         if (mode == "three" and not ops.dmff_wide_ok(C, 4 * C, torch.bfloat16)) or (mode == "two" and C > 512):
             continue
         blk.fuse_block, blk.fuse_max_c, blk.fuse_wide = fb, mc, wide
