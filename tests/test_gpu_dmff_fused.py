@@ -110,8 +110,11 @@ def rounded_reference(tok, sd, heads, loops, dtype, B, N, C):
     return torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
 
 
-# (max, mean) of |kernel - rounded_reference| / max|ref|: PROVISIONAL until the first GPU run prints the measured values
-ABS_BOUND = {torch.bfloat16: (4.0e-2, 1.2e-3), torch.float16: (6.0e-3, 1.6e-4)}
+# (max, mean) of |kernel - rounded_reference| / max|ref|.  Measured on the MI355X over the five shapes below (printed by the test;
+# profiles/r04_dmff_wide_abs_error.txt): bf16 max 3.9e-3 ... 1.1e-2 (three iterations), mean 2.2e-4 ... 5.0e-4; f16 max 6.2e-4 ... 1.4e-3, mean
+# 2.8e-5 ... 6.2e-5 — one to three units in the last place of the storage type on the largest elements (the rounding of the attention
+# probabilities, fp32 accumulation order, the exp2 / erf approximations).  The bounds are 2 x the largest value measured.
+ABS_BOUND = {torch.bfloat16: (2.3e-2, 1.0e-3), torch.float16: (2.8e-3, 1.3e-4)}
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
