@@ -123,5 +123,5 @@ def test_resident_patch_kernel_shape_table():
                 (3, 3, 2, 1, 1, 1, 64, 128), (3, 3, 2, 2, 1, 1, 32, 128), (3, 3, 1, 1, 1, 1, 64, 128)):
         assert s(*bad) == []
     assert ops.dmff_wide_ok(256, 1024, torch.bfloat16) and ops.dmff_wide_ok(512, 2048, torch.float16)
-    assert not ops.dmff_wide_ok(128, 512, torch.bfloat16) and not ops.dmff_wide_ok(384, 1536, torch.bfloat16)
+    assert ops.dmff_wide_ok(128, 512, torch.bfloat16) and not ops.dmff_wide_ok(384, 1536, torch.bfloat16) and not ops.dmff_wide_ok(1024, 4096, torch.bfloat16)
     assert not ops.dmff_wide_ok(256, 1024, torch.float32) and not ops.dmff_wide_ok(512, 2048 + 128, torch.bfloat16)
