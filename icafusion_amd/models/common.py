@@ -726,10 +726,14 @@ class CrossTransformerBlock(HipModule):
 
     # 16-bit types: one iteration = icaf_dmff_ln_qkv + icaf_dmff_attn_mlp (2 launches) instead of 7 (ICAF_DMFF_FUSE=0: A/B switch)
     fuse_block = os.environ.get("ICAF_DMFF_FUSE", "1") != "0"
-    # The fused kernels are built for C <= 512 but USED up to this width: at C <= 128 two workgroups share a CU (2 waves / SIMD) and
-    # the pair of launches beats the seven (MI355X, batch 32, N = 400: 111 vs 145 us); at C = 256 / 512 one workgroup per CU cannot
-    # hide its own latencies and each 64-row tile re-streams all 9 C^2 weights (166 vs 141 us, 430 vs 153 us) — DESIGN.md §11.
-    fuse_max_c = int(os.environ.get("ICAF_DMFF_FUSE_MAX_C", "128"))
+    # The two-launch kernels (dmff_fused.hip: LN + QKV, then attention + out-projection + LN + MLP in ONE workgroup) are built for C <= 512 and
+    # USED up to this width.  Round 2 measured them ahead at C <= 128 only (111 vs 145 us for the seven per-layer launches at P3; at C = 256 /
+    # 512 one workgroup per CU cannot hide its own latencies: 166 vs 141, 430 vs 153 us); round 3 moved C = 256 / 512 to the three-launch form
+    # (dmff_wide.hip); round 4 built that form for C = 128 too (four wavefronts, weights streamed per wave into registers: no barrier in a
+    # GEMM pass) and the stand-alone attention kernel got the rewritten inner loop: P3 block 88 us (two launches) vs 78 us (three), whole
+    # bench 15,003 / 15,061 vs 15,181 pairs/s on one box — so the default is 64 and every yolov5s level runs three launches.
+    # ICAF_DMFF_FUSE_MAX_C=128 restores the two-launch form at P3 (A/B, tests).
+    fuse_max_c = int(os.environ.get("ICAF_DMFF_FUSE_MAX_C", "64"))
     # fp32 plans keep the per-layer launches (the goldens then cover them); True runs the fp32 INSTANTIATION of the fused kernels where
     # it exists (C <= 128): the same template the 16-bit path runs, held to the reference's fp32 goldens (tests/test_gpu_dmff_fused.py)
     fuse_fp32 = os.environ.get("ICAF_DMFF_FUSE_FP32", "0") == "1"

@@ -43,7 +43,7 @@ def _check_loaded(m, yaml_names):
         names = [l.name for l in plan.launches]
         assert len(names) > 40 and names[-1] == ("detect_decode" if dtype == torch.float32 else "detect_conv+decode")
         assert names.count("cross_attention") + names.count("dmff_attn_mlp") == 3
-        assert ("dmff_attn_mlp" in names) == (dtype != torch.float32)          # 16-bit: the fused block kernels at the narrow levels
+        assert ("dmff_attn_mlp" in names or "dmff_proj_mlp" in names) == (dtype != torch.float32)     # 16-bit: the fused block kernels (two- or three-launch form)
     m.compute_dtype, m.use_graph = torch.bfloat16, True           # what test.py / detect_twostream.py do after loading
     assert m.__dict__["compute_dtype"] is torch.bfloat16
     return m

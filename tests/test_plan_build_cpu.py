@@ -71,15 +71,15 @@ def _dmff_launches(n):
 
 @pytest.mark.parametrize("loops", [1, 3])
 def test_dmff_block_launch_structure_at_every_level(loops):
-    """16-bit yolov5s: P3 (C = 128) runs LN + QKV, attention + out-projection + LN + MLP (2 launches per iteration); P4 / P5
-    (C = 256 / 512) LN + QKV, attention, out-projection + LN + MLP (3) — VERDICT r2 #3; P5, whose few 64-row tiles leave most CUs idle
+    """16-bit yolov5s: every level runs LN + QKV, attention, out-projection + LN + MLP (3 launches per iteration; CrossTransformerBlock.fuse_max_c
+    = 128 gives P3 the two-launch form of dmff_fused.hip back: LN + QKV, attention + out-projection + LN + MLP) — VERDICT r2 #3; P5, whose few 64-row tiles leave most CUs idle
     and whose weights overflow an XCD's L2, splits the MLP's hidden columns over several workgroups per tile and adds a small
     reduce launch (VERDICT r3 #1c).  fp32 keeps the seven per-layer launches."""
     m = Model(load_cfg("yolov5s_Transfusion_kaist.yaml")).eval()
     for i in (20, 21, 22):
         m.model[i].crosstransformer[0].loops = loops
     blocks = _dmff_launches(names(m.build_plan(2, 320, 320, "cpu", torch.bfloat16)))
-    assert blocks[0] == ["dmff_ln_qkv", "dmff_attn_mlp"] * loops
+    assert blocks[0] == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp"] * loops          # (round 4: the four-wavefront build at C = 128)
     assert blocks[1] == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp"] * loops
     assert blocks[2] == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp", "dmff_proj_mlp_reduce"] * loops
     from icafusion_amd import ops
@@ -89,9 +89,12 @@ def test_dmff_block_launch_structure_at_every_level(loops):
     try:
         CrossTransformerBlock.fuse_wide = False                  # A/B switch: the wide levels fall back to the per-layer launches
         plain = _dmff_launches(names(m.build_plan(2, 320, 320, "cpu", torch.bfloat16)))
-        assert plain[0] == blocks[0] and len(plain[1]) == 7 * loops and len(plain[2]) == 7 * loops
+        assert len(plain[0]) == 7 * loops and len(plain[1]) == 7 * loops and len(plain[2]) == 7 * loops
+        CrossTransformerBlock.fuse_wide, CrossTransformerBlock.fuse_max_c = True, 128          # the two-launch form at P3
+        two = _dmff_launches(names(m.build_plan(2, 320, 320, "cpu", torch.bfloat16)))
+        assert two[0] == ["dmff_ln_qkv", "dmff_attn_mlp"] * loops and two[1] == blocks[1]
     finally:
-        CrossTransformerBlock.fuse_wide = True
+        CrossTransformerBlock.fuse_wide, CrossTransformerBlock.fuse_max_c = True, 64
     f32 = _dmff_launches(names(m.build_plan(2, 320, 320, "cpu", torch.float32)))
     assert [len(b) for b in f32] == [7 * loops] * 3
 
