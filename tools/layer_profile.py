@@ -17,7 +17,7 @@ from icafusion_amd.synth import synth_images, synth_state_dict   # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="s"); ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--size", type=int, default=640); ap.add_argument("--dtype", default="bf16")
-ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--reps", type=int, default=7)
 ap.add_argument("--sweep", action="store_true", help="time every igemm launch with each tile config")
 ap.add_argument("--autotune", action="store_true")
 a = ap.parse_args()
@@ -31,13 +31,10 @@ plan = m.plan_for(a.batch, a.size, a.size, "cuda:0")
 rgb, ir = synth_images(a.batch, a.size, a.size, 0)
 plan.inputs[0].copy_(rgb.cuda()); plan.inputs[1].copy_(ir.cuda())
 plan.run(); torch.cuda.synchronize()
-acc = None
-for _ in range(a.reps):
-    r = plan.timed_run()
-    acc = [x[1] for x in r] if acc is None else [p + x[1] for p, x in zip(acc, r)]
+runs = [[x[1] for x in plan.timed_run()] for _ in range(a.reps)]
+acc = [sorted(v)[len(v) // 2] for v in zip(*runs)]       # MEDIAN over the repetitions (a single 0.9 ms hiccup in one of five runs once put 175 us on a 31 us kernel)
 rows = []
 for l, ms in zip(plan.launches, acc):
-    ms /= a.reps
     desc = l.name
     if l.fn is ops.lib().icaf_conv2d:
         c = l.keep[0]
