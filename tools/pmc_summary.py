@@ -67,12 +67,20 @@ def short(name):
     return name[:80]
 
 
-def collect(d):
+def collect(d, by_instantiation=False):
+    """by_instantiation: key the DMFF block kernels by their FULL template name instead (the three levels of a model run different
+    instantiations of one kernel — C = 128 four wavefronts, C = 256, C = 512 with the hidden split — which the short name merges)."""
     out = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                k = short(row.get("Kernel_Name", "?"))
+                full = row.get("Kernel_Name", "?")
+                if by_instantiation:
+                    if "dmff_wide" not in full and "dmff_attn_mlp" not in full and "dmff_ln_qkv" not in full:
+                        continue
+                    k = re.sub(r"^void ", "", full).replace("icaf::", "")[:120]
+                else:
+                    k = short(full)
                 c = row.get("Counter_Name", "?")
                 v = float(row.get("Counter_Value", 0))
                 e = out.setdefault(k, {}).setdefault(c, [0.0, 0])
@@ -95,7 +103,17 @@ def main():
         if "WRITE_SIZE" in cs:
             cs["write_bytes_uncorrected"] = cs["WRITE_SIZE"]["mean_per_dispatch"] * 1024
     res = {k: v for k, v in res.items() if not k.startswith("at::")}
-    print(json.dumps({"workload": workload, "unit": "bytes per dispatch",
+    inst = {}
+    for d in dirs:
+        for k, cs in collect(d, by_instantiation=True).items():
+            for c, (s, n) in cs.items():
+                inst.setdefault(k, {})[c] = {"mean_per_dispatch": s / max(n, 1), "dispatches": n}
+    for k, cs in inst.items():
+        if "FETCH_SIZE" in cs:
+            cs["fetch_bytes_corrected"] = cs["FETCH_SIZE"]["mean_per_dispatch"] * 1024 * 2
+        if "WRITE_SIZE" in cs:
+            cs["write_bytes_uncorrected"] = cs["WRITE_SIZE"]["mean_per_dispatch"] * 1024
+    print(json.dumps({"workload": workload, "unit": "bytes per dispatch", "dmff_kernels_by_instantiation": inst,
                       "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
                                 "FETCH_SIZE x1024 x2 (gfx950 128-byte requests tallied at 64 B), WRITE_SIZE x1024",
                       "kernels": res}, indent=1, sort_keys=True))
