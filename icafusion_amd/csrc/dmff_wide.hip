@@ -1,7 +1,8 @@
 // DMFF block kernels for the WIDE levels (C = 256 / 512, 16-bit types) on gfx950 — one CrossTransformerBlock iteration (reference
 // models/common.py:737-759, CrossAttention :641-687, MLP :704-709) as THREE launches:
 //
-//   dmff_wide_ln_qkv_kernel    LayerNorm (CrossAttention.LN1 / LN2, :661-662) + the six Linear(C, C) projections (:664-669)
+//   dmff_wide_ln_qkv_kernel    LayerNorm (CrossAttention.LN1 / LN2, :661-662) + the six Linear(C, C) projections (:664-669); a workgroup
+//                              = 64 rows x three passes of output channels, or ONE pass where the tiles alone do not fill the chip
 //   cross_attn_kernel          (dmff.hip) softmax(q_other k^T / sqrt(dk)) v per (image, direction, head) (:670-681)
 //   dmff_wide_proj_mlp_kernel  out-projection + coefficient mix (:682-685, :745-746), the block's shared LayerNorm (:749-750),
 //                              MLP Linear(C, 4C) -> GELU(erf) -> Linear(4C, C) and the final mix (:704-709, :751-752)
@@ -49,6 +50,7 @@ struct WideP {
     long long wqkv_gs, bqkv_gs, wo_gs, bo_gs, w1_gs, b1_gs, w2_gs, b2_gs, x_gs, y_gs;
     long long rows;
     int C, Kp, Kp4, hid, ldy;
+    int qkv_npass;            // ln_qkv: passes (of WPASS output channels) per workgroup, 3 or 1
     float eps_a, eps_m;
     float c_res_a[2], c_acc_a[2], c_res_m[2], c_acc_m[2];
 };
@@ -172,7 +174,8 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_ln_qkv_kernel(const WideP p) 
     unsigned char* tile = smem;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ngrp = C / G::WPASS;                                    // column groups of 768 channels
+    const int npass = p.qkv_npass;                                    // 3: a workgroup writes q, k AND v columns of its group; 1: one pass each
+    const int ngrp = 3 * (C / G::WPASS) / npass;                      // column groups per tile
     const int ntiles = (int)((p.rows + WROWS - 1) / WROWS);
     int g, idx;
     wide_place(blockIdx.x, g, idx);
@@ -183,8 +186,8 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_ln_qkv_kernel(const WideP p) 
 
     const u32x4* wf = (const u32x4*)((const T*)p.wqkv + g * p.wqkv_gs) + lane;
     auto next = [&](WCursor& c) {
-        if (c.seg >= 3) { c.left = 0; return; }
-        c.base = wf + (long long)((grp * 3 + c.seg) * G::NW + wn) * ks_row * 64;
+        if (c.seg >= npass) { c.left = 0; return; }
+        c.base = wf + (long long)((grp * npass + c.seg) * G::NW + wn) * ks_row * 64;
         c.left = nsl;
     };
     WCursor cur; cur.seg = 0; next(cur);
@@ -209,14 +212,14 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_ln_qkv_kernel(const WideP p) 
     const float* bias = p.bqkv + g * p.bqkv_gs;
     const int nout = 3 * C;
     T* out = (T*)p.qkv + (long long)g * p.rows * nout;
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < npass; ++j) {
         f32x16 acc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
         wpass<DT, G::SL>(acc, tile, SA, nsl, wq, cur, next);
-        const int nb = (grp * 3 + j) * G::WPASS + wn * 32;
+        const int nb = (grp * npass + j) * G::WPASS + wn * 32;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const long long row = r0 + t * 32 + l31;
@@ -517,7 +520,10 @@ static int wide_fill(const icaf_dmff_args* a, WideP& p, const char* who) {
     p.wqkv_gs = a->wqkv_gs; p.bqkv_gs = a->bqkv_gs; p.wo_gs = a->wo_gs; p.bo_gs = a->bo_gs; p.w1_gs = a->w1_gs; p.b1_gs = a->b1_gs;
     p.w2_gs = a->w2_gs; p.b2_gs = a->b2_gs; p.x_gs = a->x_gs; p.y_gs = a->y_gs;
     p.rows = (long long)a->B * a->N; p.C = a->C; p.Kp = a->Kp; p.Kp4 = a->Kp4; p.hid = a->hidden; p.ldy = a->ldy;
-    p.eps_a = a->eps_attn; p.eps_m = a->eps_mlp;
+    // LN + QKV: three output-channel passes per workgroup by default.  One pass per workgroup (three times the workgroups for the levels whose
+    // tiles alone do not fill the chip) was measured and LOSES at every level — P5 of yolov5s 26.7 -> 34.4 us, P4 19.6 -> 25.5, yolov5l P4
+    // 48.9 -> 65.5: the repeated LayerNorm and workgroup prologues cost more than the idle CUs.  a->reserved = 1 keeps it reachable for A/B.
+    p.qkv_npass = a->reserved == 1 ? 1 : 3;
     for (int g = 0; g < 2; ++g) {
         p.c_res_a[g] = a->coef_res_attn[g]; p.c_acc_a[g] = a->coef_acc_attn[g];
         p.c_res_m[g] = a->coef_res_mlp[g]; p.c_acc_m[g] = a->coef_acc_mlp[g];
@@ -529,7 +535,7 @@ template <int DT, class G>
 static int launch_wide_ln_qkv(const WideP& p, hipStream_t s) {
     const size_t lds = (size_t)WROWS * (p.C * 2 + 16);
     ICAF_LDS_OPTIN((dmff_wide_ln_qkv_kernel<DT, G>), lds);        // (size checked on EVERY call, attribute raised per device as needed)
-    const long long work = ((p.rows + WROWS - 1) / WROWS) * (p.C / G::WPASS);
+    const long long work = ((p.rows + WROWS - 1) / WROWS) * (3 * (p.C / G::WPASS) / p.qkv_npass);
     hipLaunchKernelGGL((dmff_wide_ln_qkv_kernel<DT, G>), dim3((unsigned)(8 * ((work + 3) / 4))), dim3(G::WT), lds, s, p);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;

@@ -637,12 +637,14 @@ def dmff_wide_ln_qkv(x, qkv, packs, ln, coef, eps, B, N, heads, name="dmff_ln_qk
     """LayerNorm + the six Linear(C, C) projections, wide levels (icaf_dmff_wide_ln_qkv)."""
     wp = _wide_packs(packs)
     a = _dmff_args(x, qkv, None, wp, ln, coef, eps, B, N, heads)
+    a.reserved = DMFF_QKV_NPASS                      # output-channel passes per workgroup: 0 = automatic (icaf.h)
     rows, Cc = x.shape[1], x.shape[2]
     es = x.element_size()
     return Launch(lib().icaf_dmff_wide_ln_qkv, (C.byref(a),), keep=(a, x, qkv, wp, packs, ln), name=name, flops=2.0 * 2 * rows * Cc * 3 * Cc,
                   nbytes=2 * (rows * Cc * es + 3 * Cc * Cc * es + rows * 3 * Cc * es))
 
 
+DMFF_QKV_NPASS = int(os.environ.get("ICAF_DMFF_QKV_NPASS", "0"))   # A/B switch: passes per workgroup of the wide LN + QKV kernel (0 = automatic)
 DMFF_KSPLIT = int(os.environ.get("ICAF_DMFF_KSPLIT", "0"))       # A/B switch: 0 = automatic, 1 = never split the hidden columns, 2 / 4 = force
 
 

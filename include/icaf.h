@@ -260,6 +260,8 @@ typedef struct icaf_dmff_args {
     float eps_attn, eps_mlp;
     float coef_res_attn[2], coef_acc_attn[2], coef_res_mlp[2], coef_acc_mlp[2];   /* coefficient1/3, 2/4, 5/7, 6/8 */
     void* debug_clock;   /* NULL, or 8 int64 slots: workgroup (0,0,0) of icaf_dmff_attn_mlp stores the shader clock at its phase boundaries */
+    /* reserved: icaf_dmff_wide_ln_qkv reads it as "output-channel passes per workgroup": 1 = one (A/B switch; measured slower), anything else =
+     * three; other entry points ignore it */
 } icaf_dmff_args;
 int icaf_dmff_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s);
 int icaf_dmff_attn_mlp(const icaf_dmff_args* a, icaf_stream_t s);

@@ -238,7 +238,7 @@ def test_fp32_fused_dmff_block_vs_reference_golden(name):
     rgb = torch.from_numpy(rg.normal(0, 1, (batch, c, h, w)).astype(np.float32)).to(DEV)
     ir = torch.from_numpy(rg.normal(0, 1, (batch, c, h, w)).astype(np.float32)).to(DEV)
     ct = blk.crosstransformer[0]
-    ct.fuse_block, ct.fuse_fp32 = True, True
+    ct.fuse_block, ct.fuse_fp32, ct.fuse_max_c = True, True, 128          # (the two-launch kernels: not the default at C = 128 since round 4)
     blk.invalidate()
     out = blk([rgb, ir]).float().cpu()
     names = [l.name for pl in blk.__dict__["_plans"].values() for l in pl.launches]
