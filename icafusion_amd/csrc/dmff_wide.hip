@@ -524,6 +524,7 @@ static int wide_fill(const icaf_dmff_args* a, WideP& p, const char* who) {
     // tiles alone do not fill the chip) was measured and LOSES at every level — P5 of yolov5s 26.7 -> 34.4 us, P4 19.6 -> 25.5, yolov5l P4
     // 48.9 -> 65.5: the repeated LayerNorm and workgroup prologues cost more than the idle CUs.  a->reserved = 1 keeps it reachable for A/B.
     p.qkv_npass = a->reserved == 1 ? 1 : 3;
+    p.eps_a = a->eps_attn; p.eps_m = a->eps_mlp;
     for (int g = 0; g < 2; ++g) {
         p.c_res_a[g] = a->coef_res_attn[g]; p.c_acc_a[g] = a->coef_acc_attn[g];
         p.c_res_m[g] = a->coef_res_mlp[g]; p.c_acc_m[g] = a->coef_acc_mlp[g];
