@@ -781,8 +781,7 @@ class CrossTransformerBlock(HipModule):
             coef = dict(co=co, hidden=hid)
             qkv = plan.tokens(2, rows, 3 * C)
             att = plan.tokens(2, rows, C)
-            cus = ops.device_info()["cu_count"] if plan.device.type == "cuda" else 256
-            ks = ops.dmff_wide_ksplit(rows, C, hid, cus)           # few tiles, weights beyond an XCD's L2: hidden columns split over ks workgroups
+            ks = ops.dmff_wide_ksplit(N, C, hid)                   # few tokens per image, weights beyond an XCD's L2: hidden columns split over ks workgroups
             part = plan.empty((ks, 2, rows, C), torch.float32) if ks > 1 else None
             for it in range(nloops):
                 plan.add(ops.dmff_wide_ln_qkv(tok, qkv, p, ln, coef, p["eps"], B, N, self.crossatt.h))

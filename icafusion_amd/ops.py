@@ -648,19 +648,15 @@ DMFF_QKV_NPASS = int(os.environ.get("ICAF_DMFF_QKV_NPASS", "0"))   # A/B switch:
 DMFF_KSPLIT = int(os.environ.get("ICAF_DMFF_KSPLIT", "0"))       # A/B switch: 0 = automatic, 1 = never split the hidden columns, 2 / 4 = force
 
 
-def dmff_wide_ksplit(rows, C_, hidden, cu_count=256):
-    """Hidden-column split of icaf_dmff_wide_proj_mlp_split for this level: 1 (one workgroup per 64-row tile) unless the tiles of both
-    modalities leave at least half of the CUs idle AND a modality's weights (9 C^2 16-bit elements) overflow an XCD's 4 MB L2 — P5 of
-    yolov5s at batch 32: 100 tiles for 256 CUs, 4.7 MB per modality."""
+def dmff_wide_ksplit(N, C_, hidden):
+    """Hidden-column split of icaf_dmff_wide_proj_mlp_split for a level: 2 where a modality's weights (9 C^2 16-bit elements) overflow an
+    XCD's 4 MB L2 AND the level has few tokens per image (N <= 128: P5 of yolov5s — 100 tokens, i.e. 100 tiles of 64 rows for 256 CUs at
+    batch 32, 4.7 MB of weights per modality), else 1.  Deliberately a function of the LEVEL (N, C), never of the batch size: the split
+    changes the fp32 association of the fc2 sum, and a shard of a batch must reproduce the same rows of the full batch bit for bit
+    (tests/test_gpu_fullsize.py; yolov5l's P4 — C = 512, N = 256, one tile per CU at batch 32 — measured slower with the split anyway)."""
     if DMFF_KSPLIT:
         return DMFF_KSPLIT if hidden % (256 * DMFF_KSPLIT) == 0 else 1
-    wgs = 2 * (-(-rows // 64))
-    if 9 * C_ * C_ * 2 <= 3 * 2 ** 20:
-        return 1
-    for ks in (4, 2):
-        if wgs * ks <= cu_count and hidden % (256 * ks) == 0:
-            return ks
-    return 1
+    return 2 if (9 * C_ * C_ * 2 > 3 * 2 ** 20 and N <= 128 and hidden % 512 == 0) else 1
 
 
 def dmff_wide_proj_mlp(x, att, y, packs, ln, coef, eps, B, N, heads, name="dmff_proj_mlp", partial=None, ksplit=1):

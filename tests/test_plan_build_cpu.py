@@ -83,8 +83,8 @@ def test_dmff_block_launch_structure_at_every_level(loops):
     assert blocks[1] == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp"] * loops
     assert blocks[2] == ["dmff_ln_qkv", "cross_attention", "dmff_proj_mlp", "dmff_proj_mlp_reduce"] * loops
     from icafusion_amd import ops
-    assert ops.dmff_wide_ksplit(32 * 100, 512, 2048, 256) == 2 and ops.dmff_wide_ksplit(2 * 100, 512, 2048, 256) == 4      # P5: batch 32 / batch 2
-    assert ops.dmff_wide_ksplit(32 * 256, 256, 1024, 256) == 1 and ops.dmff_wide_ksplit(32 * 256, 512, 2048, 256) == 1     # P4 of yolov5s / yolov5l: one tile per CU
+    assert ops.dmff_wide_ksplit(100, 512, 2048) == 2                                                      # P5 of yolov5s — at every batch size
+    assert ops.dmff_wide_ksplit(256, 256, 1024) == 1 and ops.dmff_wide_ksplit(256, 512, 2048) == 1        # P4 of yolov5s / yolov5l
     from icafusion_amd.models.common import CrossTransformerBlock
     try:
         CrossTransformerBlock.fuse_wide = False                  # A/B switch: the wide levels fall back to the per-layer launches
