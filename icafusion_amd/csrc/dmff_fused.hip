@@ -800,7 +800,7 @@ extern "C" int icaf_dmff_attn_mlp_lds_bytes(int C, int N, int heads, int dtype, 
 }
 
 extern "C" int icaf_dmff_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s) {
-    DmffP p;
+    DmffP p{};
     int st = fill(a, p, "icaf_dmff_ln_qkv");
     if (st) return st;
     if (!a->ln_attn_gamma[0] || !a->ln_attn_gamma[1] || !a->ln_attn_beta[0] || !a->ln_attn_beta[1]) return fail(ICAF_ERR_ARG, "icaf_dmff_ln_qkv: LayerNorm parameters missing");
@@ -809,7 +809,7 @@ extern "C" int icaf_dmff_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s) {
 }
 
 extern "C" int icaf_dmff_attn_mlp(const icaf_dmff_args* a, icaf_stream_t s) {
-    DmffP p;
+    DmffP p{};
     int st = fill(a, p, "icaf_dmff_attn_mlp");
     if (st) return st;
     if (!a->y || !a->wo || !a->bo || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ln_mlp_gamma || !a->ln_mlp_beta) return fail(ICAF_ERR_ARG, "icaf_dmff_attn_mlp: null pointer");

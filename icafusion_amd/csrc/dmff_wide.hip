@@ -600,7 +600,7 @@ static int launch_wide_reduce(const WideP& p, int ksplit, hipStream_t s) {
 using namespace icaf;
 
 extern "C" int icaf_dmff_wide_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s) {
-    WideP p;
+    WideP p{};          // (value-initialised: a field a later edit forgets to fill is zero, not stack garbage)
     int st = wide_fill(a, p, "icaf_dmff_wide_ln_qkv");
     if (st) return st;
     if (!a->qkv || !a->wqkv || !a->bqkv || !a->ln_attn_gamma[0] || !a->ln_attn_gamma[1] || !a->ln_attn_beta[0] || !a->ln_attn_beta[1])
@@ -609,7 +609,7 @@ extern "C" int icaf_dmff_wide_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s) {
 }
 
 extern "C" int icaf_dmff_wide_proj_mlp(const icaf_dmff_args* a, const void* att, icaf_stream_t s) {
-    WideP p;
+    WideP p{};          // (value-initialised: a field a later edit forgets to fill is zero, not stack garbage)
     int st = wide_fill(a, p, "icaf_dmff_wide_proj_mlp");
     if (st) return st;
     if (!att || !a->y || !a->wo || !a->bo || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ln_mlp_gamma || !a->ln_mlp_beta) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp: null pointer");
@@ -621,7 +621,7 @@ extern "C" int icaf_dmff_wide_proj_mlp(const icaf_dmff_args* a, const void* att,
 }
 
 extern "C" int icaf_dmff_wide_proj_mlp_split(const icaf_dmff_args* a, const void* att, float* partial, int ksplit, icaf_stream_t s) {
-    WideP p;
+    WideP p{};          // (value-initialised: a field a later edit forgets to fill is zero, not stack garbage)
     int st = wide_fill(a, p, "icaf_dmff_wide_proj_mlp_split");
     if (st) return st;
     if (!att || !partial || !a->y || !a->wo || !a->bo || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ln_mlp_gamma || !a->ln_mlp_beta) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp_split: null pointer");
@@ -635,7 +635,7 @@ extern "C" int icaf_dmff_wide_proj_mlp_split(const icaf_dmff_args* a, const void
 }
 
 extern "C" int icaf_dmff_wide_reduce(const icaf_dmff_args* a, const float* partial, int ksplit, icaf_stream_t s) {
-    WideP p;
+    WideP p{};          // (value-initialised: a field a later edit forgets to fill is zero, not stack garbage)
     int st = wide_fill(a, p, "icaf_dmff_wide_reduce");
     if (st) return st;
     if (!partial || !a->y || !a->b2) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_reduce: null pointer");

@@ -14,7 +14,15 @@
 //   * only the pixel operand travels by LDS-DMA (igemm's ring: 128-byte slices, XOR-swizzled through the source address, one
 //     barrier per slice, counted vmcnt) — 16 KiB per slice instead of 32, in a 4-stage ring: three slices in flight;
 //   * K order, MFMA step (32x32x16), bias / activation / residual epilogue (conv_common.h) are igemm's: bit-identical results.
-// Workgroup = NWV wavefronts = 128 pixels x 32 * NWV channels (NWV = 4: 128 x 128, NWV = 8: 128 x 256).
+// Workgroup = NWV wavefronts = 128 pixels x 32 * NWV * TN channels (NWV = 4: 128 x 128, NWV = 8: 128 x 256 with TN = 1).
+//
+// Round 4 — TN = 2: a wavefront owns TWO 32-channel blocks (64 channels x 128 pixels: eight accumulator tiles), so a pixel fragment read
+// from LDS feeds two MFMAs and the tile is twice as wide for the same pixel feed: 128 x 512 with eight wavefronts, 128 x 256 with four
+// (two workgroups per CU).  The pixel operand's LDS-DMA bytes per MAC are 2 / BN: at BN = 256 a K slice is 16 KiB of feed (~850 cycles at
+// the measured 18-20 bytes / clock / CU) against 1024 cycles of MFMAs per SIMD — co-limiting; at BN = 512 it is the same feed against 2048
+// cycles.  For the layers with 512 or more output channels (yolov5l's P4 / P5 rows, yolov5s's 20 x 20 rows).  Register budget: 128 accumulator
+// registers leave room for TWO weight buffers (one slice ahead: 32 MFMAs = 1024 cycles of cover) instead of three, so the counted wait of a step
+// leaves only that step's own pixel DMA outstanding.  Same K order / MFMA step / epilogue: bit-identical to every other configuration.
 #include "conv_common.h"
 
 // Ablation switches for timing studies (tools/quick_variant.py -DICAF_WREG_ABL=n; results are then meaningless):
@@ -27,17 +35,18 @@ namespace icaf {
 
 // MODE 1: 1x1 / stride 1 / pad 0 (plain row-major pixel matrix); MODE 2: any filter with Cin * bytes a multiple of 128 (a K slice
 // lies inside one tap: wave-uniform tap walk).  igemm.hip's address generators, pixel operand only.
-template <int DT, int NWV, int ACT, int MODE>
-__global__ __launch_bounds__(NWV * 64) void igemm_wreg_kernel(const ConvP p, const void* __restrict__ wfrag, const long long wf_gs) {
+template <int DT, int NWV, int ACT, int MODE, int TN = 1>
+__global__ __launch_bounds__(NWV * 64, (NWV == 4 && TN == 2) ? 2 : 1) void igemm_wreg_kernel(const ConvP p, const void* __restrict__ wfrag, const long long wf_gs) {
     using E = Elem<DT>;
     static_assert(DT != ICAF_F32, "16-bit types");
-    constexpr int BM = 128, BN = 32 * NWV, RB = 128, NS = 4, TM = 4;
+    constexpr int BM = 128, BN = 32 * NWV * TN, RB = 128, NS = 4, TM = 4;
+    constexpr int NB = TN == 1 ? 3 : 2;                                // weight register buffers: slices c, c + 1 (, c + 2)
     constexpr int VEC = E::VEC, BK = RB / E::BYTES;                  // 8, 64
     constexpr int RPI = 8, AI = BM / RPI, NA = AI / NWV;             // DMA instructions per slice: 16 per workgroup, 4 / 2 per wave
     constexpr int NSTEP = RB / 32;                                   // 4 MFMA steps (= weight fragments) per slice
-    constexpr int PER = NA + NSTEP;                                  // vector-memory operations per wave and slice step
+    constexpr int PER = NA + NSTEP * TN;                             // vector-memory operations per wave and slice step
     constexpr int STAGE = BM * RB;                                   // 16 KiB
-    static_assert(AI % NWV == 0 && 2 * PER <= 18, "tile shape / vmcnt immediate");
+    static_assert(AI % NWV == 0 && (TN == 1 ? 2 * PER : NA) <= 18, "tile shape / vmcnt immediate");
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -107,33 +116,38 @@ __global__ __launch_bounds__(NWV * 64) void igemm_wreg_kernel(const ConvP p, con
     // ---- weight operand: fragment-major [channel block of 32][MFMA step of 16 K][lane][8 elements]; this wave's channel block ----
     const int ksteps = p.Kp / 16;                                     // MFMA steps per channel block row
     const u32x4* __restrict__ wf = (const u32x4*)((const typename E::type*)wfrag + g * wf_gs)
-                                   + ((long long)(n0 / 32 + wave) * ksteps) * 64 + lane;
+                                   + ((long long)(n0 / 32 + wave * TN) * ksteps) * 64 + lane;      // the wave's first channel block (TN consecutive blocks)
     const int last_step = ksteps - 1;
-    auto load_w = [&](u32x4 (&dst)[NSTEP], int chunk) {               // unconditional, clamped: past the end the last fragments are re-read
+    auto load_w = [&](u32x4 (&dst)[NSTEP][TN], int chunk) {           // unconditional, clamped: past the end the last fragments are re-read
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             int ks = chunk * NSTEP + s;
             ks = ks < last_step ? ks : last_step;
-            if constexpr (ICAF_WREG_ABL & 1) dst[s] = u32x4{(unsigned)ks, (unsigned)lane, 0x3f803f80u, 0x3f803f80u};
-            else dst[s] = wf[(long long)ks * 64];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                if constexpr (ICAF_WREG_ABL & 1) dst[s][t] = u32x4{(unsigned)ks, (unsigned)lane, 0x3f803f80u, 0x3f803f80u};
+                else dst[s][t] = wf[((long long)t * ksteps + ks) * 64];
+            }
         }
     };
 
-    f32x16 acc[1][TM];
+    f32x16 acc[TN][TM];
 #pragma unroll
-    for (int b = 0; b < TM; ++b)
+    for (int t = 0; t < TN; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.0f;
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.0f;
 
     const int fkey = (l31 >> 1) & 7;
     int foff[NSTEP];
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) foff[s] = l31 * RB + (((2 * s + hi) ^ fkey) << 4);
 
-    // ---- prologue: weight fragments of slices 0, 1 -> registers; pixel slices 0 .. NS - 2 -> ring -------------------------------
-    u32x4 fw[3][NSTEP];
+    // ---- prologue: weight fragments of slices 0 (, 1) -> registers; pixel slices 0 .. NS - 2 -> ring ----------------------------
+    u32x4 fw[NB][NSTEP][TN];
     load_w(fw[0], 0);
-    load_w(fw[1], 1);
+    if constexpr (NB == 3) load_w(fw[1], 1);
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) {
         issue_a(s, 0, 1);
@@ -141,18 +155,24 @@ __global__ __launch_bounds__(NWV * 64) void igemm_wreg_kernel(const ConvP p, con
     }
     wait_vmcnt<0>();                              // (the steps below then always find "everything older than two steps" complete)
 
-    // One slice step.  P = c % 3 selects the register buffer of the weight fragments of slice c (compile-time: the K loop is
-    // unrolled by three).  Issues, in this order, the weight loads of slice c + 2 and the pixel DMA of slice c + NS - 1: exactly PER
+    // One slice step.  P = c % NB selects the register buffer of the weight fragments of slice c (compile-time: the K loop is
+    // unrolled by NB).  Issues, in this order, the weight loads of slice c + NB - 1 and the pixel DMA of slice c + NS - 1: exactly PER
     // vector-memory operations per wave — the counted wait below relies on that.
     auto step = [&](auto Ptag, int c) {
         constexpr int P = decltype(Ptag)::value;
-        // pixel slice c was issued in step c - 3 (or the prologue): complete once at most the 2 * PER operations of steps c - 2 and
-        // c - 1 are outstanding
-        wait_vmcnt<2 * PER>();
+        if constexpr (NB == 3) {
+            // pixel slice c was issued in step c - 3 (or the prologue): complete once at most the 2 * PER operations of steps c - 2 and
+            // c - 1 are outstanding (the weights of slice c were issued in step c - 2, before that step's pixel DMA)
+            wait_vmcnt<2 * PER>();
+        } else {
+            // two weight buffers: the weights of slice c were the FIRST operations of step c - 1; everything up to them is complete
+            // once at most that step's NA pixel-DMA instructions (issued after them) are outstanding — pixel slices c and c + 1 with it
+            wait_vmcnt<NA>();
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // (a) slice c visible to every wave, (b) stage (c - 1) % NS is free
         const unsigned char* a_s = lds + (c & (NS - 1)) * STAGE;
-        load_w(fw[(P + 2) % 3], c + 2);
+        load_w(fw[(P + NB - 1) % NB], c + NB - 1);
         const int sfree = (c + NS - 1) & (NS - 1);
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
@@ -163,7 +183,9 @@ __global__ __launch_bounds__(NWV * 64) void igemm_wreg_kernel(const ConvP p, con
                 else fp[b] = *(const u32x4*)(a_s + (b * 32) * RB + foff[s]);
             }
 #pragma unroll
-            for (int b = 0; b < TM; ++b) mma_step<DT>(acc[0][b], fw[P][s], fp[b]);
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) mma_step<DT>(acc[t][b], fw[P][s][t], fp[b]);
             issue_a(sfree, s, NSTEP);
         }
         advance_a();
@@ -172,26 +194,34 @@ __global__ __launch_bounds__(NWV * 64) void igemm_wreg_kernel(const ConvP p, con
     using P1 = std::integral_constant<int, 1>;
     using P2 = std::integral_constant<int, 2>;
     int c = 0;
-    for (; c + 3 <= p.nchunks; c += 3) {
-        step(P0{}, c);
-        step(P1{}, c + 1);
-        step(P2{}, c + 2);
+    if constexpr (NB == 3) {
+        for (; c + 3 <= p.nchunks; c += 3) {
+            step(P0{}, c);
+            step(P1{}, c + 1);
+            step(P2{}, c + 2);
+        }
+        if (c < p.nchunks) step(P0{}, c);
+        if (c + 1 < p.nchunks) step(P1{}, c + 1);
+    } else {
+        for (; c + 2 <= p.nchunks; c += 2) {
+            step(P0{}, c);
+            step(P1{}, c + 1);
+        }
+        if (c < p.nchunks) step(P0{}, c);
     }
-    if (c < p.nchunks) step(P0{}, c);
-    if (c + 1 < p.nchunks) step(P1{}, c + 1);
     wait_vmcnt<0>();                               // zero-fill slices issued past the end
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    epilogue<DT, DT, BM, BN, BM, 32, ACT, false>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
+    epilogue<DT, DT, BM, BN, BM, 32 * TN, ACT, false>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-const char* wreg_tag(int shape) { return shape == 1 ? "128x128" : shape == 2 ? "128x256" : "?"; }
+const char* wreg_tag(int shape) { return shape == 1 ? "128x128" : shape == 2 ? "128x256" : shape == 3 ? "128x512" : shape == 4 ? "128x256w4" : "?"; }
 
 int wreg_check(const icaf_conv_args* a, const ConvP& p, int shape) {
-    if (shape < 1 || shape > 2) return fail(ICAF_ERR_ARG, "igemm_wreg: unknown shape %d", shape);
+    if (shape < 1 || shape > 4) return fail(ICAF_ERR_ARG, "igemm_wreg: unknown shape %d", shape);
     if (!a->wf) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: no fragment-major weights (icaf_conv_args.wf)");
     if (a->dtype == ICAF_F32 || a->out_dtype != a->dtype) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: 16-bit types, out dtype == dtype");
     if ((a->Cin * 2) % 128) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: Cin * 2 bytes must be a multiple of 128 (Cin = %d)", a->Cin);
@@ -199,21 +229,25 @@ int wreg_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     if (p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: operand exceeds the 2 GiB buffer-descriptor range");
     if (a->Kp % 64) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: Kp must be a multiple of 64");
     if (((uintptr_t)a->wf & 15) || (a->wf_gs * 2) % 16) return fail(ICAF_ERR_ARG, "igemm_wreg: wf must be 16-byte aligned");
-    if (shape == 2 && a->Cout <= 128) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg 128x256: Cout = %d <= 128 (use 128x128)", a->Cout);
+    if ((shape == 2 || shape == 4) && a->Cout <= 128) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg 128x256: Cout = %d <= 128 (use 128x128)", a->Cout);
+    if (shape >= 3 && a->act == ICAF_ACT_GELU) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg %s: built for SiLU / linear layers", wreg_tag(shape));
+    if (shape == 3 && a->Cout <= 256) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg 128x512: Cout = %d <= 256 (use 128x256)", a->Cout);
+    // the fragment-major copy covers Np = Cout rounded up to 128 channels: a wider tile must not reach beyond it
+    const int bn = shape == 1 ? 128 : shape == 3 ? 512 : 256;
+    if ((long long)((a->Cout + bn - 1) / bn) * bn > ((long long)a->Cout + 127) / 128 * 128)
+        return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg %s: channel tiles reach beyond the packed weights (Cout = %d)", wreg_tag(shape), a->Cout);
     return ICAF_OK;
 }
 
-template <int DT, int NWV, int ACT>
+template <int DT, int NWV, int ACT, int TN = 1>
 static int launch_wreg_mode(const icaf_conv_args* a, const ConvP& p, int groups, hipStream_t s) {
-    constexpr int BN = 32 * NWV;
+    constexpr int BN = 32 * NWV * TN;
     constexpr int ring = 4 * 128 * 128, stage_out = TileLds<DT, DT, 128, BN>::OUT_BYTES;
     constexpr int LDS = ring > stage_out ? ring : stage_out;
     ConvP q = p;
     q.mtiles = (p.M + 127) / 128;
     q.ntiles = (p.Cout + BN - 1) / BN;
     q.nchunks = (p.K + 63) / 64;
-    // the fragment-major copy covers Np = Cout rounded up to 128 channels: a 256-wide tile must not reach beyond it
-    if ((long long)q.ntiles * BN > ((long long)p.Cout + 127) / 128 * 128) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: channel tiles reach beyond the packed weights (Cout = %d)", p.Cout);
     dim3 grid((unsigned)(q.mtiles * q.ntiles), 1, (unsigned)groups);
     const bool plain = q.kh == 1 && q.kw == 1 && q.sh == 1 && q.sw == 1 && q.ph == 0 && q.pw == 0;
     auto go = [&](auto kern) -> int {
@@ -222,22 +256,32 @@ static int launch_wreg_mode(const icaf_conv_args* a, const ConvP& p, int groups,
         ICAF_LAUNCH_CHECK();
         return ICAF_OK;
     };
-    if (plain) return go(igemm_wreg_kernel<DT, NWV, ACT, 1>);
-    return go(igemm_wreg_kernel<DT, NWV, ACT, 2>);
+    if (plain) return go(igemm_wreg_kernel<DT, NWV, ACT, 1, TN>);
+    return go(igemm_wreg_kernel<DT, NWV, ACT, 2, TN>);
 }
 
-template <int DT, int NWV>
+template <int DT, int NWV, int TN = 1>
 static int launch_wreg_act(const icaf_conv_args* a, const ConvP& p, int groups, hipStream_t s) {
-    if (p.act == ICAF_ACT_SILU) return launch_wreg_mode<DT, NWV, ICAF_ACT_SILU>(a, p, groups, s);
-    if (p.act == ICAF_ACT_GELU) return launch_wreg_mode<DT, NWV, ICAF_ACT_GELU>(a, p, groups, s);
-    return launch_wreg_mode<DT, NWV, ICAF_ACT_NONE>(a, p, groups, s);
+    if (p.act == ICAF_ACT_SILU) return launch_wreg_mode<DT, NWV, ICAF_ACT_SILU, TN>(a, p, groups, s);
+    if constexpr (TN == 1) { if (p.act == ICAF_ACT_GELU) return launch_wreg_mode<DT, NWV, ICAF_ACT_GELU, TN>(a, p, groups, s); }
+    else if (p.act == ICAF_ACT_GELU) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: the 64-channel-per-wave tiles are built for SiLU / linear layers");
+    return launch_wreg_mode<DT, NWV, ICAF_ACT_NONE, TN>(a, p, groups, s);
+}
+
+template <int DT>
+static int launch_wreg_shape(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s) {
+    switch (shape) {
+        case 1: return launch_wreg_act<DT, 4>(a, p, a->groups, s);
+        case 2: return launch_wreg_act<DT, 8>(a, p, a->groups, s);
+        case 3: return launch_wreg_act<DT, 8, 2>(a, p, a->groups, s);      // 128 x 512: eight waves x 64 channels
+        default: return launch_wreg_act<DT, 4, 2>(a, p, a->groups, s);     // 128 x 256: four waves x 64 channels
+    }
 }
 
 int launch_wreg(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s) {
     int st = wreg_check(a, p, shape);
     if (st) return st;
-    if (a->dtype == ICAF_BF16) return shape == 1 ? launch_wreg_act<ICAF_BF16, 4>(a, p, a->groups, s) : launch_wreg_act<ICAF_BF16, 8>(a, p, a->groups, s);
-    return shape == 1 ? launch_wreg_act<ICAF_F16, 4>(a, p, a->groups, s) : launch_wreg_act<ICAF_F16, 8>(a, p, a->groups, s);
+    return a->dtype == ICAF_BF16 ? launch_wreg_shape<ICAF_BF16>(a, p, shape, s) : launch_wreg_shape<ICAF_F16>(a, p, shape, s);
 }
 
 }  // namespace icaf

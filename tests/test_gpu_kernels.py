@@ -390,6 +390,15 @@ WREG_CASES = [
     (5, 20, 20, 512, 512, 1, 1, ops.ACT_SILU, False, 1, 2),     # 1x1, K = 8 slices (8 % 3 == 2), two 256-wide tiles
     (2, 20, 20, 1024, 512, 1, 1, ops.ACT_SILU, False, 2, 1),    # SPPF cv2, paired: K = 16 slices (16 % 3 == 1)
     (1, 13, 13, 64, 384, 3, 2, ops.ACT_SILU, False, 1, 2),      # 128 x 256 tile reaching beyond Cout: rejected (checked below)
+    # round 4: a wave owns 64 channels (two weight buffers, the K loop unrolled by two): 128 x 512 with eight waves (shape 3), 128 x 256 with four (4)
+    (3, 20, 20, 256, 512, 3, 1, ops.ACT_SILU, True, 1, 3),      # K = 36 slices (even), residual, ragged last pixel tile (1200 = 9 * 128 + 48)
+    (2, 40, 40, 128, 512, 3, 2, ops.ACT_SILU, False, 2, 3),     # stride 2, paired, K = 18 slices
+    (5, 20, 20, 512, 1024, 1, 1, ops.ACT_SILU, False, 1, 3),    # 1x1, two 512-wide tiles, K = 8 slices
+    (2, 17, 19, 192, 512, 1, 1, ops.ACT_NONE, True, 1, 3),      # K = 3 slices (odd: the tail step), linear, residual
+    (1, 9, 9, 64, 512, 1, 1, ops.ACT_SILU, False, 1, 3),        # ONE K slice, one ragged pixel tile
+    (3, 20, 20, 256, 256, 3, 1, ops.ACT_SILU, True, 2, 4),      # four waves x 64 channels, paired, residual, K = 36 slices
+    (2, 33, 31, 128, 512, 1, 1, ops.ACT_SILU, False, 1, 4),     # two 256-wide tiles, K = 2 slices
+    (1, 13, 13, 320, 256, 3, 2, ops.ACT_NONE, False, 1, 4),     # K = 45 slices (odd), stride 2, linear
 ]
 
 
@@ -397,8 +406,9 @@ WREG_CASES = [
 @pytest.mark.parametrize("case", WREG_CASES)
 def test_conv_weights_from_registers_kernel(case, dt):
     """igemm_wreg.hip vs torch, and BIT-EXACT vs the implicit-GEMM kernel.  The K loop is unrolled by three with a tail of 0-2
-    steps, the pixel ring is four stages deep, the weights come fragment-major straight from memory: the cases cover every tail
-    length, 1x1 / 3x3 / stride 2, residuals, ragged tiles, both tile widths and the paired (groups = 2) launch."""
+    steps (by two with a tail of 0-1 for the 64-channel-per-wave tiles), the pixel ring is four stages deep, the weights come
+    fragment-major straight from memory: the cases cover every tail length, 1x1 / 3x3 / stride 2, residuals, ragged tiles, all four
+    tile shapes and the paired (groups = 2) launch."""
     B, H, W, cin, cout, k, st, act, use_res, G, shape = case
     p_ = k // 2
     Ho, Wo = (H + 2 * p_ - k) // st + 1, (W + 2 * p_ - k) // st + 1
