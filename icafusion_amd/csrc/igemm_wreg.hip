@@ -35,17 +35,17 @@ namespace icaf {
 
 // MODE 1: 1x1 / stride 1 / pad 0 (plain row-major pixel matrix); MODE 2: any filter with Cin * bytes a multiple of 128 (a K slice
 // lies inside one tap: wave-uniform tap walk).  igemm.hip's address generators, pixel operand only.
-template <int DT, int NWV, int ACT, int MODE, int TN = 1>
+template <int DT, int NWV, int ACT, int MODE, int TN = 1, int BM_ = 128>
 __global__ __launch_bounds__(NWV * 64, (NWV == 4 && TN == 2) ? 2 : 1) void igemm_wreg_kernel(const ConvP p, const void* __restrict__ wfrag, const long long wf_gs) {
     using E = Elem<DT>;
     static_assert(DT != ICAF_F32, "16-bit types");
-    constexpr int BM = 128, BN = 32 * NWV * TN, RB = 128, NS = 4, TM = 4;
+    constexpr int BM = BM_, BN = 32 * NWV * TN, RB = 128, NS = 4, TM = BM / 32;      // (BM = 64: twice the workgroups for the layers with few pixels)
     constexpr int NB = TN == 1 ? 3 : 2;                                // weight register buffers: slices c, c + 1 (, c + 2)
     constexpr int VEC = E::VEC, BK = RB / E::BYTES;                  // 8, 64
     constexpr int RPI = 8, AI = BM / RPI, NA = AI / NWV;             // DMA instructions per slice: 16 per workgroup, 4 / 2 per wave
     constexpr int NSTEP = RB / 32;                                   // 4 MFMA steps (= weight fragments) per slice
     constexpr int PER = NA + NSTEP * TN;                             // vector-memory operations per wave and slice step
-    constexpr int STAGE = BM * RB;                                   // 16 KiB
+    constexpr int STAGE = BM * RB;                                   // 16 KiB (8 KiB at BM = 64)
     static_assert(AI % NWV == 0 && (TN == 1 ? 2 * PER : NA) <= 18, "tile shape / vmcnt immediate");
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
@@ -218,10 +218,13 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && TN == 2) ? 2 : 1) void igemm
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-const char* wreg_tag(int shape) { return shape == 1 ? "128x128" : shape == 2 ? "128x256" : shape == 3 ? "128x512" : shape == 4 ? "128x256w4" : "?"; }
+const char* wreg_tag(int shape) {
+    static const char* t[] = {"?", "128x128", "128x256", "128x512", "128x256w4", "64x256", "64x128"};
+    return shape >= 1 && shape <= 6 ? t[shape] : "?";
+}
 
 int wreg_check(const icaf_conv_args* a, const ConvP& p, int shape) {
-    if (shape < 1 || shape > 4) return fail(ICAF_ERR_ARG, "igemm_wreg: unknown shape %d", shape);
+    if (shape < 1 || shape > 6) return fail(ICAF_ERR_ARG, "igemm_wreg: unknown shape %d", shape);
     if (!a->wf) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: no fragment-major weights (icaf_conv_args.wf)");
     if (a->dtype == ICAF_F32 || a->out_dtype != a->dtype) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: 16-bit types, out dtype == dtype");
     if ((a->Cin * 2) % 128) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: Cin * 2 bytes must be a multiple of 128 (Cin = %d)", a->Cin);
@@ -229,23 +232,23 @@ int wreg_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     if (p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: operand exceeds the 2 GiB buffer-descriptor range");
     if (a->Kp % 64) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: Kp must be a multiple of 64");
     if (((uintptr_t)a->wf & 15) || (a->wf_gs * 2) % 16) return fail(ICAF_ERR_ARG, "igemm_wreg: wf must be 16-byte aligned");
-    if ((shape == 2 || shape == 4) && a->Cout <= 128) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg 128x256: Cout = %d <= 128 (use 128x128)", a->Cout);
+    if ((shape == 2 || shape == 4 || shape == 5) && a->Cout <= 128) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg 128x256: Cout = %d <= 128 (use 128x128)", a->Cout);
     if (shape >= 3 && a->act == ICAF_ACT_GELU) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg %s: built for SiLU / linear layers", wreg_tag(shape));
     if (shape == 3 && a->Cout <= 256) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg 128x512: Cout = %d <= 256 (use 128x256)", a->Cout);
     // the fragment-major copy covers Np = Cout rounded up to 128 channels: a wider tile must not reach beyond it
-    const int bn = shape == 1 ? 128 : shape == 3 ? 512 : 256;
+    const int bn = (shape == 1 || shape == 6) ? 128 : shape == 3 ? 512 : 256;
     if ((long long)((a->Cout + bn - 1) / bn) * bn > ((long long)a->Cout + 127) / 128 * 128)
         return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg %s: channel tiles reach beyond the packed weights (Cout = %d)", wreg_tag(shape), a->Cout);
     return ICAF_OK;
 }
 
-template <int DT, int NWV, int ACT, int TN = 1>
+template <int DT, int NWV, int ACT, int TN = 1, int BM = 128>
 static int launch_wreg_mode(const icaf_conv_args* a, const ConvP& p, int groups, hipStream_t s) {
     constexpr int BN = 32 * NWV * TN;
-    constexpr int ring = 4 * 128 * 128, stage_out = TileLds<DT, DT, 128, BN>::OUT_BYTES;
+    constexpr int ring = 4 * BM * 128, stage_out = TileLds<DT, DT, BM, BN>::OUT_BYTES;
     constexpr int LDS = ring > stage_out ? ring : stage_out;
     ConvP q = p;
-    q.mtiles = (p.M + 127) / 128;
+    q.mtiles = (p.M + BM - 1) / BM;
     q.ntiles = (p.Cout + BN - 1) / BN;
     q.nchunks = (p.K + 63) / 64;
     dim3 grid((unsigned)(q.mtiles * q.ntiles), 1, (unsigned)groups);
@@ -256,16 +259,16 @@ static int launch_wreg_mode(const icaf_conv_args* a, const ConvP& p, int groups,
         ICAF_LAUNCH_CHECK();
         return ICAF_OK;
     };
-    if (plain) return go(igemm_wreg_kernel<DT, NWV, ACT, 1, TN>);
-    return go(igemm_wreg_kernel<DT, NWV, ACT, 2, TN>);
+    if (plain) return go(igemm_wreg_kernel<DT, NWV, ACT, 1, TN, BM>);
+    return go(igemm_wreg_kernel<DT, NWV, ACT, 2, TN, BM>);
 }
 
-template <int DT, int NWV, int TN = 1>
+template <int DT, int NWV, int TN = 1, int BM = 128>
 static int launch_wreg_act(const icaf_conv_args* a, const ConvP& p, int groups, hipStream_t s) {
-    if (p.act == ICAF_ACT_SILU) return launch_wreg_mode<DT, NWV, ICAF_ACT_SILU, TN>(a, p, groups, s);
-    if constexpr (TN == 1) { if (p.act == ICAF_ACT_GELU) return launch_wreg_mode<DT, NWV, ICAF_ACT_GELU, TN>(a, p, groups, s); }
-    else if (p.act == ICAF_ACT_GELU) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: the 64-channel-per-wave tiles are built for SiLU / linear layers");
-    return launch_wreg_mode<DT, NWV, ICAF_ACT_NONE, TN>(a, p, groups, s);
+    if (p.act == ICAF_ACT_SILU) return launch_wreg_mode<DT, NWV, ICAF_ACT_SILU, TN, BM>(a, p, groups, s);
+    if constexpr (TN == 1 && BM == 128) { if (p.act == ICAF_ACT_GELU) return launch_wreg_mode<DT, NWV, ICAF_ACT_GELU, TN, BM>(a, p, groups, s); }
+    else if (p.act == ICAF_ACT_GELU) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: the round-4 tiles are built for SiLU / linear layers");
+    return launch_wreg_mode<DT, NWV, ICAF_ACT_NONE, TN, BM>(a, p, groups, s);
 }
 
 template <int DT>
@@ -274,7 +277,9 @@ static int launch_wreg_shape(const icaf_conv_args* a, const ConvP& p, int shape,
         case 1: return launch_wreg_act<DT, 4>(a, p, a->groups, s);
         case 2: return launch_wreg_act<DT, 8>(a, p, a->groups, s);
         case 3: return launch_wreg_act<DT, 8, 2>(a, p, a->groups, s);      // 128 x 512: eight waves x 64 channels
-        default: return launch_wreg_act<DT, 4, 2>(a, p, a->groups, s);     // 128 x 256: four waves x 64 channels
+        case 4: return launch_wreg_act<DT, 4, 2>(a, p, a->groups, s);      // 128 x 256: four waves x 64 channels
+        case 5: return launch_wreg_act<DT, 4, 2, 64>(a, p, a->groups, s);  //  64 x 256: four waves x 64 channels, half the pixels
+        default: return launch_wreg_act<DT, 4, 1, 64>(a, p, a->groups, s); //  64 x 128: four waves x 32 channels, half the pixels
     }
 }
 

@@ -399,6 +399,13 @@ WREG_CASES = [
     (3, 20, 20, 256, 256, 3, 1, ops.ACT_SILU, True, 2, 4),      # four waves x 64 channels, paired, residual, K = 36 slices
     (2, 33, 31, 128, 512, 1, 1, ops.ACT_SILU, False, 1, 4),     # two 256-wide tiles, K = 2 slices
     (1, 13, 13, 320, 256, 3, 2, ops.ACT_NONE, False, 1, 4),     # K = 45 slices (odd), stride 2, linear
+    # 64-pixel tiles (twice the workgroups for the layers with few pixels): 64 x 256 (shape 5), 64 x 128 (6)
+    (3, 20, 20, 256, 256, 3, 1, ops.ACT_SILU, True, 2, 5),      # paired, residual, K = 36 slices, ragged last tile (1200 = 18 * 64 + 48)
+    (2, 20, 20, 512, 512, 1, 1, ops.ACT_SILU, False, 1, 5),     # two 256-wide tiles, K = 8 slices
+    (1, 11, 13, 192, 256, 3, 2, ops.ACT_NONE, False, 1, 5),     # K = 27 slices (odd), stride 2, linear
+    (3, 20, 20, 256, 128, 3, 1, ops.ACT_SILU, True, 2, 6),      # 64 x 128: three weight buffers, K = 36 slices (36 % 3 == 0)
+    (2, 20, 20, 512, 384, 1, 1, ops.ACT_SILU, False, 1, 6),     # three channel tiles, K = 8 slices (8 % 3 == 2)
+    (1, 9, 9, 64, 136, 1, 1, ops.ACT_NONE, True, 1, 6),         # ragged M and N, ONE K slice
 ]
 
 
