@@ -233,7 +233,7 @@ int wreg_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     if (a->Kp % 64) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: Kp must be a multiple of 64");
     if (((uintptr_t)a->wf & 15) || (a->wf_gs * 2) % 16) return fail(ICAF_ERR_ARG, "igemm_wreg: wf must be 16-byte aligned");
     if ((shape == 2 || shape == 4 || shape == 5) && a->Cout <= 128) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg 128x256: Cout = %d <= 128 (use 128x128)", a->Cout);
-    if (shape >= 3 && a->act == ICAF_ACT_GELU) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg %s: built for SiLU / linear layers", wreg_tag(shape));
+    if (shape == 3 && a->act == ICAF_ACT_GELU) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg %s: built for SiLU / linear layers", wreg_tag(shape));
     if (shape == 3 && a->Cout <= 256) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg 128x512: Cout = %d <= 256 (use 128x256)", a->Cout);
     // the fragment-major copy covers Np = Cout rounded up to 128 channels: a wider tile must not reach beyond it
     const int bn = (shape == 1 || shape == 6) ? 128 : shape == 3 ? 512 : 256;
@@ -266,8 +266,9 @@ static int launch_wreg_mode(const icaf_conv_args* a, const ConvP& p, int groups,
 template <int DT, int NWV, int TN = 1, int BM = 128>
 static int launch_wreg_act(const icaf_conv_args* a, const ConvP& p, int groups, hipStream_t s) {
     if (p.act == ICAF_ACT_SILU) return launch_wreg_mode<DT, NWV, ICAF_ACT_SILU, TN, BM>(a, p, groups, s);
-    if constexpr (TN == 1 && BM == 128) { if (p.act == ICAF_ACT_GELU) return launch_wreg_mode<DT, NWV, ICAF_ACT_GELU, TN, BM>(a, p, groups, s); }
-    else if (p.act == ICAF_ACT_GELU) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg: the round-4 tiles are built for SiLU / linear layers");
+    if constexpr (NWV == 4) { if (p.act == ICAF_ACT_GELU) return launch_wreg_mode<DT, NWV, ICAF_ACT_GELU, TN, BM>(a, p, groups, s); }
+    else if (p.act == ICAF_ACT_GELU && TN == 2) return fail(ICAF_ERR_UNSUPPORTED, "igemm_wreg 128x512: built for SiLU / linear layers");
+    if constexpr (NWV == 8 && TN == 1) { if (p.act == ICAF_ACT_GELU) return launch_wreg_mode<DT, NWV, ICAF_ACT_GELU, TN, BM>(a, p, groups, s); }
     return launch_wreg_mode<DT, NWV, ICAF_ACT_NONE, TN, BM>(a, p, groups, s);
 }
 

@@ -315,15 +315,15 @@ def conv_candidates(a):
         cands.append(61)                     # weights fed from registers (igemm_wreg.hip): 128 x 128 ...
         if a.Cout > 128:
             cands.append(62)                 # ... and 128 x 256
-        if a.act != ACT_GELU:                # a wave owns 64 channels (round 4): the pixel feed per MAC halves
+        # round 4: a wave owns 64 channels — the pixel feed per MAC halves
+        if a.Cout > 128 and a.Cout % 256 == 0:
+            cands.append(64)                 # 128 x 256 with four waves: two workgroups per CU
+        if a.Cout > 256 and a.Cout % 512 == 0 and a.act != ACT_GELU:
+            cands.append(63)                 # 128 x 512 with eight waves
+        if a.B * a.Ho * a.Wo * a.groups <= 64 * 1024:      # few pixels (the 20 x 20 rows at batch 32): 64-pixel tiles double the workgroups
+            cands.append(66)                 # 64 x 128, four waves x 32 channels
             if a.Cout > 128 and a.Cout % 256 == 0:
-                cands.append(64)             # 128 x 256 with four waves: two workgroups per CU
-            if a.Cout > 256 and a.Cout % 512 == 0:
-                cands.append(63)             # 128 x 512 with eight waves
-            if a.B * a.Ho * a.Wo * a.groups <= 64 * 1024:      # few pixels (the 20 x 20 rows at batch 32): 64-pixel tiles double the workgroups
-                cands.append(66)             # 64 x 128, four waves x 32 channels
-                if a.Cout > 128 and a.Cout % 256 == 0:
-                    cands.append(65)         # 64 x 256, four waves x 64 channels
+                cands.append(65)             # 64 x 256, four waves x 64 channels
     if (a.kh, a.kw, a.ph, a.pw) == (3, 3, 1, 1) and a.act == ACT_SILU and a.out_dtype == a.dtype and not a.pre and not a.w2:
         for shape, (bn, stride) in CTILE_SHAPES.items():       # 3x3 direct convolution from an LDS halo patch
             if a.sh == stride and a.sw == stride and a.Cout <= bn and (bn < 64 or a.Cout > bn // 2):

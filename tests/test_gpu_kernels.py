@@ -406,6 +406,9 @@ WREG_CASES = [
     (3, 20, 20, 256, 128, 3, 1, ops.ACT_SILU, True, 2, 6),      # 64 x 128: three weight buffers, K = 36 slices (36 % 3 == 0)
     (2, 20, 20, 512, 384, 1, 1, ops.ACT_SILU, False, 1, 6),     # three channel tiles, K = 8 slices (8 % 3 == 2)
     (1, 9, 9, 64, 136, 1, 1, ops.ACT_NONE, True, 1, 6),         # ragged M and N, ONE K slice
+    (2, 10, 10, 256, 1024, 1, 1, ops.ACT_GELU, False, 2, 4),    # an MLP's fc1 (GELU epilogue) on the four-wave 64-channel tile, paired
+    (2, 10, 10, 256, 512, 1, 1, ops.ACT_GELU, False, 1, 5),     # ... and on the 64-pixel tiles
+    (1, 10, 10, 128, 384, 1, 1, ops.ACT_GELU, True, 1, 6),
 ]
 
 
