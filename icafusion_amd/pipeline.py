@@ -41,7 +41,10 @@ class DetectionPipeline:
         # forward (20x20 layers, DMFF, Detect: launches that leave CUs idle) overlap the full-width layers of the next
         self.depth = max(1, int(depth)) if overlap else 1         # overlap=False is the strictly sequential baseline: one batch, one stream
         self.plans = [model.plan_for(batch, height, width, self.device, u8=self.u8, slot=s) for s in range(self.depth)]
-        self.copy_stream = torch.cuda.Stream(device=self.device) if self.u8 else None
+        # (a HIGH-PRIORITY stream: HIP maps the streams of a process onto a few hardware queues, and a copy stream that shares its queue with
+        #  a forward stream waits behind that stream's graph — the copies then do not overlap the forwards at all; priority streams get
+        #  queues of their own)
+        self.copy_stream = torch.cuda.Stream(device=self.device, priority=-1) if self.u8 else None
         self.stage = [torch.empty_like(self.plans[0].inputs[0]) for _ in range(self.depth + 1)] if self.u8 else []
         self.copied = [torch.cuda.Event() for _ in self.stage]
         self.stage_free = [torch.cuda.Event() for _ in self.stage]

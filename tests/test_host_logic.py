@@ -150,6 +150,11 @@ def test_pmc_summary_kernel_names_match_bench_names():
         "void icaf::igemm_stream_kernel<1, 128, 1>(icaf::ConvP)": "igemm_stream_bf16_128x128",
         "void icaf::igemm_stream_kernel<2, 64, 0>(icaf::ConvP)": "igemm_stream_f16_128x64",
         "void icaf::igemm_wreg_kernel<1, 8, 1, 2>(icaf::ConvP, void const*, long long)": "igemm_wreg_bf16_128x256",
+        "void icaf::igemm_wreg_kernel<1, 8, 1, 2, 1, 128>(icaf::ConvP, void const*, long long)": "igemm_wreg_bf16_128x256",
+        "void icaf::igemm_wreg_kernel<1, 4, 1, 2, 2, 128>(icaf::ConvP, void const*, long long)": "igemm_wreg_bf16_128x256w4",
+        "void icaf::igemm_wreg_kernel<2, 4, 0, 1, 1, 64>(icaf::ConvP, void const*, long long)": "igemm_wreg_f16_64x128",
+        "void icaf::igemm_wreg_kernel<1, 4, 1, 1, 2, 64>(icaf::ConvP, void const*, long long)": "igemm_wreg_bf16_64x256",
+        "void icaf::igemm_wreg_kernel<1, 8, 1, 1, 2, 128>(icaf::ConvP, void const*, long long)": "igemm_wreg_bf16_128x512",
         "void icaf::detect_conv_kernel<1, 3, 6>(icaf::ConvP, icaf::DetectEpi<3, 6>)": "detect_conv+decode",
         "void icaf::detect_decode_kernel<true>(float const*, int, float*)": "detect_decode",
         "void icaf::upsample_kernel<true>(unsigned int __vector(4) const*, int)": "upsample_nearest",
@@ -245,7 +250,7 @@ def test_committed_tune_caches_only_name_configurations_the_tuner_would_time():
             cw = act == ops.ACT_SILU and bool(ops.cwide_shapes(kh, kw, sh, sw, kh // 2, kw // 2, cin, cout))
             wf = (dtype != ops.F32 and out_dtype == dtype and (cin * 2) % 128 == 0 and not pre and ((not cout2 and cout > 64) or cw))   # ops.conv2d's rule
             a = SimpleNamespace(Cout=cout, Cin=cin, kh=kh, kw=kw, sh=sh, sw=sw, ph=kh // 2, pw=kw // 2, dtype=dtype, out_dtype=out_dtype,
-                                act=act, pre=bool(pre), w2=bool(cout2), Cout2=cout2, res=bool(res), wf=wf, groups=groups)
+                                act=act, pre=bool(pre), w2=bool(cout2), Cout2=cout2, res=bool(res), wf=wf, groups=groups, B=1, Ho=1, Wo=M)
             assert tile in ops.conv_candidates(a), (os.path.basename(f), key, tile)
             assert ldy >= cout and ldx >= cin and M > 0 and groups in (1, 2)
             n += 1

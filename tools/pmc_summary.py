@@ -28,10 +28,12 @@ def short(name):
     if m:
         dt, bn = map(int, m.groups())
         return f"igemm_stream_{_DN[dt]}_128x{bn}"
-    m = re.match(r"icaf::igemm_wreg_kernel<(\d+), (\d+)(?:, \w+)*>", name)           # weight operand fed from registers
+    m = re.match(r"icaf::igemm_wreg_kernel<(\d+), (\d+), \d+, \d+(?:, (\d+))?(?:, (\d+))?>", name)           # weight operand fed from registers (DT, NWV, ACT, MODE, TN, BM)
     if m:
-        dt, nwv = map(int, m.groups())
-        return f"igemm_wreg_{_DN[dt]}_128x{32 * nwv}"
+        dt, nwv = int(m.group(1)), int(m.group(2))
+        tn, bm = int(m.group(3) or 1), int(m.group(4) or 128)
+        tag = {(4, 1, 128): "128x128", (8, 1, 128): "128x256", (8, 2, 128): "128x512", (4, 2, 128): "128x256w4", (4, 2, 64): "64x256", (4, 1, 64): "64x128"}.get((nwv, tn, bm), f"{bm}x{32 * nwv * tn}")
+        return f"igemm_wreg_{_DN[dt]}_{tag}"                                    # (= wreg_tag() of igemm_wreg.hip, what bench.py reports)
     m = re.match(r"icaf::cstream_kernel<(\d+), (true|false)>", name)              # persistent 3x3, filter resident in LDS
     if m:
         return f"cstream_{_DN[int(m.group(1))]}_8x16n64"                        # (with or without the chained 1x1: one name, as bench.py reports it)
