@@ -104,6 +104,7 @@ _FRAG_CACHE = {}              # id(packed tensor) -> (weakref to it, fragment-ma
 CWIDE = os.environ.get("ICAF_CWIDE", "1") != "0"               # A/B switch: resident-patch / streamed-weights 3x3 kernel (cwide.hip) as a tuner candidate
 CSTREAM = os.environ.get("ICAF_CSTREAM", "1") != "0"           # A/B switch: persistent resident-filter 3x3 kernel as a tuner candidate
 WREG_GEMM = os.environ.get("ICAF_WREG_GEMM", "1") != "0"       # A/B switch: weights-from-registers kernels as tuner candidates
+WREG64_MAXPIX = int(os.environ.get("ICAF_WREG64_MAXPIX", str(128 * 1024)))     # launches with at most this many pixels are offered the 64-pixel wreg tiles
 
 
 def frag_weights(w_packed):
@@ -320,7 +321,7 @@ def conv_candidates(a):
             cands.append(64)                 # 128 x 256 with four waves: two workgroups per CU
         if a.Cout > 256 and a.Cout % 512 == 0 and a.act != ACT_GELU:
             cands.append(63)                 # 128 x 512 with eight waves
-        if a.B * a.Ho * a.Wo * a.groups <= 64 * 1024:      # few pixels (the 20 x 20 rows at batch 32): 64-pixel tiles double the workgroups
+        if a.B * a.Ho * a.Wo * a.groups <= WREG64_MAXPIX:  # few pixels (the 20 x 20 / 40 x 40 rows at batch 32): 64-pixel tiles double the workgroups
             cands.append(66)                 # 64 x 128, four waves x 32 channels
             if a.Cout > 128 and a.Cout % 256 == 0:
                 cands.append(65)             # 64 x 256, four waves x 64 channels
