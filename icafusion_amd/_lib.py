@@ -30,6 +30,7 @@ class ConvArgs(C.Structure):
         ("w2_gs", C.c_longlong), ("bias2_gs", C.c_longlong), ("y2_gs", C.c_longlong),
         ("Kp2", C.c_int), ("Cout2", C.c_int), ("ldy2", C.c_int), ("chain_keep", C.c_int),
         ("wf", C.c_void_p), ("wf_gs", C.c_longlong),
+        ("x2", C.c_void_p), ("x2_gs", C.c_longlong), ("ldx2", C.c_int), ("reserved2", C.c_int),
     ]
 
 

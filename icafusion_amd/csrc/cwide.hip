@@ -14,7 +14,11 @@
 //   * wave w owns output channels [32 w, 32 w + 32) of the block and ALL the 4 x 8 sub-tiles: one weight fragment feeds NSUB MFMAs,
 //     and the fragments come from the fragment-major copy of the packed filter (icaf.h: icaf_conv_args.wf; one coalesced 16-byte
 //     load per lane = one MFMA A operand), three 4-step slices ahead in registers: no weight ring, no barrier inside the K loop;
-//   * the chained 1x1 (128 -> <= 128) takes its weights through the same per-wave stream.
+//   * the chained 1x1 (128 -> <= 128) takes its weights through the same per-wave stream;
+//   * CHAIN = 2, the C3 TAIL (round 4): the block's LAST Bottleneck carries the C3's cv3 (models/common.py:226,
+//     cv3(cat(m(cv1(x)), cv2(x)))): the completed m tile stays in the staging tile, the cv2 half of the same pixels (icaf.h:
+//     icaf_conv_args.x2) is parked beside it, and the 1x1 over K = [m | cv2] = 256 -> 256 channels runs as two 128-channel passes
+//     through the same weight ring — m is never written, cat(m, cv2) never read, one launch less per C3.
 // K walks (ky, kx, cin) in igemm's order with igemm's MFMA step, and the epilogue repeats the shared epilogue's expressions (bias +
 // SiLU on the fp32 accumulator, rounding to the storage type, residual added to the rounded value, chained 1x1 on the tile as
 // stored): results are bit-identical to every other launch configuration of the layer (tests/test_gpu_fullsize.py).
@@ -63,6 +67,9 @@ template <int CIN, int STR, int NSUB> struct CwTile {
     static constexpr int KSTEPS = 9 * CIN / 16, NSLICE = KSTEPS / CW_SL;
     static constexpr int LDS = PATCH > NPX * CW_SO ? PATCH : NPX * CW_SO;
     static constexpr int WG_PER_CU = (160 * 1024) / LDS >= 3 ? 3 : (160 * 1024) / LDS >= 2 ? 2 : 1;
+    // C3 tail: the m tile and the cv2 tile side by side once the K loop is done
+    static constexpr int LDS_TAIL = PATCH > 2 * NPX * CW_SO ? PATCH : 2 * NPX * CW_SO;
+    static constexpr int WG_PER_CU_TAIL = (160 * 1024) / LDS_TAIL >= 3 ? 3 : (160 * 1024) / LDS_TAIL >= 2 ? 2 : 1;
     static_assert(CIN == 64 || CIN == 128, "entries of 128 or 256 bytes");
     static_assert(NSLICE % CW_DEPTH == 0, "the register ring rotates statically");
 };
@@ -79,8 +86,8 @@ __device__ long long icaf_cw_stamps[32];
 #define CW_STAMP(i) do {} while (0)
 #endif
 
-template <int DT, int CIN, int STR, int NSUB, bool CHAIN>
-__global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwide_kernel(const ConvP p, const CwGeom gm, const void* __restrict__ wfrag,
+template <int DT, int CIN, int STR, int NSUB, int CHAIN>         // CHAIN: 0 = none, 1 = chained 1x1 over the tile, 2 = C3 tail (cv3 over [tile | x2])
+__global__ __launch_bounds__(256, (CHAIN == 2 ? CwTile<CIN, STR, NSUB>::WG_PER_CU_TAIL : CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwide_kernel(const ConvP p, const CwGeom gm, const void* __restrict__ wfrag,
                                                                                     const long long wf_gs) {
     using E = Elem<DT>;
     using T = typename E::type;
@@ -93,6 +100,7 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     unsigned char* patch = lds;
     unsigned char* stg = lds;                                        // the output tile is staged over the patch once the K loop is done
+    unsigned char* stgb = lds + G::NPX * CW_SO;                      // C3 tail: the cv2 half of cv3's input, then the second half of its output
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = 32-channel group of the block
@@ -203,15 +211,25 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
             rres[it] = *(const u32x4*)(rg + (long long)(m < 0 ? 0 : m) * p.ldr + n0 + cv * VEC);
         }
     }
+    u32x4 xcat[CHAIN == 2 ? NIT : 1];                                // C3 tail: the cv2 vectors of the same positions, likewise in flight
+    if constexpr (CHAIN == 2) {
+        const T* __restrict__ x2g = (const T*)p.x2 + g * p.x2_gs;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
+            const int m = row_to_m(row);
+            xcat[it] = *(const u32x4*)(x2g + (long long)(m < 0 ? 0 : m) * p.ldx2 + cv * VEC);
+        }
+    }
     f32x4 bq[4], bq2[4];
+    const float* __restrict__ bias2 = (CHAIN && p.bias2) ? p.bias2 + g * p.bias2_gs : nullptr;
     {
         const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
-        const float* __restrict__ bias2 = (CHAIN && p.bias2) ? p.bias2 + g * p.bias2_gs : nullptr;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const int n = wave * 32 + 8 * qd + 4 * hi;
             bq[qd] = bias ? *(const f32x4*)(bias + n0 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-            bq2[qd] = bias2 ? *(const f32x4*)(bias2 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (CHAIN != 2) bq2[qd] = bias2 ? *(const f32x4*)(bias2 + n) : f32x4{0.f, 0.f, 0.f, 0.f};      // (the tail asks for its 2 x 4 behind the K loop)
         }
     }
 
@@ -223,6 +241,13 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
         for (int r = 0; r < 16; ++r) acc[bb][r] = 0.0f;
     const T* w2f = nullptr;
     if constexpr (CHAIN) w2f = (const T*)p.w2 + g * p.w2_gs;
+    // slice c of the chained layer's weights — row-major packed [Np2][Kp2], lane (hi, r) of step ks2 reads w2[row + r][16 ks2 + 8 hi .. + 8].
+    // CHAIN 1: 2 slices (K = 128); tail: 8 slices, slice c = steps 4 (c >> 1) .. + 4 of channel pass c & 1 (K = 256, two 128-channel passes)
+    auto chain_slice = [&](int c, u32x4 (&dst)[CW_SL]) {
+        const int row = (CHAIN == 2 ? (c & 1) * CW_N : 0) + wave * 32 + l31, k0 = (CHAIN == 2 ? (c >> 1) : c) * CW_SL;
+#pragma unroll
+        for (int k = 0; k < CW_SL; ++k) dst[k] = *(const u32x4*)(w2f + (long long)row * p.Kp2 + (k0 + k) * 16 + hi * 8);
+    };
 #pragma unroll
     for (int sl = 0; sl < NSLICE; ++sl) {
         const int u = sl % CW_DEPTH;
@@ -248,13 +273,9 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
         if (sl + CW_DEPTH < NSLICE && !(ICAF_CW_ABL & 2)) {
 #pragma unroll
             for (int k = 0; k < CW_SL; ++k) wq[u][k] = wf[((sl + CW_DEPTH) * CW_SL + k) * 64];
-        } else if constexpr (CHAIN) {
-            const int c2 = sl + CW_DEPTH - NSLICE;                   // 0 .. 2: the chained 1x1 has 8 steps = 2 slices
-            if (c2 >= 0 && c2 < 2) {
-#pragma unroll
-                for (int k = 0; k < CW_SL; ++k)
-                    wq[u][k] = *(const u32x4*)(w2f + (long long)(wave * 32 + l31) * p.Kp2 + (c2 * CW_SL + k) * 16 + hi * 8);
-            }
+        } else if constexpr (CHAIN != 0) {
+            const int c2 = sl + CW_DEPTH - NSLICE;                   // 0 .. 2: the chained 1x1 has 8 steps = 2 slices, the C3 tail 8 slices
+            if (c2 >= 0 && c2 < (CHAIN == 2 ? CW_DEPTH : 2)) chain_slice(c2, wq[u]);      // (NSLICE % CW_DEPTH == 0: chain slice c sits in slot c % CW_DEPTH)
         }
         __builtin_amdgcn_sched_barrier(0);         // (left alone the scheduler hoists the fragment reads of several slices: registers)
     }
@@ -262,7 +283,7 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
     __syncthreads();                               // every wave has left the K loop: the patch may be overwritten by the staged tile
     CW_STAMP(4);
 
-    auto stage = [&](const f32x16 (&a)[NSUB], const f32x4 (&bv)[4], float scale) {
+    auto stage = [&](unsigned char* dst, const f32x16 (&a)[NSUB], const f32x4 (&bv)[4], float scale) {
 #pragma unroll
         for (int bb = 0; bb < NSUB; ++bb)
 #pragma unroll
@@ -274,13 +295,20 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
                 u32x2 pk;
                 if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
                 else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
-                *(u32x2*)(stg + (bb * 32 + l31) * CW_SO + nl * E::BYTES) = pk;
+                *(u32x2*)(dst + (bb * 32 + l31) * CW_SO + nl * E::BYTES) = pk;
             }
     };
-    stage(acc, bq, alpha_acc);
+    stage(stg, acc, bq, alpha_acc);
+    if constexpr (CHAIN == 2) {                    // the cv2 half of cv3's pixel operand beside the tile
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
+            *(u32x4*)(stgb + row * CW_SO + cv * 16) = xcat[it];
+        }
+    }
     __syncthreads();
     CW_STAMP(5);
-    if constexpr (!CHAIN) {
+    if constexpr (CHAIN == 0) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
@@ -321,30 +349,77 @@ __global__ __launch_bounds__(256, (CwTile<CIN, STR, NSUB>::WG_PER_CU)) void cwid
             }
         }
         __syncthreads();                           // the completed tile is visible
-        f32x16 acc2[NSUB];
-#pragma unroll
-        for (int bb = 0; bb < NSUB; ++bb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[bb][r] = 0.0f;
-#pragma unroll
-        for (int ks2 = 0; ks2 < CW_N / 16; ++ks2) {                  // K = 128 channels of the tile: eight MFMA steps
-            // (slice c2 = ks2 / 4 of the chained weights sits in ring slot (NSLICE + c2) % CW_DEPTH — the refill order above)
-            const int u = (NSLICE + ks2 / CW_SL) % CW_DEPTH, k = ks2 % CW_SL;
-#pragma unroll
-            for (int bb = 0; bb < NSUB; ++bb) {
-                const u32x4 fp2 = *(const u32x4*)(stg + (bb * 32 + l31) * CW_SO + ((2 * ks2 + hi) << 4));
-                mma_step<DT>(acc2[bb], wq[u][k], fp2);
-            }
-        }
-        __syncthreads();                           // the tile has been consumed
-        stage(acc2, bq2, 1.0f);
-        __syncthreads();
         T* __restrict__ y2g = (T*)p.y2 + g * p.y2_gs;
+        if constexpr (CHAIN == 1) {
+            f32x16 acc2[NSUB];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
-            const int m = row_to_m(row), n = cv * VEC;
-            if (m >= 0 && n < p.Cout2) *(u32x4*)(y2g + (long long)m * p.ldy2 + n) = *(const u32x4*)(stg + row * CW_SO + cv * 16);
+            for (int bb = 0; bb < NSUB; ++bb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[bb][r] = 0.0f;
+#pragma unroll
+            for (int ks2 = 0; ks2 < CW_N / 16; ++ks2) {                  // K = 128 channels of the tile: eight MFMA steps
+                // (slice c2 = ks2 / 4 of the chained weights sits in ring slot (NSLICE + c2) % CW_DEPTH — the refill order above)
+                const int u = (NSLICE + ks2 / CW_SL) % CW_DEPTH, k = ks2 % CW_SL;
+#pragma unroll
+                for (int bb = 0; bb < NSUB; ++bb) {
+                    const u32x4 fp2 = *(const u32x4*)(stg + (bb * 32 + l31) * CW_SO + ((2 * ks2 + hi) << 4));
+                    mma_step<DT>(acc2[bb], wq[u][k], fp2);
+                }
+            }
+            __syncthreads();                           // the tile has been consumed
+            stage(stg, acc2, bq2, 1.0f);
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
+                const int m = row_to_m(row), n = cv * VEC;
+                if (m >= 0 && n < p.Cout2) *(u32x4*)(y2g + (long long)m * p.ldy2 + n) = *(const u32x4*)(stg + row * CW_SO + cv * 16);
+            }
+        } else {
+            // C3 tail: y2 = SiLU(W3 . [m | cv2] + bias3), K = 256 in cv3's own order (sixteen MFMA steps: eight over the tile, eight over
+            // the cv2 half), two passes of 128 output channels with their own accumulators; the weights come through the ring as in the
+            // K loop (slice c in slot c % 3, refilled three slices ahead), one slice = four steps of one pass
+            f32x16 acc2[2][NSUB];
+#pragma unroll
+            for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+                for (int bb = 0; bb < NSUB; ++bb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[pz][bb][r] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int u = c % CW_DEPTH, pz = c & 1;
+#pragma unroll
+                for (int k = 0; k < CW_SL; ++k) {
+                    const int ks2 = (c >> 1) * CW_SL + k;
+                    const unsigned char* src = ks2 < 8 ? stg : stgb;
+                    u32x4 fp2[NSUB];
+#pragma unroll
+                    for (int bb = 0; bb < NSUB; ++bb) fp2[bb] = *(const u32x4*)(src + (bb * 32 + l31) * CW_SO + ((2 * (ks2 & 7) + hi) << 4));
+#pragma unroll
+                    for (int bb = 0; bb < NSUB; ++bb) mma_step<DT>(acc2[pz][bb], wq[u][k], fp2[bb]);
+                }
+                if (c + CW_DEPTH < 8) chain_slice(c + CW_DEPTH, wq[u]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x4 bz[2][4];                            // (asked for only now: 32 registers the 8 x 8 form does not have during the GEMM)
+#pragma unroll
+            for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd)
+                    bz[pz][qd] = bias2 ? *(const f32x4*)(bias2 + pz * CW_N + wave * 32 + 8 * qd + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
+            __syncthreads();                           // both tiles have been consumed
+            stage(stg, acc2[0], bz[0], 1.0f);
+            stage(stgb, acc2[1], bz[1], 1.0f);
+            __syncthreads();
+#pragma unroll
+            for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int idx = tid + it * 256, row = idx >> 4, cv = idx & 15;
+                    const int m = row_to_m(row), n = pz * CW_N + cv * VEC;
+                    if (m >= 0 && n < p.Cout2) *(u32x4*)(y2g + (long long)m * p.ldy2 + n) = *(const u32x4*)((pz ? stgb : stg) + row * CW_SO + cv * 16);
+                }
         }
     }
     if constexpr (ICAF_CW_PF > 0) asm volatile("" ::"v"(pfsink));
@@ -369,7 +444,14 @@ int cwide_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     if (!a->wf) return fail(ICAF_ERR_UNSUPPORTED, "cwide: needs the fragment-major weight copy (icaf_conv_args.wf)");
     if (p.x_bytes == 0) return fail(ICAF_ERR_UNSUPPORTED, "cwide: operand exceeds the 2 GiB buffer-descriptor range");
     if (!p.vec_y || (a->res && !p.vec_r)) return fail(ICAF_ERR_UNSUPPORTED, "cwide: y / res must take 16-byte vectors");
-    if (a->w2) {
+    if (a->x2) {          // C3 tail: cv3 over [this layer's tile | x2]
+        if (!a->w2) return fail(ICAF_ERR_ARG, "cwide: x2 without the chained layer's weights (w2)");
+        if (sh.s != 1 || sh.cin != 128) return fail(ICAF_ERR_UNSUPPORTED, "cwide %s: the C3 tail is built for the stride-1 128 -> 128 shapes (tile ids 81 / 82)", sh.tag);
+        if (a->Cout != CW_N || a->Cout2 != 2 * CW_N || a->Kp2 != 2 * CW_N || !p.vec_y2)
+            return fail(ICAF_ERR_UNSUPPORTED, "cwide: the C3 tail is a 1x1 of [128 | 128] -> 256 channels with Kp2 = 256 (Cout = %d, Cout2 = %d, Kp2 = %d)", a->Cout, a->Cout2, a->Kp2);
+        if (a->ldx2 < CW_N || a->ldx2 % 8 || ((uintptr_t)a->x2 & 15) || (a->x2_gs * 2) % 16) return fail(ICAF_ERR_ARG, "cwide: x2 must take 16-byte vectors (ldx2 = %d)", a->ldx2);
+        if (a->chain_keep) return fail(ICAF_ERR_UNSUPPORTED, "cwide: the C3 tail does not keep the intermediate tensor");
+    } else if (a->w2) {
         if (a->Cout != CW_N || a->Cout2 > CW_N || a->Cout2 % 32 || a->Kp2 != CW_N || !p.vec_y2) return fail(ICAF_ERR_UNSUPPORTED, "cwide: chained 1x1 of 128 -> (32, 64, 96 or 128) channels with Kp2 = 128");
         if (a->res && !a->chain_keep) return fail(ICAF_ERR_UNSUPPORTED, "cwide: a residual needs chain_keep");
         if (a->chain_keep && (a->alpha_acc[0] != 1.0f || a->alpha_acc[1] != 1.0f)) return fail(ICAF_ERR_UNSUPPORTED, "cwide: chain_keep with alpha_acc != 1");
@@ -377,22 +459,24 @@ int cwide_check(const icaf_conv_args* a, const ConvP& p, int shape) {
     return ICAF_OK;
 }
 
-template <int DT, int CIN, int STR, int NSUB, bool CHAIN>
+template <int DT, int CIN, int STR, int NSUB, int CHAIN>
 static int launch_cwide_cfg(const icaf_conv_args* a, const ConvP& p, hipStream_t s) {
     using G = CwTile<CIN, STR, NSUB>;
     CwGeom gm;
     gm.tiles_x = (p.Wo + G::TW - 1) / G::TW;
     gm.tiles_y = (p.Ho + CW_TH - 1) / CW_TH;
     gm.ntile = p.B * gm.tiles_x * gm.tiles_y;
-    ICAF_LDS_OPTIN((cwide_kernel<DT, CIN, STR, NSUB, CHAIN>), G::LDS);
-    cwide_kernel<DT, CIN, STR, NSUB, CHAIN><<<dim3((unsigned)gm.ntile, (unsigned)(a->Cout / CW_N), (unsigned)a->groups), dim3(256), G::LDS, s>>>(p, gm, a->wf, a->wf_gs);
+    constexpr int lds = CHAIN == 2 ? G::LDS_TAIL : G::LDS;
+    ICAF_LDS_OPTIN((cwide_kernel<DT, CIN, STR, NSUB, CHAIN>), lds);
+    cwide_kernel<DT, CIN, STR, NSUB, CHAIN><<<dim3((unsigned)gm.ntile, (unsigned)(a->Cout / CW_N), (unsigned)a->groups), dim3(256), lds, s>>>(p, gm, a->wf, a->wf_gs);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
 
 template <int DT, int CIN, int STR, int NSUB>
 static int launch_cwide_ch(const icaf_conv_args* a, const ConvP& p, hipStream_t s) {
-    return a->w2 ? launch_cwide_cfg<DT, CIN, STR, NSUB, true>(a, p, s) : launch_cwide_cfg<DT, CIN, STR, NSUB, false>(a, p, s);
+    if constexpr (CIN == 128 && STR == 1) { if (a->x2) return launch_cwide_cfg<DT, CIN, STR, NSUB, 2>(a, p, s); }      // (cwide_check let x2 through for these shapes only)
+    return a->w2 ? launch_cwide_cfg<DT, CIN, STR, NSUB, 1>(a, p, s) : launch_cwide_cfg<DT, CIN, STR, NSUB, 0>(a, p, s);
 }
 
 template <int DT>

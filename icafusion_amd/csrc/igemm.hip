@@ -26,8 +26,8 @@
 //     buffer-descriptor range and kept selectable for A/B measurements (configuration ids 11..14).
 #include "conv_common.h"
 
-static_assert(sizeof(icaf_conv_args) == 288, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
-static_assert(sizeof(icaf_bneck_args) == 352, "icaf_bneck_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
+static_assert(sizeof(icaf_conv_args) == 312, "icaf_conv_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
+static_assert(sizeof(icaf_bneck_args) == 376, "icaf_bneck_args layout is mirrored by ctypes in icafusion_amd/_lib.py");
 
 namespace icaf {
 
@@ -483,6 +483,7 @@ static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
         return (pipe != 1 && !dma_ok) ? a->tile % 10 + 10 : a->tile;
     }
     if (a->tile == 25 || a->tile == 26 || a->tile == 28 || a->tile == 29) return a->tile;          // validated in launch_tile
+    if (a->x2) return 81;                           // C3 tail: cwide.hip only (its check names what the layer must look like)
     const bool f32 = a->dtype == ICAF_F32 || a->out_dtype == ICAF_F32;
     const int N = a->Cout;
     const long long M = p.M;
@@ -643,6 +644,8 @@ static int validate(const icaf_conv_args* a) {
     if ((long long)a->B * a->Ho * a->Wo > 0x7fffffffLL) return fail(ICAF_ERR_ARG, "icaf_conv2d: too many output pixels");
     if (a->w2 && (!a->y2 || a->Cout2 < 1 || a->ldy2 < a->Cout2 || a->Kp2 < a->Cout || (a->Kp2 * (a->dtype == ICAF_F32 ? 4 : 2)) % 128 || ((uintptr_t)a->w2 & 15)))
         return fail(ICAF_ERR_ARG, "icaf_conv2d: chained 1x1 needs y2, ldy2 >= Cout2 >= 1, Kp2 >= Cout in whole 128-byte slices, aligned w2");
+    if (a->x2 && (!a->w2 || a->dtype == ICAF_F32 || a->Kp2 < 2 * a->Cout || a->ldx2 < a->Cout))
+        return fail(ICAF_ERR_ARG, "icaf_conv2d: x2 (the second half of the chained 1x1's input) needs w2, a 16-bit type, Kp2 >= 2 Cout and ldx2 >= Cout");
     if (a->pre && (a->pre_mode < 0 || a->pre_mode > 1)) return fail(ICAF_ERR_ARG, "icaf_conv2d: pre_mode must be 0 (bilinear) or 1 (nearest)");
     if (a->pre && (a->pre_h < 1 || a->pre_w < 1 || a->ldpre < a->Cout || (a->ldpre & 3) || ((uintptr_t)a->pre & 15) || a->groups != 1))
         return fail(ICAF_ERR_ARG, "icaf_conv2d: pre needs pre_h, pre_w >= 1, ldpre >= Cout and a multiple of 4, 16-byte alignment, groups == 1");
@@ -655,7 +658,7 @@ static void fill(const icaf_conv_args* a, ConvP& p) {
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.ldx = a->ldx; p.Ho = a->Ho; p.Wo = a->Wo; p.Cout = a->Cout;
     p.ldy = a->ldy; p.kh = a->kh; p.kw = a->kw; p.sh = a->sh; p.sw = a->sw; p.ph = a->ph; p.pw = a->pw; p.ldr = a->ldr;
     p.Kp = a->Kp; p.act = a->act;
-    p.x2 = nullptr; p.x2_gs = 0; p.ldx2 = 0;
+    p.x2 = a->x2; p.x2_gs = a->x2_gs; p.ldx2 = a->ldx2;      // (C3 tail, cwide.hip; icaf_bottleneck overwrites them with its own)
     p.M = a->B * a->Ho * a->Wo;
     p.K = a->kh * a->kw * a->Cin;
     const int bk = a->dtype == ICAF_F32 ? 16 : 32;
@@ -700,6 +703,7 @@ extern "C" int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s) {
     fill(a, p);
     const int tile = pick_tile(a, p);
     hipStream_t hs = S(s);
+    if (a->x2 && tile != 81 && tile != 82) return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: x2 (C3 tail) is built for launch configurations 81 / 82 only (tile %d)", tile);
     if (tile == 71) return launch_cstream(a, p, hs);        // persistent 3x3 with the filter resident in LDS (64 -> 64 channels)
     if (tile > 90) return launch_cwpers(a, p, tile - 90, hs); // the same, persistent: double-buffered patch, rolling weight stream (cwpers.hip)
     if (tile > 80) return launch_cwide(a, p, tile - 80, hs);  // 3x3 (stride 1 / 2) from a resident halo patch, weights streamed into registers
@@ -724,6 +728,7 @@ extern "C" int icaf_bottleneck(const icaf_bneck_args* b, icaf_stream_t s) {
     const int eb = a->dtype == ICAF_F32 ? 4 : 2;
     if (b->Kp1 * eb != 128) return fail(ICAF_ERR_ARG, "icaf_bottleneck: the packed 1x1 weights must have 128-byte rows (Kp1 = %d)", b->Kp1);
     if (a->pre) return fail(ICAF_ERR_ARG, "icaf_bottleneck: no pre-activation term");
+    if (a->x2) return fail(ICAF_ERR_ARG, "icaf_bottleneck: conv.x2 must be NULL (the block's cv2 half is icaf_bneck_args.x2)");
     if (a->x == a->y) return fail(ICAF_ERR_ARG, "icaf_bottleneck: in-place operation is not possible (neighbouring patches read x)");
     ConvP p;
     fill(a, p);
@@ -739,6 +744,7 @@ extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int b
     ConvP p;
     fill(a, p);
     const int tile = pick_tile(a, p);
+    if (a->x2 && tile != 81 && tile != 82) return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: x2 (C3 tail) is built for launch configurations 81 / 82 only (tile %d)", tile);
     static const char* dn[] = {"f32", "bf16", "f16"};
     if (tile == 71) {
         st = cstream_check(a, p);

@@ -157,10 +157,11 @@ class Conv(HipModule):
               (icaf.h).
         cin_slice: (k0, k1) — use only these input-channel columns of the weights (x then has k1 - k0 channels): the
               full-resolution half of a 1x1 conv over cat(up(a), b), whose other half arrives as the nearest pre_term.
-        chain: (convs, twin_convs, y2[, keep]) — 1x1 SiLU Convs (their outputs concatenated, e.g. the cv1 | cv2 of the C3
+        chain: (convs, twin_convs, y2[, keep[, x2]]) — 1x1 SiLU Convs (their outputs concatenated, e.g. the cv1 | cv2 of the C3
               behind a down-sampling Conv) applied to this layer's output tile inside the same launch; only y2 is written —
               unless keep is set: then `out` (residual included) is written too and the 1x1 consumes it as stored (a
-              Bottleneck's 3x3 followed by the next Bottleneck's 1x1).
+              Bottleneck's 3x3 followed by the next Bottleneck's 1x1).  x2: the chained Conv reads cat(this layer's output, x2)
+              (a C3's last Bottleneck carrying cv3, x2 = cv2's output: C3.emit).
         swap_halves: the input view holds the two halves of the layer's input channels in swapped order (C3 after an
               odd number of fused Bottlenecks): the weight columns are swapped to match when they are packed."""
         if self.conv.groups != 1 or self.conv.dilation != (1, 1):
@@ -249,6 +250,7 @@ class Conv(HipModule):
         if chain is not None:
             convs, twin_convs, y2 = chain[:3]
             keep = len(chain) > 3 and bool(chain[3])
+            x2 = chain[4] if len(chain) > 4 else None
             n2 = sum(c.conv.out_channels for c in convs)
 
             def pack2():
@@ -262,10 +264,13 @@ class Conv(HipModule):
                 return (torch.stack([p[0] for p in packs]).contiguous(), packs[0][1], torch.stack([p[2] for p in packs]).contiguous())
             w2p, kp2, b2p = self._cached(("chain",) + key_tail + tuple(id(c) for c in convs), pack2)
             ch = dict(w=w2p, kp=kp2, bias=b2p, y=y2, cout=n2, keep=keep)
+            if x2 is not None:
+                ch["x2"] = x2
             if not keep:
                 out = y2[..., :c2] if y2.shape[-1] >= c2 else plan.act(B, Ho, Wo, c2, pair=paired)   # (y is ignored by the kernel)
         plan.add(ops.conv2d(x, wp, kp, bp, out, kh, kw, sh, sw, ph, pw, c1, c2, self._act_code(), res=res,
-                            name=f"conv{kh}x{kw}s{sh}" + ("+1x1" if ch else ""), pre=pre_term, chain=ch, pre_nearest=pre_nearest))
+                            name=f"conv{kh}x{kw}s{sh}" + (("+cv3" if ch.get("x2") is not None else "+1x1") if ch else ""), pre=pre_term, chain=ch,
+                            pre_nearest=pre_nearest))
         return (out if ch["keep"] else y2) if ch else out
 
     fuse_stem2 = True    # stem + the 3x3/s2 Conv behind it + that Conv's chained cv1 | cv2 as ONE persistent kernel
@@ -329,6 +334,17 @@ class Conv(HipModule):
                 and isinstance(nxt.act, nn.SiLU) and k.kernel_size == (3, 3) and k.groups == 1 and k.in_channels % 64 == 0
                 and kn.kernel_size == (1, 1) and kn.stride == (1, 1) and kn.groups == 1 and kn.in_channels == k.out_channels
                 and max(k.out_channels, kn.out_channels) <= self.chain_max_width)
+
+    chain_tail = os.environ.get("ICAF_C3_TAIL", "1") != "0"      # A/B switch: a C3's cv3 rides on its last Bottleneck's 3x3 (a class default, as fuse_decode)
+
+    def chain_ok_tail(self, plan, cv3):
+        """Can the C3's cv3 (1x1 SiLU over cat(m, cv2)) ride on this 3x3 layer — the block's last Bottleneck.cv2 — so that neither m nor
+        the concatenation reach HBM?  (icaf_conv2d: x2; built in cwide.hip for 128 -> 128 layers with 256 output channels of cv3)"""
+        k, k3 = self.conv, cv3.conv
+        return (self.chain_tail and ops.CWIDE and plan.dtype in (torch.bfloat16, torch.float16) and isinstance(self.act, nn.SiLU)
+                and isinstance(cv3.act, nn.SiLU) and (k.kernel_size, k.stride, _pair(k.padding), k.groups) == ((3, 3), (1, 1), (1, 1), 1)
+                and (k.in_channels, k.out_channels) == (128, 128) and k3.kernel_size == (1, 1) and k3.stride == (1, 1) and k3.groups == 1
+                and _pair(k3.padding) == (0, 0) and k3.in_channels == 2 * k.out_channels and k3.out_channels == 256)
 
 
 class Bottleneck(HipModule):
@@ -486,6 +502,13 @@ class C3(HipModule):
             if nxt is not None and self.chain_bottlenecks and blk.cv2.chain_ok_1x1(plan, nxt.cv1):
                 t_next = plan.act(B, H, W, nxt.cv1.conv.out_channels, pair=paired)
                 ch = ((nxt.cv1,), (twin.m[j + 1].cv1,) if paired else None, t_next, True)
+            if j == len(self.m) - 1 and cur == 0 and blk.cv2.chain_ok_tail(plan, self.cv3):
+                # the block's tail as ONE launch: m = [a +] SiLU(conv3x3(t)) stays in the kernel's staging tile, cv3 reads [m | b] from there
+                # and from cv2's half of the buffer (icaf.h: icaf_conv_args.x2) — m is never written, cat(m, b) never read
+                if out is None:
+                    out = plan.act(B, H, W, k3.out_channels, pair=paired)
+                return blk.cv2.emit(plan, t, out=a, res=a if blk.add else None, twin=tw.cv2 if paired else None,
+                                    chain=((self.cv3,), (twin.cv3,) if paired else None, out, False, cat[..., c_:2 * c_]))
             blk.cv2.emit(plan, t, out=a, res=a if blk.add else None, twin=tw.cv2 if paired else None, chain=ch)
         src = cat[..., :2 * c_] if cur == 0 else cat[..., c_:3 * c_]
         return self.cv3.emit(plan, src, out=out, twin=twin.cv3 if paired else None, swap_halves=cur != 0)

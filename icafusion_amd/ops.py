@@ -101,6 +101,7 @@ def pack_conv_weight(w4d, dt, cin_pad=None):
 
 
 _FRAG_CACHE = {}              # id(packed tensor) -> (weakref to it, fragment-major copy); entries die with the packed tensor
+TAIL_8X16_MINPIX = int(os.environ.get("ICAF_TAIL_8X16_MINPIX", 200_000))     # conv_candidates: C3 tail, see there
 CWIDE = os.environ.get("ICAF_CWIDE", "1") != "0"               # A/B switch: resident-patch / streamed-weights 3x3 kernel (cwide.hip) as a tuner candidate
 CSTREAM = os.environ.get("ICAF_CSTREAM", "1") != "0"           # A/B switch: persistent resident-filter 3x3 kernel as a tuner candidate
 WREG_GEMM = os.environ.get("ICAF_WREG_GEMM", "1") != "0"       # A/B switch: weights-from-registers kernels as tuner candidates
@@ -185,7 +186,7 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
         assert pre.dtype == torch.float32 and Bp == B and cp >= cout and groups == 1
         a.pre, a.pre_h, a.pre_w, a.ldpre = pre.data_ptr(), hp, wp_, ldp
         a.pre_mode = int(bool(pre_nearest))     # nearest: the map is the low-resolution half of a 1x1 conv over cat(up(a), b)
-    if chain is not None:             # chained 1x1 + SiLU on the output tile (icaf.h): dict(w=, kp=, bias=, y=, cout=)
+    if chain is not None:             # chained 1x1 + SiLU on the output tile (icaf.h): dict(w=, kp=, bias=, y=, cout=[, keep=][, x2=])
         y2 = chain["y"]
         B2, H2, W2, c2y, ldy2 = _act_geom(y2)
         assert (B2, H2, W2) == (B, Ho, Wo) and c2y >= chain["cout"] and y2.dtype == x.dtype and (y2.dim() == 5) == (x.dim() == 5)
@@ -196,14 +197,22 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
         if x.dim() == 5:
             a.w2_gs, a.y2_gs = chain["w"].stride(0), y2.stride(0)
             a.bias2_gs = chain["bias"].stride(0) if chain.get("bias") is not None else 0
+        x2 = chain.get("x2")
+        if x2 is not None:            # C3 tail: the chained layer reads K = [this layer's tile | x2] (icaf.h: icaf_conv_args.x2)
+            Bx, Hx, Wx, cx2, ldx2 = _act_geom(x2)
+            assert (Bx, Hx, Wx) == (B, Ho, Wo) and cx2 >= cout and x2.dtype == x.dtype and (x2.dim() == 5) == (x.dim() == 5)
+            a.x2, a.ldx2, a.x2_gs = x2.data_ptr(), ldx2, (x2.stride(0) if x.dim() == 5 else 0)
     m = B * Ho * Wo
     flops = 2.0 * m * cout * kh * kw * cin * groups
     es, eo = x.element_size(), y.element_size()
     nbytes = groups * (B * H * W * cin * es + cout * kh * kw * cin * es + m * cout * eo
                        + (m * cout * es if res is not None else 0))
     if chain is not None:
-        flops += 2.0 * m * cout * chain["cout"] * groups
+        k2 = cout * (2 if chain.get("x2") is not None else 1)
+        flops += 2.0 * m * k2 * chain["cout"] * groups
         nbytes += groups * (m * chain["cout"] - (0 if chain.get("keep") else m * cout)) * eo      # y2 is written instead of / besides y
+        if chain.get("x2") is not None:
+            nbytes += groups * (m * cout + k2 * chain["cout"]) * es       # the x2 half of the chained layer's input, its weights
     return Launch(lib().icaf_conv2d, (C.byref(a),), keep=(a, x, w_packed, bias, y, res, pre, chain, wf), name=name, flops=flops,
                   nbytes=nbytes)
 
@@ -264,7 +273,7 @@ def cwide_shapes(kh, kw, sh, sw, ph, pw, cin, cout):
 
 def _conv_signature(a):
     return (a.B * a.Ho * a.Wo, a.Cout, a.Cin, a.kh, a.kw, a.sh, a.sw, a.H, a.W, a.ldx, a.ldy, a.groups, a.dtype,
-            a.out_dtype, a.act, bool(a.res), bool(a.pre) + a.pre_mode, a.Cout2 if a.w2 else 0, bool(a.chain_keep))
+            a.out_dtype, a.act, bool(a.res), bool(a.pre) + a.pre_mode, a.Cout2 if a.w2 else 0, 2 if a.x2 else bool(a.chain_keep))
 
 
 def conv_candidates(a):
@@ -275,7 +284,13 @@ def conv_candidates(a):
              and a.out_dtype == a.dtype and a.act == ACT_SILU and not a.pre and CSTREAM)
     cw = (cwide_shapes(a.kh, a.kw, a.sh, a.sw, a.ph, a.pw, a.Cin, a.Cout)
           if (a.dtype != F32 and a.wf and a.out_dtype == a.dtype and a.act == ACT_SILU and not a.pre and CWIDE) else [])
-    if a.w2:                           # chained 1x1: one N tile covering both layers, LDS-DMA pipelines 0 / 2
+    if a.w2 and a.x2:                  # C3 tail (the chained cv3 reads [tile | x2]): cwide.hip's 8 x 16 / 8 x 8 forms only
+        # Below ~200 k pixels per stream (the 40 x 40 maps of yolov5s at batch 32 / 64: one round of 8 x 16 tiles for the chip) only the 8 x 8
+        # form is offered: isolated timings prefer 8 x 16 there (2 workgroups of 252 registers and 70 KB per CU), but with a second forward in
+        # flight that form starves the co-running kernels — same-box A/B of the whole bench: 15,858 with 8 x 16 against 16,082 without the tail and
+        # 16,091 with 8 x 8 (3 workgroups of 168 registers and 35 KB).  The 80 x 80 / 160 x 160 maps of yolov5l have 4 - 16 x the tiles: tuned.
+        cands = ([82] if a.B * a.Ho * a.Wo < TAIL_8X16_MINPIX else [81, 82]) if CWIDE else []
+    elif a.w2:                         # chained 1x1: one N tile covering both layers, LDS-DMA pipelines 0 / 2
         t = 2 if max(a.Cout, a.Cout2) <= 64 else 1
         cands = [t, t + 20]
         if cw and a.Cout == 128 and a.Cout2 <= 128 and a.Cout2 % 32 == 0:

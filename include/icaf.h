@@ -145,6 +145,17 @@ typedef struct icaf_conv_args {
      * stride in elements.  16-bit types (icafusion_amd.ops.frag_weights builds it once per layer). */
     const void* wf;
     long long wf_gs;
+    /* Optional second half of the chained 1x1's input (NULL = none; needs w2): the chained layer then reads K = [this layer's output
+     * tile (Cout channels) | x2 (Cout more channels of the same pixels)]:
+     *   y2 = SiLU( W2 . cat( [alpha_res*res +] SiLU(A.W + bias), x2 ) + bias2 )
+     * This is the TAIL of a C3 block (models/common.py:216-227: cv3(cat(m(cv1(x)), cv2(x)))): the last Bottleneck's 3x3 (+ shortcut,
+     * `res` allowed without chain_keep) carries cv3, x2 = cv2's output; the Bottleneck chain's result and the concatenation never reach HBM.
+     * x2: NHWC, pixel stride ldx2 elements, x2_gs = group stride in elements; W2 packed [Np][Kp2] with K in cv3's own order [m | cv2].
+     * Built for 128 -> 128 3x3 / stride 1 layers with Cout2 = 256, Kp2 = 256, 16-bit types, launch configurations 81 / 82 (cwide.hip);
+     * bit-identical to the two launches. */
+    const void* x2;
+    long long x2_gs;
+    int ldx2, reserved2;
 } icaf_conv_args;
 
 int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s);

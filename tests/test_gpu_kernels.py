@@ -321,6 +321,82 @@ def test_conv3x3_resident_patch_streamed_weights_kernel(case, dt, shape):
             close(from_act(outs[0][1][g] if G == 2 else outs[0][1]), F.silu(F.conv2d(q(m, dt), q(w2s[g], dt), b2s[g])), dt, f"cwide chain {case}", factor=2.0)
 
 
+CWIDE_TAIL_CASES = [
+    # B, H, W, use_res, groups: the C3 tail — 3x3 128 -> 128 (+ shortcut) carrying cv3 over cat(m, x2) -> 256 channels (icaf_conv_args.x2)
+    (8, 40, 40, True, 2),        # backbone C3 at 40 x 40, both streams
+    (4, 40, 40, False, 1),       # head C3 (no shortcut)
+    (3, 21, 27, True, 1),        # ragged map: partial tiles on both edges
+    (1, 8, 16, False, 1),        # ONE tile
+    (32, 40, 40, True, 2),       # the bench's batch
+]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tile", [81, 82])
+@pytest.mark.parametrize("case", CWIDE_TAIL_CASES)
+def test_conv3x3_with_c3_tail_equals_two_launches(case, dt, tile):
+    """cwide.hip, CHAIN = 2: y2 = SiLU(W3 . cat([res +] SiLU(conv3x3(x)), x2) + b3) in one launch vs the 3x3 launch (igemm) followed by
+    the 1x1 launch over the materialised concatenation (igemm): BIT-EXACT (same K order [m | x2], MFMA step and epilogue expressions),
+    and close to torch on the rounded operands.  The intermediate m is not written (its buffer keeps the fill value)."""
+    B, H, W, use_res, G = case
+    c = 128
+    xs = [rnd((B, c, H, W), 271 + g) for g in range(G)]
+    ws = [rnd((c, c, 3, 3), 273 + g, 1.0 / math.sqrt(c * 9)) for g in range(G)]
+    bs = [rnd((c,), 275 + g, 0.2) for g in range(G)]
+    rs = [rnd((B, c, H, W), 277 + g) for g in range(G)] if use_res else None
+    x2s = [rnd((B, c, H, W), 279 + g) for g in range(G)]
+    w3s = [rnd((2 * c, 2 * c, 1, 1), 281 + g, 1.0 / math.sqrt(2 * c)) for g in range(G)]
+    b3s = [rnd((2 * c,), 283 + g, 0.2) for g in range(G)]
+    stk = (lambda t: torch.stack(t).contiguous()) if G == 2 else (lambda t: t[0])
+    shape = (G, B, H, W) if G == 2 else (B, H, W)
+    xa = stk([to_act(x, dt) for x in xs])
+    packs = [ops.pack_conv_weight(w.to(DEV), dt) for w in ws]
+    wp, kp = stk([p0[0] for p0 in packs]), packs[0][1]
+    bp = stk([ops.pack_bias(b.to(DEV), c) for b in bs])
+    ra = stk([to_act(r, dt) for r in rs]) if use_res else None
+    # the buffer cv3 reads in the two-launch form: [m | x2] (as C3.emit places them); the tail reads its x2 half in place
+    cat = torch.full(shape + (2 * c,), 7.0, dtype=dt, device=DEV)
+    for g in range(G):
+        (cat[g] if G == 2 else cat)[..., c:] = to_act(x2s[g], dt)
+    p3 = [ops.pack_conv_weight(w.to(DEV), dt) for w in w3s]
+    w3p, kp3 = stk([p0[0] for p0 in p3]), p3[0][1]
+    b3p = stk([ops.pack_bias(b.to(DEV), 2 * c) for b in b3s])
+    assert kp3 == 2 * c
+    # one launch
+    y_unused = torch.full(shape + (c,), 7.0, dtype=dt, device=DEV)
+    y2 = torch.full(shape + (2 * c + 8,), 7.0, dtype=dt, device=DEV)[..., :2 * c]
+    run(ops.conv2d(xa, wp, kp, bp, y_unused, 3, 3, 1, 1, 1, 1, c, c, ops.ACT_SILU, res=ra, tile=tile,
+                   chain=dict(w=w3p, kp=kp3, bias=b3p, y=y2, cout=2 * c, x2=cat[..., c:])))
+    assert bool((y_unused == 7.0).all()), "the intermediate tensor must not be written"
+    # two launches through igemm
+    run(ops.conv2d(xa, wp, kp, bp, cat[..., :c], 3, 3, 1, 1, 1, 1, c, c, ops.ACT_SILU, res=ra, tile=28))
+    y2_ref = torch.full(shape + (2 * c,), 7.0, dtype=dt, device=DEV)
+    run(ops.conv2d(cat, w3p, kp3, b3p, y2_ref, 1, 1, 1, 1, 0, 0, 2 * c, 2 * c, ops.ACT_SILU, tile=21))
+    assert torch.equal(y2, y2_ref), f"tail != two launches, max diff {(y2.float() - y2_ref.float()).abs().max().item()}"
+    for g in range(G):
+        m = F.silu(F.conv2d(q(xs[g], dt), q(ws[g], dt), bs[g], 1, 1))
+        if use_res:
+            m = m + q(rs[g], dt)
+        ref = F.silu(F.conv2d(torch.cat((q(m, dt), q(x2s[g], dt)), 1), q(w3s[g], dt), b3s[g]))
+        close(from_act(y2[g] if G == 2 else y2), ref, dt, f"cwide tail {case} group {g}", factor=2.0)
+
+
+def test_c3_tail_argument_checks():
+    """x2 without w2, on a launch configuration that is not built for it, or with a cv3 width other than 256: errors with a reason."""
+    from icafusion_amd._lib import IcafError
+    dt, c = torch.bfloat16, 128
+    x = torch.zeros((1, 8, 16, c), dtype=dt, device=DEV)
+    wp, kp = ops.pack_conv_weight(torch.zeros((c, c, 3, 3), device=DEV), dt)
+    w3p, kp3 = ops.pack_conv_weight(torch.zeros((2 * c, 2 * c, 1, 1), device=DEV), dt)
+    y, y2, x2 = torch.zeros_like(x), torch.zeros((1, 8, 16, 2 * c), dtype=dt, device=DEV), torch.zeros_like(x)
+    for tile in (21, 28, 91):
+        with pytest.raises(IcafError, match="x2"):
+            run(ops.conv2d(x, wp, kp, None, y, 3, 3, 1, 1, 1, 1, c, c, ops.ACT_SILU, tile=tile, chain=dict(w=w3p, kp=kp3, bias=None, y=y2, cout=2 * c, x2=x2)))
+    w1p, kp1 = ops.pack_conv_weight(torch.zeros((c, 2 * c, 1, 1), device=DEV), dt)
+    with pytest.raises(IcafError, match="256"):
+        run(ops.conv2d(x, wp, kp, None, y, 3, 3, 1, 1, 1, 1, c, c, ops.ACT_SILU, tile=81, chain=dict(w=w1p, kp=kp1, bias=None, y=y2[..., :c], cout=c, x2=x2)))
+
+
 CWIDE_S2_CASES = [
     # B, H, W, cin, cout, groups, chain cout2 (0 = none), tile id: stride-2 3x3 from a resident halo patch (even | odd column planes)
     (4, 160, 160, 64, 128, 2, 128, 83),      # backbone 160 -> 80 + the C3's cv1 | cv2 (chained 1x1), both backbones

@@ -319,6 +319,31 @@ def test_chained_bottlenecks_plan_is_bit_identical(name):
     assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("name,dtype,shape", [("yolov5s_Transfusion_kaist.yaml", torch.bfloat16, (2, 320, 352)),
+                                              ("yolov5s_Transfusion_kaist.yaml", torch.float16, (3, 352, 416)),
+                                              ("yolov5l_Transfusion_kaist.yaml", torch.bfloat16, (2, 320, 320))])
+def test_c3_tail_plan_is_bit_identical(name, dtype, shape):
+    """C3 blocks whose last Bottleneck is a 128 -> 128 3x3: cv3 rides on that launch (Conv.chain_tail; icaf_conv_args.x2) vs the
+    separate cv3 GEMM over cat(m, cv2): one launch less per such C3, identical network output (backbone blocks with the shortcut
+    and both streams in one launch, head blocks without)."""
+    B, H, W = shape
+    cfg, sd, m = build(name, 29, dtype)
+    rgb, ir = synth_images(B, H, W, seed=29)
+    outs, tails, counts = [], [], []
+    try:
+        for on in (True, False):
+            Conv.chain_tail = on
+            m.invalidate()
+            names = [l.name for l in m.plan_for(B, H, W).launches]
+            tails.append(names.count("conv3x3s1+cv3"))
+            counts.append(len(names))
+            outs.append(m(rgb.cuda(), ir.cuda())[0].clone())
+    finally:
+        Conv.chain_tail = True
+    assert tails[0] >= 2 and tails[1] == 0 and counts[1] - counts[0] == tails[0]
+    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_folded_upsample_matches_materialised_concat(dtype):
     """Head rows Upsample -> Concat -> C3 with the up-sampled half of the C3's 1x1 computed at low resolution

@@ -25,8 +25,8 @@ def test_library_exports_every_header_symbol():
     for name in declared:
         assert hasattr(handle, name)
     assert handle.icaf_version() >= 100
-    assert ctypes.sizeof(_lib.ConvArgs) == 288      # static_assert'ed on the C side (igemm.hip)
-    assert ctypes.sizeof(_lib.BneckArgs) == 352
+    assert ctypes.sizeof(_lib.ConvArgs) == 312      # static_assert'ed on the C side (igemm.hip)
+    assert ctypes.sizeof(_lib.BneckArgs) == 376
 
 
 def test_yaml_generator_is_in_sync():
@@ -250,7 +250,8 @@ def test_committed_tune_caches_only_name_configurations_the_tuner_would_time():
             cw = act == ops.ACT_SILU and bool(ops.cwide_shapes(kh, kw, sh, sw, kh // 2, kw // 2, cin, cout))
             wf = (dtype != ops.F32 and out_dtype == dtype and (cin * 2) % 128 == 0 and not pre and ((not cout2 and cout > 64) or cw))   # ops.conv2d's rule
             a = SimpleNamespace(Cout=cout, Cin=cin, kh=kh, kw=kw, sh=sh, sw=sw, ph=kh // 2, pw=kw // 2, dtype=dtype, out_dtype=out_dtype,
-                                act=act, pre=bool(pre), w2=bool(cout2), Cout2=cout2, res=bool(res), wf=wf, groups=groups, B=1, Ho=1, Wo=M)
+                                act=act, pre=bool(pre), w2=bool(cout2), Cout2=cout2, res=bool(res), wf=wf, groups=groups, B=1, Ho=1, Wo=M,
+                                x2=chain_keep == 2)        # (the last field is 2 for a C3 tail: ops._conv_signature)
             assert tile in ops.conv_candidates(a), (os.path.basename(f), key, tile)
             assert ldy >= cout and ldx >= cin and M > 0 and groups in (1, 2)
             n += 1

@@ -33,6 +33,7 @@ def test_yolov5s_plan_level_fusions_and_their_switches():
     base = names(m.build_plan(2, 320, 320, "cpu", torch.bfloat16))
     assert base[0] == "stem+conv3x3s2+1x1" and base[1] == "bottleneck+cv3" and base.count("conv3x3s1+1x1") == 3
     assert "upsample_nearest" in base and "c3_up_term" not in base           # folded up-sampling is off by default
+    assert base.count("conv3x3s1+cv3") == 3 and len(base) == 63              # the three C3 blocks with 128-channel Bottlenecks end in ONE launch (3x3 + cv3)
     u8 = names(m.build_plan(2, 320, 320, "cpu", torch.bfloat16, u8=True))
     assert u8 == base                                                        # same launches from the uint8 batch
     try:
@@ -42,8 +43,11 @@ def test_yolov5s_plan_level_fusions_and_their_switches():
         assert names(m.build_plan(2, 320, 320, "cpu", torch.bfloat16))[1:3] == ["bottleneck", "conv1x1s1"]
         C3.fuse_cv3, C3.chain_bottlenecks = True, False
         assert "conv3x3s1+1x1" not in names(m.build_plan(2, 320, 320, "cpu", torch.bfloat16))
+        C3.chain_bottlenecks, Conv.chain_tail = True, False
+        plain = names(m.build_plan(2, 320, 320, "cpu", torch.bfloat16))
+        assert "conv3x3s1+cv3" not in plain and len(plain) == len(base) + 3
     finally:
-        Conv.fuse_stem2, C3.fuse_cv3, C3.chain_bottlenecks = True, True, True
+        Conv.fuse_stem2, C3.fuse_cv3, C3.chain_bottlenecks, Conv.chain_tail = True, True, True, True
     m.fold_upsample = True
     folded = names(m.build_plan(2, 320, 320, "cpu", torch.bfloat16))
     assert folded.count("c3_up_term") == 2 and "upsample_nearest" not in folded and len(folded) == len(base)
@@ -57,6 +61,8 @@ def test_wider_models_keep_the_generic_launches():
     for cfg_name in ("yolov5n_Transfusion_kaist.yaml", "yolov5l_Transfusion_VEDAI.yaml"):
         n = names(Model(load_cfg(cfg_name)).eval().build_plan(1, 320, 320, "cpu", torch.bfloat16))
         assert "stem+conv3x3s2+1x1" not in n and "bottleneck+cv3" not in n
+        # the C3 tail follows the Bottleneck width (c_ = 128): yolov5l has it at P3, yolov5n at P5 — backbone and head block each
+        assert n.count("conv3x3s1+cv3") == 2
 
 
 def _dmff_launches(n):

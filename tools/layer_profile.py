@@ -20,13 +20,14 @@ ap.add_argument("--size", type=int, default=640); ap.add_argument("--dtype", def
 ap.add_argument("--reps", type=int, default=7)
 ap.add_argument("--sweep", action="store_true", help="time every igemm launch with each tile config")
 ap.add_argument("--autotune", action="store_true")
+ap.add_argument("--tune-cache", default=None, help="tile choices to load instead of profiles/tune_cache.json (implies --autotune)")
 a = ap.parse_args()
 dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
 cfg = yaml.safe_load(open(os.path.join(ROOT, "models", "transformer", f"yolov5{a.model}_Transfusion_kaist.yaml")))
 m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 0)); m = m.to("cuda:0"); m.compute_dtype = dt
-m.autotune = a.autotune
-if a.autotune:        # the committed igemm configuration choices: the same kernels bench.py launches
-    ops.load_tune_cache(os.path.join(ROOT, "profiles", "tune_cache.json"))
+m.autotune = a.autotune or bool(a.tune_cache)
+if m.autotune:        # the committed igemm configuration choices: the same kernels bench.py launches
+    ops.load_tune_cache(a.tune_cache or os.path.join(ROOT, "profiles", "tune_cache.json"))
 plan = m.plan_for(a.batch, a.size, a.size, "cuda:0")
 rgb, ir = synth_images(a.batch, a.size, a.size, 0)
 plan.inputs[0].copy_(rgb.cuda()); plan.inputs[1].copy_(ir.cuda())
