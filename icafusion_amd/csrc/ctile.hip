@@ -22,6 +22,10 @@
 #ifndef ICAF_CTILE_ABL
 #define ICAF_CTILE_ABL 0
 #endif
+// 1 = the fused Bottleneck + cv3 asks for its residual / cv2 vectors behind the 3x3 loop (the form before round 4; A/B builds only)
+#ifndef ICAF_CTILE_LATE3
+#define ICAF_CTILE_LATE3 0
+#endif
 
 namespace icaf {
 
@@ -86,6 +90,12 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
         (void*)((const typename E::type*)p.w + g * p.w_gs), 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
+    auto row_to_m = [&](int row) {
+        const int st = row >> 5, r = row & 31;
+        const int py = TW == 32 ? st : st * 2 + (r >> 4), px = TW == 32 ? r : (r & 15);
+        const int gy = y0 + py, gx = x0 + px;
+        return (gy < p.Ho && gx < p.Wo) ? (b * p.Ho + gy) * p.Wo + gx : -1;
+    };
     // ---- 1. halo patch -> LDS (each DMA instruction fills 64 consecutive 16-byte slots) --------------------------
     {
         const int nslots = (HH * PITCH) << lsp;
@@ -105,6 +115,25 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
             const unsigned voff = ok ? img_off + (unsigned)((gy * p.W + gx) * p.ldx) * E::BYTES + (unsigned)(cs << 4) : OOB;
             if constexpr (!(ICAF_CTILE_ABL & 1))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(xpatch + (j << 10)), 16, voff, 0, 0, 0);
+        }
+    }
+
+    // CHAIN3: the residual (the Bottleneck's input) and the cv2 half of cv3's operand at this thread's tile positions are requested NOW, beside
+    // the patch — a pixel's [cv1 | cv2] channels are ONE 128-byte line of the C3's buffer, so the lines the patch DMA brings in serve these
+    // loads from the L2 — and held in registers through the 3x3 loop.  (Requested behind the loop, as before round 4, they were a dependent
+    // HBM round trip at the end of every workgroup's life and re-fetched lines the L2 had dropped: PMC 387 MB per launch for 210 MB read.)
+    constexpr int VPR3 = BN / VEC, NIT3 = CHAIN3 ? BM * VPR3 / NTHREADS : 1;
+    u32x4 rv[NIT3], cv2v[NIT3];
+    if constexpr (CHAIN3 && !ICAF_CTILE_LATE3) {
+        const typename E::type* __restrict__ rg = p.res ? (const typename E::type*)p.res + g * p.res_gs : nullptr;
+        const typename E::type* __restrict__ x2g = (const typename E::type*)p.x2 + g * p.x2_gs;
+#pragma unroll
+        for (int it = 0; it < NIT3; ++it) {
+            const int idx = tid + it * NTHREADS, row = idx / VPR3, cv = idx - row * VPR3;
+            const int m = row_to_m(row);
+            const long long mm = m < 0 ? 0 : m;
+            rv[it] = rg ? *(const u32x4*)(rg + mm * p.ldr + cv * VEC) : u32x4{0u, 0u, 0u, 0u};
+            cv2v[it] = *(const u32x4*)(x2g + mm * p.ldx2 + cv * VEC);
         }
     }
 
@@ -266,12 +295,6 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    auto row_to_m = [&](int row) {
-        const int st = row >> 5, r = row & 31;
-        const int py = TW == 32 ? st : st * 2 + (r >> 4), px = TW == 32 ? r : (r & 15);
-        const int gy = y0 + py, gx = x0 + px;
-        return (gy < p.Ho && gx < p.Wo) ? (b * p.Ho + gy) * p.Wo + gx : -1;
-    };
     if constexpr (CHAIN3) {
         static_assert(FUSE1 && TN == 1 && BN == 32, "cv3 chained behind the fused Bottleneck: c_ = 32");
         constexpr int N3 = 2 * BN, SO3 = N3 * E::BYTES + 16;           // tile row: [cv2 | m], stride as the epilogue's
@@ -302,16 +325,16 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
         {
             constexpr int VPR = BN / VEC, NIT = BM * VPR / NTHREADS;   // 4 vectors per row and half, 4 rows per thread
             const typename E::type* __restrict__ rg = p.res ? (const typename E::type*)p.res + g * p.res_gs : nullptr;
-            const typename E::type* __restrict__ x2g = (const typename E::type*)p.x2 + g * p.x2_gs;
-            u32x4 rv[NIT], cv2v[NIT];
-            int mrow[NIT];
+            if constexpr (ICAF_CTILE_LATE3) {                              // (A/B build: the loads where they were before round 4)
+                const typename E::type* __restrict__ x2g = (const typename E::type*)p.x2 + g * p.x2_gs;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int idx = tid + it * NTHREADS, row = idx / VPR, cv = idx - row * VPR;
-                mrow[it] = row_to_m(row);
-                const long long mm = mrow[it] < 0 ? 0 : mrow[it];
-                rv[it] = rg ? *(const u32x4*)(rg + mm * p.ldr + cv * VEC) : u32x4{0u, 0u, 0u, 0u};
-                cv2v[it] = *(const u32x4*)(x2g + mm * p.ldx2 + cv * VEC);
+                for (int it = 0; it < NIT; ++it) {
+                    const int idx = tid + it * NTHREADS, row = idx / VPR, cv = idx - row * VPR;
+                    const int m = row_to_m(row);
+                    const long long mm = m < 0 ? 0 : m;
+                    rv[it] = rg ? *(const u32x4*)(rg + mm * p.ldr + cv * VEC) : u32x4{0u, 0u, 0u, 0u};
+                    cv2v[it] = *(const u32x4*)(x2g + mm * p.ldx2 + cv * VEC);
+                }
             }
             const float alpha_res = p.alpha_res[g];
 #pragma unroll

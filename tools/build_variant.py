@@ -29,5 +29,6 @@ for spec in sys.argv[2:]:
 B.CSRC = src
 B.OBJDIR = os.path.join(ROOT, "icafusion_amd", f"_obj_{tag}")
 B.LIB = os.path.join(B.LIBDIR, f"libicaf_{tag}.so")
+B.RESOURCES = os.path.join(B.LIBDIR, f"kernel_resources_{tag}.json")       # (not the product library's table)
 B.build(force=True)
 print(B.LIB)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time single conv launches of the bench plan (yolov5s bf16, batch 32, 640x640) under given launch configurations:
+"""Time single conv launches of the bench plan (yolov5s — ICAF_PROBE_MODEL=l: yolov5l — bf16, batch 32, 640x640) under given launch configurations:
     python tools/probes/time_layer.py idx:tile[,tile...] [idx:tile,...] ...        (ICAF_LIB selects the library build)
 prints microseconds per launch (median of 5 x 10 back-to-back launches) - for same-box A/B of kernel variants."""
 import os, sys
@@ -9,7 +9,8 @@ import torch, yaml
 from icafusion_amd import ops
 from icafusion_amd.models.yolo import Model
 from icafusion_amd.synth import synth_state_dict
-cfg = yaml.safe_load(open(os.path.join(ROOT, "models", "transformer", "yolov5s_Transfusion_kaist.yaml")))
+MODEL = os.environ.get("ICAF_PROBE_MODEL", "s")          # "l": the yolov5l shard (config 3)
+cfg = yaml.safe_load(open(os.path.join(ROOT, "models", "transformer", f"yolov5{MODEL}_Transfusion_kaist.yaml")))
 m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 0)); m = m.to("cuda:0"); m.compute_dtype = torch.bfloat16
 plan = m.plan_for(32, 640, 640, "cuda:0")
 plan.run(); torch.cuda.synchronize()
