@@ -387,9 +387,13 @@ def main():
                  "avg_launch_us_with_second_forward_in_flight": over_us, "launches_per_step": dn // reps,
                  "share_of_forward_kernel_time": round(dms / reps / total_ms, 3)})
     att = per_kernel.get("cross_attention")
+    # every kernel of the forward with its own two roofline fractions (the `roofline` object above is the first entry of this table: the kernel
+    # with the largest share of the forward's kernel time)
     kernels = {k: {"ms_per_step": round(v[0] / reps, 4), "launches": v[3] // reps,
                    "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[1] else None,
-                   "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1)} for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
+                   "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1),
+                   "mfma_frac": round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4) if v[1] else None,
+                   "hbm_frac": round(v[2] / (v[0] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)} for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
 
     if rank == 0:
         pairs = (args.global_batch if strong else B * world) * args.steps

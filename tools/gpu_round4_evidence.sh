@@ -40,8 +40,5 @@ PY
 run_cfg c3_l_bf16_b32_640 --model l --batch 32
 cd $R && SQ_INSTS=1 bash tools/gpu_pmc_sq.sh --model l --batch 32 --tune-cache $R/profiles/tune_cache_c3_l_bf16_b32_640.json > gpurun_out/pmc_sq_c3.log 2>&1
 cp gpurun_out/pmc_sq_summary.json gpurun_out/pmc_sq_summary_c3.json; cp gpurun_out/pmc_sq_insts.json gpurun_out/pmc_sq_insts_c3.json; grep "dmff\|cross_att" gpurun_out/pmc_sq_c3.log
-# config 4's committed cache predates the 64-channel-per-wave tiles: offer them to it first (the refreshed cache travels back in gpurun_out/)
-ICAF_RETUNE_TILES=63,64 timeout 600 python bench.py --no-cpu-baseline --no-latency --no-h2d --repeats 1 --tune-cache $R/profiles/tune_cache_c4_s_bf16_b64_512x640_loops3.json --loops 3 --height 512 --width 640 --batch 64 > /dev/null 2>&1
-cp $R/profiles/tune_cache_c4_s_bf16_b64_512x640_loops3.json $R/gpurun_out/tune_cache_c4_s_bf16_b64_512x640_loops3.json
 run_cfg c4_s_bf16_b64_512x640_loops3 --loops 3 --height 512 --width 640 --batch 64
 run_cfg c5_l_vedai_f16_b16_1280 --model l --dataset VEDAI --dtype f16 --height 1280 --width 1280 --batch 16 --conf 0.3
