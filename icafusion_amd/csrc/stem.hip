@@ -260,17 +260,28 @@ __global__ __launch_bounds__(NTHREADS) void stem_kernel(const StemP q) {
 //            tile staged in LDS exactly as igemm's CHAIN stages it;
 //   stage 3  the chained 1x1 (K = 64) and the shared epilogue writing only y.
 // Every stage repeats the K order, MFMA step and rounding points of the kernel it replaces, so y is bit-identical to
-// icaf_stem -> icaf_conv2d(chained) (tested).  LDS: 24 KiB + 38 KiB patches + 60 KiB weights = 122 KiB, one workgroup
+// icaf_stem -> icaf_conv2d(chained) (tested).  LDS: 28 KiB + 45 KiB patches + 60 KiB weights = 133 KiB, one workgroup
 // per CU; the patch walk is XCD-aware like the stem's.
 constexpr int S2_TH = 4, S2_TW = 32;                                   // tile of the 3x3/s2 layer's output pixels
 constexpr int S2_HH = 2 * S2_TH + 1, S2_HWD = 2 * S2_TW + 1;           // stem-output halo patch: 9 x 65 pixels
-constexpr int S2_HALF = (S2_HWD + 1) / 2, S2_PITCH = 2 * S2_HALF;      // 33 even | 33 odd columns per row
-constexpr int S2_NH = S2_HH * S2_PITCH;                                // 594 entries of 64 bytes
-constexpr int S2_HALO_BYTES = ((S2_NH * 4 + 63) / 64) * 1024;          // 38 KiB
+// Round 4 (late): both patches are laid out so that the tap offsets of the two MFMA loops are multiples of 16 entries: the XOR-swizzle keys
+// ((entry >> 3) & 1 for the 32-byte entries, (entry >> 2) & 3 for the 64-byte ones) then do not change from tap to tap, a lane's fragment
+// addresses are a handful of tile-invariant registers + compile-time immediates (precomputed once per workgroup), and the K loops carry no
+// address arithmetic.  SQ counters had put this kernel at 0.54 VALU issue against 0.21 MFMA busy: 758 vector instructions per wave and tile,
+// of which only ~350 are the three SiLU layers — the rest was index decode (divisions by the pitch) and swizzle arithmetic per fragment read.
+constexpr int S2_LHALF = (S2_HWD + 1) / 2, S2_LPITCH = 2 * S2_LHALF;   // LOGICAL enumeration of the stem pixels of a tile: 33 even | 33 odd columns per row
+constexpr int S2_NL = S2_HH * S2_LPITCH;                               // 594 logical entries = 19 sub-tile jobs of 32
+constexpr int S2_HALF = 48, S2_PITCH = 80;                             // PHYSICAL: even columns at [0, 33), odd columns at [48, 80) of an 80-entry row
+constexpr int S2_NH = S2_HH * S2_PITCH;                                // 720 entries of 64 bytes
+constexpr int S2_HALO_BYTES = ((S2_NH * 4 + 63) / 64) * 1024;          // 45 KiB
 constexpr int S2_SR = S2_HH + 2, S2_SC = S2_HWD + 2;                   // space-to-depth patch under it: 11 x 67
-constexpr int S2_SHALF = (S2_SC + 1) / 2, S2_SPITCH = 2 * S2_SHALF;    // 34 | 34
-constexpr int S2_NS = S2_SR * S2_SPITCH;                               // 748 entries of 32 bytes
-constexpr int S2_S2D_BYTES = ((S2_NS * 2 + 63) / 64) * 1024;           // 24 KiB
+constexpr int S2_SPAIRS = (S2_SC + 1) / 2;                             // 34 column pairs per row (the PAIR staging's thread map)
+constexpr int S2_SHALF = 40, S2_SPITCH = 80;                           // PHYSICAL: even columns at [0, 34), odd at [40, 74) of an 80-entry row
+constexpr int S2_NS = S2_SR * S2_SPITCH;                               // 880 entries of 32 bytes
+constexpr int S2_S2D_BYTES = ((S2_NS * 2 + 63) / 64) * 1024;           // 28 KiB
+static_assert(S2_PITCH % 16 == 0 && S2_HALF % 16 == 0 && S2_SPITCH % 16 == 0, "tap offsets must keep the swizzle keys");
+static_assert(S2_LHALF <= S2_HALF && S2_HALF + S2_LHALF - 1 <= S2_PITCH && S2_SPAIRS <= S2_SHALF && S2_SHALF + S2_SPAIRS <= S2_SPITCH, "planes fit their rows");
+static_assert(S2_NS <= 2 * 512, "two space-to-depth entries per thread");
 constexpr int S2_THREADS = 512;
 constexpr int S2_C0 = 32, S2_C1 = 64, S2_C2 = 64, S2_W1_SLICES = 5;    // K1 = 288 -> 5 slices of 128 bytes
 constexpr int S2_LDS = S2_S2D_BYTES + S2_HALO_BYTES + (3 * S2_C0 + S2_W1_SLICES * S2_C1 + S2_C2) * 128;
@@ -335,8 +346,8 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
         if (tid + S2_THREADS < S2_NS) store_entry<DT, U8>(s2d, tid + S2_THREADS, v1);
     };
     // PAIR: thread -> (patch row psr, column pair pk): entries (psr, 2 pk) of the even plane and (psr, 2 pk + 1) of the odd plane
-    constexpr int S2_NPAIR = S2_SR * S2_SHALF;                             // 374
-    const int psr = tid / S2_SHALF, pk = tid - psr * S2_SHALF;
+    constexpr int S2_NPAIR = S2_SR * S2_SPAIRS;                            // 374
+    const int psr = tid / S2_SPAIRS, pk = tid - psr * S2_SPAIRS;
     float4 pr[PAIR ? 6 : 1];
     bool pin0 = false, pin1 = false;
     auto fetch_pair = [&](const TileWalk& t) {
@@ -405,7 +416,38 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
     int foff[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) foff[s] = l31 * RB + (((2 * s + hi) ^ fkey) << 4);
-    const int lb2 = wm * 2 * S2_PITCH + l31;                               // stage 2: lane's entry for tap (0, 0)
+    // ---- tile-invariant fragment addresses (see the layout note above) ---------------------------------------------------------
+    // stage 1: this wave's up to three sub-tile jobs (19 jobs over 8 waves).  With PAIR staging the LAST waves do no image loads and no
+    // patch commits, so the jobs are dealt from the last wave down (results do not depend on the dealing).
+    constexpr int S2_NJOBS = (S2_NL + 31) / 32, S2_JPW = (S2_NJOBS + S2_THREADS / 64 - 1) / (S2_THREADS / 64);
+    const int job0 = PAIR ? S2_THREADS / 64 - 1 - wave : wave;
+    int s1_rd[S2_JPW][3], s1_wr[S2_JPW], s1_key[S2_JPW], s1_hy[S2_JPW], s1_hx[S2_JPW];
+#pragma unroll
+    for (int jj = 0; jj < S2_JPW; ++jj) {
+        const int lidx = ((job0 + jj * (S2_THREADS / 64)) << 5) + l31;         // logical entry: (row, plane, column index)
+        const int lc = lidx < S2_NL ? lidx : 0;
+        const int hy = lc / S2_LPITCH, rem = lc - hy * S2_LPITCH, pl = rem >= S2_LHALF, i = rem - pl * S2_LHALF;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int sc = 2 * i + pl + kx;
+            const int e = hy * S2_SPITCH + (sc & 1) * S2_SHALF + (sc >> 1);     // space-to-depth entry of tap (0, kx); tap row ky: + ky * S2_SPITCH
+            s1_rd[jj][kx] = ((e << 1) + (hi ^ ((e >> 3) & 1))) << 4;
+        }
+        const int idx = hy * S2_PITCH + pl * S2_HALF + i;                      // physical entry of the stem pixel in the halo patch
+        s1_wr[jj] = lidx < S2_NL ? (idx << 6) + (hi << 3) : -1;                // byte address of channel quad 0's slot 0 (+ 8 bytes for the upper lane half)
+        s1_key[jj] = (idx >> 2) & 3;
+        s1_hy[jj] = hy;
+        s1_hx[jj] = 2 * i + pl;
+    }
+    // stage 2: the lane's output pixel (row wm, column l31): entry of tap (0, 0) and of tap (0, 2) (one entry further), each with the two
+    // 16-byte channel slots a K step of 16 reads; taps (ky, kx & 1) are immediates
+    int s2_rd[2][2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int idx = wm * 2 * S2_PITCH + l31 + d;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) s2_rd[d][h2] = ((idx << 2) + (((h2 * 2 + hi) ^ (idx >> 2)) & 3)) << 4;
+    }
 
     // Per-stream constants held in registers: the stem's weight fragments and the three bias vectors of this lane's
     // channels.  (Loading a bias inside the tile loop is a dependent L2 round trip per use — with one workgroup per CU
@@ -444,35 +486,22 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
 
         // ---- stage 1: stem over the halo patch ------------------------------------------------------------------
         {
-            // 19 sub-tile jobs over 8 waves: three waves take a third job.  With PAIR staging the LAST waves do no image loads and no
-            // patch commits, so they are the ones to carry it (jobs dealt from the last wave down; results do not depend on the dealing)
-            for (int j = (PAIR ? S2_THREADS / 64 - 1 - wave : wave); j < (S2_NH + 31) / 32; j += S2_THREADS / 64) {
-                const int idx = (j << 5) + l31;
-                const int idc = idx < S2_NH ? idx : 0;
-                const int hy = idc / S2_PITCH, rem = idc - hy * S2_PITCH, pl = rem >= S2_HALF, i = rem - pl * S2_HALF;
-                int eb[3];
+            const int sy0 = 2 * y0 - 1, sx0 = 2 * x0 - 1;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int sc = 2 * i + pl + kx;
-                    eb[kx] = hy * S2_SPITCH + (sc & 1) * S2_SHALF + (sc >> 1);
-                }
+            for (int jj = 0; jj < S2_JPW; ++jj) {
+                if (job0 + jj * (S2_THREADS / 64) >= S2_NJOBS) break;             // (wave-uniform)
                 f32x16 a0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a0[r] = 0.0f;
+                u32x4 fp[9];
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int ky = tap / 3, kx = tap - 3 * ky;
-                    const int e = eb[kx] + ky * S2_SPITCH;
-                    const u32x4 fp = *(const u32x4*)(s2d + (((e << 1) + (hi ^ ((e >> 3) & 1))) << 4));
-                    mma_step<DT>(a0, fw0[tap], fp);
-                }
-                const int hx = 2 * i + pl;
-                const int sy = 2 * y0 - 1 + hy, sx = 2 * x0 - 1 + hx;
-                const bool inside = hx < S2_HWD && (unsigned)sy < (unsigned)q.Hs && (unsigned)sx < (unsigned)q.Ws;
-                if (idx < S2_NH) {
+                for (int tap = 0; tap < 9; ++tap) fp[tap] = *(const u32x4*)(s2d + s1_rd[jj][tap % 3] + (tap / 3) * (S2_SPITCH * 32));
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) mma_step<DT>(a0, fw0[tap], fp[tap]);
+                const bool inside = s1_hx[jj] < S2_HWD && (unsigned)(sy0 + s1_hy[jj]) < (unsigned)q.Hs && (unsigned)(sx0 + s1_hx[jj]) < (unsigned)q.Ws;
+                if (s1_wr[jj] >= 0) {
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
-                        const int nl = 8 * qd + 4 * hi;
                         float v[4] = {0.f, 0.f, 0.f, 0.f};
                         if (inside) {
 #pragma unroll
@@ -481,8 +510,7 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
                         u32x2 pk;
                         if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
                         else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
-                        const int slot = (idx << 2) + (((nl >> 3) ^ (idx >> 2)) & 3);
-                        *(u32x2*)(halo + (slot << 4) + ((nl & 7) << 1)) = pk;
+                        *(u32x2*)(halo + s1_wr[jj] + ((qd ^ s1_key[jj]) << 4)) = pk;      // channel quad qd lives in slot qd ^ key of the entry
                     }
                 }
             }
@@ -496,9 +524,7 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
 #pragma unroll
         for (int k = 0; k < 9 * C0 / 16; ++k) {    // K = (tap, channel): 16 per MFMA step
             const int tap = k >> 1, ky = tap / 3, kx = tap - 3 * ky;
-            const int idx = lb2 + ky * S2_PITCH + (kx & 1) * S2_HALF + (kx >> 1);
-            const int csl = (k & 1) * 2 + hi;
-            const u32x4 fp = *(const u32x4*)(halo + (((idx << 2) + ((csl ^ (idx >> 2)) & 3)) << 4));
+            const u32x4 fp = *(const u32x4*)(halo + s2_rd[kx >> 1][k & 1] + (ky * S2_PITCH + (kx & 1) * S2_HALF) * 64);
             const u32x4 fw = *(const u32x4*)(w1b + (k >> 2) * C1 * RB + (wn * 32) * RB + foff[k & 3]);
             mma_step<DT>(acc[0][0], fw, fp);
         }
