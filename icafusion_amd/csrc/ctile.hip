@@ -49,10 +49,16 @@ template <int S, int TW> struct HaloGeom {
 // the pixel operand of the 2c_ -> Cout2 1x1 (weights resident in LDS); only cv3's output is written (p.w2 / bias2 / y2,
 // p.x2 = the cv2 half).  Channel order of the tile = [cv2 | m] (the order the three-slot C3 buffer presents after one
 // fused Bottleneck; the weights are packed to match), K order and MFMA step as igemm: bit-identical to the two launches.
+constexpr int ct_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
 template <int DT, int TH, int TW, int BN, int ACT, int S, bool FUSE1, bool CHAIN3 = false>
-__device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const int lcin, const int tiles_x,
+__device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp_arg, const int lcin_arg, const int tiles_x,
                                            const int tiles_per_img, const int halo_bytes) {
     using E = Elem<DT>;
+    // The fused Bottleneck is c_ -> c_ -> c_ with c_ = BN: channel count, slots per pixel and the K loop's trip count are compile-time
+    // constants there, so the tap / slot arithmetic of every MFMA step folds away and the loop unrolls (SQ counters had this kernel at
+    // 0.74 VALU issue against 0.14 MFMA busy: 13 vector instructions of address arithmetic per two MFMAs).  The plain 3x3 keeps the run-time values.
+    const int lsp = FUSE1 ? ct_log2(BN * E::BYTES / 16) : lsp_arg, lcin = FUSE1 ? ct_log2(BN) : lcin_arg;
     using G = HaloGeom<S, TW>;
     constexpr int VEC = E::VEC;
     constexpr int RB = 128, NS = 3;
@@ -255,7 +261,7 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
         // (the first barrier of the 3x3 loop below makes the second patch visible)
     }
 
-    for (int c = 0; c < p.nchunks; ++c) {
+    auto kstep = [&](const int c) {
         wait_vmcnt<(NS - 2) * NBW>();              // slice c (and, for c = 0, the halo patch issued before it) landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -291,6 +297,13 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp, const 
                     }
             }
         }
+        };
+    if constexpr (FUSE1) {
+        constexpr int NCH = (9 * BN + BK - 1) / BK;                    // = p.nchunks (launch_bneck fills it from the same geometry)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) kstep(c);
+    } else {
+        for (int c = 0; c < p.nchunks; ++c) kstep(c);
     }
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
