@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 evidence, refresh of the DEFAULT workload (and config 4) after the last change of their tune caches: same steps as tools/gpu_round4_evidence.sh for
-# those two workloads (configs 3 / 5 keep their files: caches and library paths unchanged since that call).
+# Round-4 evidence, refresh of the two yolov5s workloads (default, config 4) after a change that only they see (their tune caches; stem2 / icaf_bottleneck):
+# same steps as tools/gpu_round4_evidence.sh for those two (configs 3 / 5 keep their files: nothing on their paths changed since that call).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
 find gpurun_out -mindepth 1 -maxdepth 1 ! -name '.last_call.json' -exec rm -rf {} +
@@ -15,8 +15,6 @@ cd $R && timeout 300 python tools/layer_profile.py --autotune > gpurun_out/layer
 cd $R && ICAF_DMFF_FUSE=0 timeout 300 python tools/layer_profile.py --autotune > gpurun_out/layer_profile_plain.txt 2>/dev/null; head -1 gpurun_out/layer_profile_plain.txt
 name=c4_s_bf16_b64_512x640_loops3
 ARGS="--loops 3 --height 512 --width 640 --batch 64"
-ICAF_RETUNE_TILES=63,64,65,66 timeout 600 python bench.py --no-cpu-baseline --no-latency --no-h2d --repeats 1 --tune-cache $R/profiles/tune_cache_$name.json $ARGS > /dev/null 2>&1
-cp $R/profiles/tune_cache_$name.json $R/gpurun_out/tune_cache_$name.json
 cd $R && PMC_NAME=$name bash tools/gpu_pmc.sh --tune-cache $R/profiles/tune_cache_$name.json $ARGS 2>&1 | tail -1
 cd $R; timeout 900 python bench.py --no-cpu-baseline --tune-cache $R/profiles/tune_cache_$name.json $ARGS > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err
 cd /tmp && rm -rf /tmp/icaf_raw/prof_$name
