@@ -134,3 +134,22 @@ def test_resident_patch_kernel_shape_table():
     assert ops.dmff_wide_ok(256, 1024, torch.bfloat16) and ops.dmff_wide_ok(512, 2048, torch.float16)
     assert ops.dmff_wide_ok(128, 512, torch.bfloat16) and not ops.dmff_wide_ok(384, 1536, torch.bfloat16) and not ops.dmff_wide_ok(1024, 4096, torch.bfloat16)
     assert not ops.dmff_wide_ok(256, 1024, torch.float32) and not ops.dmff_wide_ok(512, 2048 + 128, torch.bfloat16)
+
+
+def test_c3_tail_launch_configurations_follow_the_map_size():
+    """ops.conv_candidates for a C3 tail (cv3 chained behind the last Bottleneck's 3x3, icaf_conv_args.x2): only cwide.hip's two forms, and below
+    TAIL_8X16_MINPIX pixels per stream only the 8 x 8 form (the 8 x 16 form wins isolated timings there and loses the bench: DESIGN.md section 15);
+    the tuner signature keeps tails apart from chain_keep launches of the same shape."""
+    from types import SimpleNamespace
+
+    from icafusion_amd import ops
+
+    def tail(m):
+        return SimpleNamespace(Cout=128, Cin=128, kh=3, kw=3, sh=1, sw=1, ph=1, pw=1, dtype=ops.BF16, out_dtype=ops.BF16, act=ops.ACT_SILU, pre=False,
+                               w2=True, x2=True, Cout2=256, res=True, wf=True, groups=2, B=1, Ho=1, Wo=m, H=1, W=m, ldx=128, ldy=256, pre_mode=0,
+                               chain_keep=0)
+    assert ops.conv_candidates(tail(51200)) == [82] and ops.conv_candidates(tail(81920)) == [82]
+    assert ops.conv_candidates(tail(204800)) == [81, 82] and ops.conv_candidates(tail(409600)) == [81, 82]
+    a = tail(51200)
+    b = SimpleNamespace(**{**vars(a), "x2": False, "chain_keep": 1})
+    assert ops._conv_signature(a) != ops._conv_signature(b) and ops._conv_signature(a)[-1] == 2
