@@ -387,7 +387,7 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp_arg, co
                 for (int bb = 0; bb < TM; ++bb) mma_step<DT>(acc3[a][bb], fw3[a], fp3[bb]);
         }
         __syncthreads();                           // the tile has been consumed: the epilogue may overwrite it
-        epilogue<DT, DT, BM, N3, WM, N3, ICAF_ACT_SILU, false, true>(acc3, lds, p, g, row_to_m, 0);
+        epilogue<DT, DT, BM, N3, WM, N3, ICAF_ACT_SILU, false, true, false, true>(acc3, lds, p, g, row_to_m, 0);   // (launch_bneck: Cout2 == 64, y2 in 16-byte vectors)
     } else {
         epilogue<DT, DT, BM, BN, WM, BN, ACT, false>(acc, lds, p, g, row_to_m, 0);
     }
@@ -484,9 +484,9 @@ int launch_bneck(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t
     if (a->dtype == ICAF_F32) return fail(ICAF_ERR_UNSUPPORTED, "icaf_bottleneck: 16-bit types only");
     if (a->Cin != a->Cout || (a->Cin != 32 && a->Cin != 64) || kShapes[shape - 1].bn != a->Cout || kShapes[shape - 1].s != 1)
         return fail(ICAF_ERR_UNSUPPORTED, "icaf_bottleneck: c_ = %d -> %d with patch shape %d is not built (c_ in {32, 64})", a->Cin, a->Cout, shape);
-    if (a->w2) {          // cv3 chained behind the Bottleneck: c_ = 32 (shape 1), 64 output channels or fewer, with a residual or not
-        if (shape != 1 || a->Cout2 > 64 || a->Kp2 != 64 || !p.x2 || p.ldx2 % 8 || ((uintptr_t)p.x2 & 15) || (!p.vec_r && a->res))
-            return fail(ICAF_ERR_UNSUPPORTED, "icaf_bottleneck: chained cv3 needs patch shape 1 (c_ = 32), Cout2 <= 64, Kp2 = 64, an aligned cv2 half");
+    if (a->w2) {          // cv3 chained behind the Bottleneck: c_ = 32 (shape 1), 64 output channels, with a residual or not
+        if (shape != 1 || a->Cout2 != 64 || !p.vec_y2 || a->Kp2 != 64 || !p.x2 || p.ldx2 % 8 || ((uintptr_t)p.x2 & 15) || (!p.vec_r && a->res))
+            return fail(ICAF_ERR_UNSUPPORTED, "icaf_bottleneck: chained cv3 needs patch shape 1 (c_ = 32), Cout2 = 64 written in 16-byte vectors, Kp2 = 64, an aligned cv2 half");
         if (a->dtype == ICAF_BF16) return launch_ctile_cfg<ICAF_BF16, 8, 32, 32, 1, true, true>(p, a->groups, s);
         return launch_ctile_cfg<ICAF_F16, 8, 32, 32, 1, true, true>(p, a->groups, s);
     }

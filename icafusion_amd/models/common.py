@@ -457,7 +457,7 @@ class C3(HipModule):
         # neighbours' patches read x), so the chain ping-pongs between slot 0 and slot 2; cv3 then reads [a | b] or
         # [b | a'] — in the second case with its weight columns swapped to match.
         k3 = self.cv3.conv
-        tail3 = (self.fuse_cv3 and len(self.m) == 1 and fused[0] and c_ == 32 and k3.out_channels <= 64 and k3.kernel_size == (1, 1)
+        tail3 = (self.fuse_cv3 and len(self.m) == 1 and fused[0] and c_ == 32 and k3.out_channels == 64 and k3.kernel_size == (1, 1)
                  and k3.stride == (1, 1) and k3.groups == 1 and k3.in_channels == 2 * c_ and isinstance(self.cv3.act, nn.SiLU))
         cat = plan.act(B, H, W, (3 if any(fused) and not tail3 else 2) * c_, pair=paired)
         if lead is not None and len(lead) == 4:

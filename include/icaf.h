@@ -168,7 +168,7 @@ int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s);
  * With conv.w2 != NULL (shape 1 only) the C3's cv3 rides on the block (models/common.py:226):
  *   y2 = SiLU( W2 . cat(x2, [x +] SiLU(conv3x3(...))) + bias2 )
  * x2 = the cv2 half of cv3's input (NHWC, c_ channels, pixel stride ldx2), W2 packed [Np][64] with its K columns in the
- * order [cv2 | m]; only y2 (conv.y2 / ldy2 / Cout2 <= 64) is written — conv.y is ignored.  Bit-identical to icaf_bottleneck
+ * order [cv2 | m]; only y2 (conv.y2 / ldy2, Cout2 = 64, 16-byte aligned rows) is written — conv.y is ignored.  Bit-identical to icaf_bottleneck
  * followed by the 1x1 icaf_conv2d. */
 typedef struct icaf_bneck_args {
     icaf_conv_args conv;
