@@ -46,7 +46,7 @@ __device__ __forceinline__ int xcd_tile(int ntile_total) {
 // selecting the fields here keeps ConvP in scalar registers — a modified copy of the struct would live in scratch memory.
 // WB = true writes every final output vector (residual included) back into the staged LDS tile as well: igemm's chained
 // 1x1 then consumes, as its pixel operand, exactly what this layer stores.
-// FULLVEC = true: the caller has checked that the whole BN-channel tile is written (Cout == BN, n0 == 0) in 16-byte vectors without a residual — the
+// FULLVEC = true: the caller has checked that whole BN-channel tiles are written (Cout % BN == 0) in 16-byte vectors without a residual — the
 // write-back is then one vector load and one store per thread and round; the general loop below compiles four fall-back paths in (a short last vector, a
 // scalar residual, unaligned rows), ~30 instructions of branching per round even when none is taken (icaf_bottleneck + cv3: eight rounds per workgroup).
 template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, bool PRE, bool SECOND = false, bool WB = false, bool FULLVEC = false, typename RowMap>
@@ -165,7 +165,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, row = idx / VPR, cv = idx & (VPR - 1);
             const int m = row_to_m(row);
-            if (m >= 0) *(u32x4*)(yg + (long long)m * ldy + cv * VO) = *(const u32x4*)(lds + row * SO + cv * 16);
+            if (m >= 0) *(u32x4*)(yg + (long long)m * ldy + n0 + cv * VO) = *(const u32x4*)(lds + row * SO + cv * 16);
         }
         return;
     }

@@ -212,7 +212,13 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && TN == 2) ? 2 : 1) void igemm
     wait_vmcnt<0>();                               // zero-fill slices issued past the end
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    epilogue<DT, DT, BM, BN, BM, 32 * TN, ACT, false>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
+    // (workgroup-uniform: most launches write whole tiles in vectors without a residual — the checked fast write-back of conv_common.h.  Carrying
+    //  both loops costs the 128-pixel / 32-channel-per-wave tiles a workgroup per CU in registers, so only the 64-pixel and the 64-channel forms do)
+    constexpr bool FAST_WB = BM == 64 || TN == 2;
+    if (FAST_WB && !p.res && p.vec_y && p.Cout % BN == 0)
+        epilogue<DT, DT, BM, BN, BM, 32 * TN, ACT, false, false, false, true>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
+    else
+        epilogue<DT, DT, BM, BN, BM, 32 * TN, ACT, false>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
