@@ -64,11 +64,11 @@ def kernels_of(path):
                 res[cur] = collections.Counter()
             continue
         t = line.strip()
+        if t.startswith(".Lfunc_end"):                 # (not the first s_endpgm: a kernel with a uniform early exit has several)
+            cur = None
         if cur is None or not t or t[0] in ";." or t.endswith(":"):
             continue
         res[cur][classify(t.split()[0])] += 1
-        if t.startswith("s_endpgm"):
-            cur = None
     return res
 
 
