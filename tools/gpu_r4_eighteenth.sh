@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 4, eighteenth GPU call: stem2 with tile-invariant fragment addresses (the library) against the form before (libicaf_oldbneck.so): the stem tests and
-# kernel tests, plan-level bit-identity, the kernel time and the whole bench, same box.
+# Round 4, eighteenth GPU call: icaf_bottleneck with compile-time channel geometry and an unrolled K loop (the library) against the form before
+# (libicaf_oldbneck.so): kernel tests, plan-level bit-identity, the kernel's time and the whole bench, same box.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out
 timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "bottleneck or halo_patch or conv3x3" --timeout=180 --tb=short -p no:cacheprovider > gpurun_out/t18_kernels.log 2>&1
 echo "== kernels: $(tail -1 gpurun_out/t18_kernels.log)"; grep -E "^(FAILED|ERROR)" gpurun_out/t18_kernels.log | head
