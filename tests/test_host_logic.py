@@ -283,3 +283,22 @@ def test_wide_dmff_entry_points_reject_what_they_are_not_built_for():
     a.hidden, a.Kp4 = 1024, 1024
     assert lib().icaf_dmff_wide_proj_mlp(C.byref(a), None, None) != 0                    # attention output missing
     assert _lib.IcafError
+
+
+def test_isa_mix_splits_kernels_and_classifies_instructions(tmp_path):
+    """tools/isa_mix.py (the static instruction-mix table under profiles/): a kernel runs from its label to .Lfunc_end — a uniform early exit puts a
+    second s_endpgm in the middle — and every instruction lands in one class."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_mix", os.path.join(REPO, "tools", "isa_mix.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    asm = tmp_path / "k.s"
+    asm.write_text("\n".join([
+        "\t.text", "helper:", "\tv_mov_b32_e32 v0, 0", "\ts_setpc_b64 s[30:31]", ".Lfunc_end0:",
+        "k1: ; @k1", "\ts_load_dwordx2 s[0:1], s[4:5], 0x0", "\ts_waitcnt lgkmcnt(0)", "\ts_cbranch_scc1 .LBB1_2", "\tv_exp_f32_e32 v1, v0", "\ts_endpgm",
+        ".LBB1_2:", "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], 0", "\tds_read_b128 v[0:3], v4", "\tglobal_store_dwordx4 v[0:1], v[2:5], off",
+        "\ts_barrier", "\tv_rcp_f32_e32 v2, v1", "\tv_add_f32_e32 v3, v2, v1", "\ts_endpgm", ".Lfunc_end1:",
+        "\t.amdhsa_kernel k1", "\t.end_amdhsa_kernel"]))
+    got = m.kernels_of(str(asm))
+    assert list(got) == ["k1"]
+    assert dict(got["k1"]) == {"salu": 4, "waitcnt": 1, "trans": 2, "mfma": 1, "lds": 1, "vmem": 1, "barrier": 1, "valu": 1}
