@@ -38,6 +38,9 @@ __device__ __forceinline__ int xcd_tile(int ntile_total) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+#ifndef ICAF_EPI_FAST
+#define ICAF_EPI_FAST 0          // 1: the restructured write-back (A/B builds; see the epilogue)
+#endif
 // ---- epilogue shared by both pipelines: bias + activation in registers, LDS staging, 16-byte write-back --------
 // row_to_m(tile_row) -> linear output pixel index (b, ho, wo), or -1 when the tile row lies outside the tensor.
 // PRE = true compiles the pre-activation bilinear term in (it costs ~40 registers, so only the few instantiations that
@@ -169,6 +172,74 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
         }
         return;
     }
+#if ICAF_EPI_FAST
+    // A/B build (tools/build_variant.py ... -DICAF_EPI_FAST=1; NOT the product library yet: prepared at the end of round 4, to be measured): the write-back as
+    // two checked fast loops — whole tiles in 16-byte vectors, without / with a vector residual — and ONE compact general loop (not unrolled, nothing held
+    // across iterations) for everything else, instead of the unrolled general loop below whose four fall-back paths cost ~30 instructions of branching
+    // per 16-byte store.  Same arithmetic in every path (staged vector + alpha_res * residual, fma per element).
+    if constexpr (VO == E::VEC && NVEC % NT == 0 && (VPR & (VPR - 1)) == 0) {
+        if (vec_y && n0 + BN <= Cout && (!rg || p.vec_r)) {            // (workgroup-uniform)
+            if (!rg) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int idx = tid + it * NT, row = idx / VPR, cv = idx & (VPR - 1);
+                    const int m = row_to_m(row);
+                    if (m >= 0) *(u32x4*)(yg + (long long)m * ldy + n0 + cv * VO) = *(const u32x4*)(lds + row * SO + cv * 16);
+                }
+            } else {
+                u32x4 rv[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {                     // all residual vectors in flight first (clamped rows: never used)
+                    const int idx = tid + it * NT, row = idx / VPR, cv = idx & (VPR - 1);
+                    const int m = row_to_m(row);
+                    rv[it] = *(const u32x4*)(rg + (long long)(m < 0 ? 0 : m) * p.ldr + n0 + cv * VO);
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int idx = tid + it * NT, row = idx / VPR, cv = idx & (VPR - 1);
+                    const int m = row_to_m(row);
+                    if (m < 0) continue;
+                    float v[VO], r[VO];
+                    unpack16<ODT>(*(const u32x4*)(lds + row * SO + cv * 16), v);
+                    unpack16<DT>(rv[it], r);
+#pragma unroll
+                    for (int j = 0; j < VO; ++j) v[j] = __builtin_fmaf(alpha_res, r[j], v[j]);
+                    const u32x4 o = pack16<ODT>(v);
+                    if constexpr (WB) *(u32x4*)(lds + row * SO + cv * 16) = o;
+                    *(u32x4*)(yg + (long long)m * ldy + n0 + cv * VO) = o;
+                }
+            }
+            return;
+        }
+#pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, row = idx / VPR, cv = idx & (VPR - 1);
+            const int m = row_to_m(row), n = n0 + cv * VO;
+            if (m < 0 || n >= Cout) continue;
+            const u32x4 sv = *(const u32x4*)(lds + row * SO + cv * 16);
+            const int nvalid = (Cout - n) < VO ? (Cout - n) : VO;
+            typename EO::type* yp = yg + (long long)m * ldy + n;
+            if (!rg && vec_y && nvalid == VO) { *(u32x4*)yp = sv; continue; }
+            float v[VO];
+            unpack16<ODT>(sv, v);
+            if (rg) {
+                const typename E::type* rp = rg + (long long)m * p.ldr + n;
+                if (p.vec_r && nvalid == VO) {
+                    float r[VO];
+                    unpack16<DT>(*(const u32x4*)rp, r);
+#pragma unroll
+                    for (int j = 0; j < VO; ++j) v[j] = __builtin_fmaf(alpha_res, r[j], v[j]);
+                } else {
+                    for (int j = 0; j < nvalid; ++j) v[j] = __builtin_fmaf(alpha_res, E::ld(rp + j), v[j]);
+                }
+            }
+            if constexpr (WB) *(u32x4*)(lds + row * SO + cv * 16) = pack16<ODT>(v);
+            if (vec_y && nvalid == VO) *(u32x4*)yp = pack16<ODT>(v);
+            else for (int j = 0; j < nvalid; ++j) EO::st(yp + j, v[j]);
+        }
+        return;
+    }
+#endif
     // residual vectors of all of this thread's output vectors first (one batch of loads in flight instead of a
     // load -> wait -> add -> store chain per vector)
     u32x4 rvec[NIT];
