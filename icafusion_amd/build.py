@@ -108,10 +108,21 @@ def build(force=False, verbose=True):
         # visibility: the extern "C" entry points carry default visibility through the flag below
         cmd = [cc] + [c for c in COMMON if c != "-fvisibility=hidden"] + PER_FILE.get(src, []) + \
               ["-c", os.path.join(CSRC, src), "-o", obj]
+        # per-object cache: an object is reused when its source, every header and its flags are unchanged (a kernel iteration recompiles ONE
+        # file instead of fifteen: 20-200 s instead of 3.5 min); the resource remarks of the compile are kept beside it
+        key = _digest([os.path.join(CSRC, src)] + headers, " ".join(cmd[1:]))
+        keyf, resf = obj[:-2] + ".key", obj[:-2] + ".res.json"
+        if not force and os.path.exists(obj) and os.path.exists(keyf) and os.path.exists(resf) and open(keyf).read().strip() == key:
+            return obj, json.load(open(resf))
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr[-6000:]}")
-        return obj, parse_resources(r.stderr)
+        res1 = parse_resources(r.stderr)
+        with open(resf, "w") as f:
+            json.dump(res1, f)
+        with open(keyf, "w") as f:
+            f.write(key)
+        return obj, res1
 
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         results = list(ex.map(compile_one, srcs))

@@ -280,7 +280,7 @@ constexpr int S2_SHALF = 40, S2_SPITCH = 80;                           // PHYSIC
 constexpr int S2_NS = S2_SR * S2_SPITCH;                               // 880 entries of 32 bytes
 constexpr int S2_S2D_BYTES = ((S2_NS * 2 + 63) / 64) * 1024;           // 28 KiB
 static_assert(S2_PITCH % 16 == 0 && S2_HALF % 16 == 0 && S2_SPITCH % 16 == 0, "tap offsets must keep the swizzle keys");
-static_assert(S2_LHALF <= S2_HALF && S2_HALF + S2_LHALF - 1 <= S2_PITCH && S2_SPAIRS <= S2_SHALF && S2_SHALF + S2_SPAIRS <= S2_SPITCH, "planes fit their rows");
+static_assert(S2_LHALF <= S2_HALF && S2_HALF + S2_HWD / 2 - 1 < S2_PITCH && S2_SPAIRS <= S2_SHALF && S2_SHALF + S2_SPAIRS <= S2_SPITCH, "planes fit their rows");
 static_assert(S2_NS <= 2 * 512, "two space-to-depth entries per thread");
 constexpr int S2_THREADS = 512;
 constexpr int S2_C0 = 32, S2_C1 = 64, S2_C2 = 64, S2_W1_SLICES = 5;    // K1 = 288 -> 5 slices of 128 bytes
@@ -434,7 +434,9 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
             s1_rd[jj][kx] = ((e << 1) + (hi ^ ((e >> 3) & 1))) << 4;
         }
         const int idx = hy * S2_PITCH + pl * S2_HALF + i;                      // physical entry of the stem pixel in the halo patch
-        s1_wr[jj] = lidx < S2_NL ? (idx << 6) + (hi << 3) : -1;                // byte address of channel quad 0's slot 0 (+ 8 bytes for the upper lane half)
+        // (the logical enumeration has S2_LHALF = 33 odd slots per row but only 32 odd columns exist: the phantom slot (hx = 65) would land on the next
+        //  row's even column 0 — the same address another lane of the same ds_write targets — and, in the last row, one entry past the patch: never stored)
+        s1_wr[jj] = (lidx < S2_NL && 2 * i + pl < S2_HWD) ? (idx << 6) + (hi << 3) : -1;      // byte address of channel quad 0's slot 0 (+ 8 bytes for the upper lane half)
         s1_key[jj] = (idx >> 2) & 3;
         s1_hy[jj] = hy;
         s1_hx[jj] = 2 * i + pl;

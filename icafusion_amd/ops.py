@@ -329,8 +329,8 @@ def conv_candidates(a):
         cands += cw
     if a.wf and WREG_GEMM and not a.pre and not a.w2:
         cands.append(61)                     # weights fed from registers (igemm_wreg.hip): 128 x 128 ...
-        if a.Cout > 128:
-            cands.append(62)                 # ... and 128 x 256
+        if a.Cout > 128 and -(-a.Cout // 256) * 256 <= -(-a.Cout // 128) * 128:
+            cands.append(62)                 # ... and 128 x 256 (its last channel tile must stay inside the packed Np = Cout rounded up to 128: wreg_check)
         # round 4: a wave owns 64 channels — the pixel feed per MAC halves
         if a.Cout > 128 and a.Cout % 256 == 0:
             cands.append(64)                 # 128 x 256 with four waves: two workgroups per CU
@@ -692,6 +692,8 @@ def dmff_wide_ksplit(N, C_, hidden):
     batch 32, 4.7 MB of weights per modality), else 1.  Deliberately a function of the LEVEL (N, C), never of the batch size: the split
     changes the fp32 association of the fc2 sum, and a shard of a batch must reproduce the same rows of the full batch bit for bit
     (tests/test_gpu_fullsize.py; yolov5l's P4 — C = 512, N = 256, one tile per CU at batch 32 — measured slower with the split anyway)."""
+    if C_ < 256:
+        return 1                                     # icaf_dmff_wide_proj_mlp_split is built for the 256-channel passes (C = 256 / 512) only
     if DMFF_KSPLIT:
         return DMFF_KSPLIT if hidden % (256 * DMFF_KSPLIT) == 0 else 1
     return 2 if (9 * C_ * C_ * 2 > 3 * 2 ** 20 and N <= 128 and hidden % 512 == 0) else 1

@@ -85,8 +85,12 @@ def test_strong_scaling_helpers_cover_uneven_splits():
             cnt[r, k] = lo + k
     dg, cg = D.gathered_to_global(det, cnt, G)
     assert dg.shape == (G, max_det, 6) and cg.tolist() == list(range(G)) and [float(dg[i, 0, 0]) for i in range(G)] == list(range(G))
-    de, ce = D.gathered_to_global(det[:, :2], cnt[:, :2], 8)           # an even split comes back as views
-    assert de.shape == (8, max_det, 6) and de.data_ptr() == det[:, :2].reshape(-1, max_det, 6).data_ptr() or de.shape[0] == 8
+    det_even, cnt_even = det[:, :2].contiguous(), cnt[:, :2].contiguous()       # (world, 2, ...): 8 pairs over 4 ranks, no padding
+    de, ce = D.gathered_to_global(det_even, cnt_even, 8)                       # an even split comes back as VIEWS of the gathered block
+    assert de.shape == (8, max_det, 6) and ce.shape == (8,)
+    assert de.untyped_storage().data_ptr() == det_even.untyped_storage().data_ptr() and de.data_ptr() == det_even.data_ptr()
+    assert ce.untyped_storage().data_ptr() == cnt_even.untyped_storage().data_ptr() and ce.data_ptr() == cnt_even.data_ptr()
+    assert torch.equal(de, det_even.reshape(8, max_det, 6)) and torch.equal(ce, cnt_even.reshape(8))
 
 
 def test_bench_strong_scaling_launch_with_four_ranks_and_an_uneven_split():
