@@ -30,7 +30,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=
           "-Rpass-analysis=kernel-resource-usage"]
 RESOURCES = os.path.join(LIBDIR, "kernel_resources.json")
 # kernels whose K loops use counted vmcnt waits: any scratch use (spill) would race with them
-NO_SCRATCH = re.compile(r"cstream_kernel|cwide_kernel|cwpers_kernel|detect_conv_kernel|igemm_dma_kernel|igemm_stream_kernel|igemm_wreg_kernel|ctile_kernel|bneck_kernel|stem_kernel|stem2_kernel|dmff_\w*kernel")
+NO_SCRATCH = re.compile(r"cstream_kernel|cwide_kernel|cwpers_kernel|detect_conv_kernel|igemm_dma_kernel|igemm_stream_kernel|igemm_wreg_kernel|igemm_pers_kernel|ctile_kernel|bneck_kernel|stem_kernel|stem2_kernel|dmff_\w*kernel")
 _REMARK = re.compile(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|"
                      r"LDS Size \[bytes/block\]|VGPRs Spill|SGPRs Spill):\s+(\S+)")
 

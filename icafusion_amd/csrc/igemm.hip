@@ -469,12 +469,15 @@ const char* cwpers_tag(int shape);
 int wreg_check(const icaf_conv_args* a, const ConvP& p, int shape);
 int launch_wreg(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
 const char* wreg_tag(int shape);
+// igemm_pers.hip
+int pers_check(const icaf_conv_args* a, const ConvP& p);
+int launch_pers(const icaf_conv_args* a, const ConvP& p, hipStream_t s);
 
 //   40 + shape: 3x3 direct convolution from an LDS halo tile (ctile.hip); 50 + shape: persistent streaming GEMM for 1x1 layers
 //   (igemm_stream.hip); 60 + shape: weight operand fed from registers (igemm_wreg.hip); an explicit request that the layer cannot
 //   satisfy is an error (the autotuner skips it), it is never chosen silently.  71: persistent 3x3 with a resident filter (cstream.hip);
 //   80 + shape: 3x3 (stride 1 / 2) from a resident halo patch with the weights streamed per wave into registers (cwide.hip);
-//   90 + shape: its persistent form (cwpers.hip).
+//   90 + shape: its persistent form (cwpers.hip).  67: persistent, balanced 256-channel implicit GEMM for the long-K layers (igemm_pers.hip).
 static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
     const bool dma_ok = p.x_bytes != 0;
     if (a->tile > 40 && a->tile < 100) return a->tile;
@@ -708,6 +711,7 @@ extern "C" int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s) {
     if (tile > 90) return launch_cwpers(a, p, tile - 90, hs); // the same, persistent: double-buffered patch, rolling weight stream (cwpers.hip)
     if (tile > 80) return launch_cwide(a, p, tile - 80, hs);  // 3x3 (stride 1 / 2) from a resident halo patch, weights streamed into registers
     if (tile > 70) return fail(ICAF_ERR_ARG, "unknown tile id %d", tile);
+    if (tile == 67) return launch_pers(a, p, hs);             // persistent, balanced spans of 256-channel tiles, one workgroup per CU (igemm_pers.hip)
     if (tile > 60) return launch_wreg(a, p, tile - 60, hs);
     if (tile > 50) return launch_stream(a, p, tile - 50, hs);
     if (tile > 40) return launch_ctile(a, p, tile - 40, hs);
@@ -765,6 +769,12 @@ extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int b
         return ICAF_OK;
     }
     if (tile > 70) return fail(ICAF_ERR_ARG, "unknown tile id %d", tile);
+    if (tile == 67) {
+        st = pers_check(a, p);
+        if (st) return st;
+        snprintf(buf, buf_len, "igemm_pers_%s_256x256", dn[a->dtype]);
+        return ICAF_OK;
+    }
     if (tile > 60) {
         st = wreg_check(a, p, tile - 60);
         if (st) return st;

@@ -105,6 +105,8 @@ TAIL_8X16_MINPIX = int(os.environ.get("ICAF_TAIL_8X16_MINPIX", 200_000))     # c
 CWIDE = os.environ.get("ICAF_CWIDE", "1") != "0"               # A/B switch: resident-patch / streamed-weights 3x3 kernel (cwide.hip) as a tuner candidate
 CSTREAM = os.environ.get("ICAF_CSTREAM", "1") != "0"           # A/B switch: persistent resident-filter 3x3 kernel as a tuner candidate
 WREG_GEMM = os.environ.get("ICAF_WREG_GEMM", "1") != "0"       # A/B switch: weights-from-registers kernels as tuner candidates
+PERS_GEMM = os.environ.get("ICAF_PERS_GEMM", "1") != "0"       # A/B switch: the persistent long-K GEMM (launch configuration 67) as a tuner candidate
+PERS_MIN_K = int(os.environ.get("ICAF_PERS_MIN_K", "512"))      # ... offered to layers with at least this many K elements (eight 64-element slices)
 WREG64_MAXPIX = int(os.environ.get("ICAF_WREG64_MAXPIX", str(128 * 1024)))     # launches with at most this many pixels are offered the 64-pixel wreg tiles
 
 
@@ -336,6 +338,8 @@ def conv_candidates(a):
             cands.append(64)                 # 128 x 256 with four waves: two workgroups per CU
         if a.Cout > 256 and a.Cout % 512 == 0 and a.act != ACT_GELU:
             cands.append(63)                 # 128 x 512 with eight waves
+        if a.Cout % 256 == 0 and a.kh * a.kw * a.Cin >= PERS_MIN_K and a.kh * a.kw <= 16 and not (a.act == ACT_GELU and a.kh * a.kw > 1) and PERS_GEMM:
+            cands.append(67)                 # round 5: persistent, balanced spans of 256-channel tiles, one eight-wave workgroup per CU (igemm_pers.hip)
         if a.B * a.Ho * a.Wo * a.groups <= WREG64_MAXPIX:  # few pixels (the 20 x 20 / 40 x 40 rows at batch 32): 64-pixel tiles double the workgroups
             cands.append(66)                 # 64 x 128, four waves x 32 channels
             if a.Cout > 128 and a.Cout % 256 == 0:

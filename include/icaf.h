@@ -115,7 +115,8 @@ typedef struct icaf_conv_args {
     float alpha_res[2];
     int tile; /* 0 = auto; otherwise force a launch configuration (tuning / tests; a configuration the layer does not satisfy is an error,
                * never replaced silently).  1-4 (+10 / 20 / 30 per pipeline), 25 / 26 / 28 / 29: igemm.hip tiles; 40 + shape: ctile.hip;
-               * 51 / 52: igemm_stream.hip; 61 / 62: igemm_wreg.hip; 71: cstream.hip; 80 + shape: cwide.hip; 90 + shape: cwpers.hip.
+               * 51 / 52: igemm_stream.hip; 61 - 66: igemm_wreg.hip; 67: igemm_pers.hip (persistent long-K GEMM, Cout in whole 256-channel tiles);
+               * 71: cstream.hip; 80 + shape: cwide.hip; 90 + shape: cwpers.hip.
                * Every configuration of a layer produces the same bits (same K order, MFMA step, epilogue expressions). */
     /* Optional pre-activation term, bilinearly resized (align_corners=False) from a coarse fp32 map:
      *   y = alpha_res*res + alpha_acc * act( A.W + bias + bilinear(pre)[b][ho][wo][n] )

@@ -155,6 +155,8 @@ def test_pmc_summary_kernel_names_match_bench_names():
         "void icaf::igemm_wreg_kernel<2, 4, 0, 1, 1, 64>(icaf::ConvP, void const*, long long)": "igemm_wreg_f16_64x128",
         "void icaf::igemm_wreg_kernel<1, 4, 1, 1, 2, 64>(icaf::ConvP, void const*, long long)": "igemm_wreg_bf16_64x256",
         "void icaf::igemm_wreg_kernel<1, 8, 1, 1, 2, 128>(icaf::ConvP, void const*, long long)": "igemm_wreg_bf16_128x512",
+        "void icaf::igemm_pers_kernel<1, 1, 2>(icaf::ConvP, void const*, long long, int)": "igemm_pers_bf16_256x256",
+        "void icaf::igemm_pers_kernel<2, 0, 1>(icaf::ConvP, void const*, long long, int)": "igemm_pers_f16_256x256",
         "void icaf::detect_conv_kernel<1, 3, 6>(icaf::ConvP, icaf::DetectEpi<3, 6>)": "detect_conv+decode",
         "void icaf::detect_decode_kernel<true>(float const*, int, float*)": "detect_decode",
         "void icaf::upsample_kernel<true>(unsigned int __vector(4) const*, int)": "upsample_nearest",

@@ -34,6 +34,9 @@ def short(name):
         tn, bm = int(m.group(3) or 1), int(m.group(4) or 128)
         tag = {(4, 1, 128): "128x128", (8, 1, 128): "128x256", (8, 2, 128): "128x512", (4, 2, 128): "128x256w4", (4, 2, 64): "64x256", (4, 1, 64): "64x128"}.get((nwv, tn, bm), f"{bm}x{32 * nwv * tn}")
         return f"igemm_wreg_{_DN[dt]}_{tag}"                                    # (= wreg_tag() of igemm_wreg.hip, what bench.py reports)
+    m = re.match(r"icaf::igemm_pers_kernel<(\d+), \d+, \d+>", name)            # persistent long-K GEMM (DT, ACT, MODE)
+    if m:
+        return f"igemm_pers_{_DN[int(m.group(1))]}_256x256"
     m = re.match(r"icaf::cstream_kernel<(\d+), (true|false)>", name)              # persistent 3x3, filter resident in LDS
     if m:
         return f"cstream_{_DN[int(m.group(1))]}_8x16n64"                        # (with or without the chained 1x1: one name, as bench.py reports it)
