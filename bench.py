@@ -173,7 +173,7 @@ def h2d_feed(model, args, B, H, W, dev):
     from icafusion_amd.pipeline import DetectionPipeline
     pipe = DetectionPipeline(model, B, H, W, dev, conf_thres=args.conf, iou_thres=args.iou, world=1, overlap=not args.no_overlap,
                              depth=args.depth, u8=True)
-    nbuf = pipe.depth + 3
+    nbuf = pipe.nplans + 2
     g = torch.Generator().manual_seed(1234)
     host = [torch.randint(0, 256, (B, 6, H, W), dtype=torch.uint8, generator=g).pin_memory() for _ in range(nbuf)]
     for k in range(max(args.warmup, nbuf)):
@@ -205,8 +205,8 @@ def h2d_feed(model, args, B, H, W, dev):
     return {"pairs_per_s_with_h2d": round(rate, 2), "min": round(min(rates), 2), "max": round(max(rates), 2),
             "host_bytes_per_batch": nbytes, "pcie_gbs_achieved_in_loop": round(rate / B * nbytes / 1e9, 2),
             "pcie_gbs_copy_alone": round(nbytes / copy_s / 1e9, 2), "copy_alone_ms_per_batch": round(1e3 * copy_s, 3),
-            "note": f"pinned host uint8 (B,6,H,W) -> one of {pipe.depth + 1} device staging buffers on a copy stream, device-to-device into the plan's input in front of "
-                    f"each replay, {pipe.depth} batch(es) in flight, {nbuf} rotating host buffers; "
+            "note": f"pinned host uint8 (B,6,H,W) -> ONE copy on a high-priority copy stream straight into the input buffer of one of {pipe.nplans} plans "
+                    f"(the one not in flight), {pipe.depth} batch(es) in flight, {nbuf} rotating host buffers; "
                     "forward from uint8 (icaf_stem2 / icaf_preprocess_u8) + NMS; median of 3 x K steps"}
 
 

@@ -39,7 +39,11 @@ __device__ __forceinline__ int xcd_tile(int ntile_total) {
 }
 
 #ifndef ICAF_EPI_FAST
-#define ICAF_EPI_FAST 0          // 1: the restructured write-back (A/B builds; see the epilogue)
+#define ICAF_EPI_FAST 1          // 1: the restructured write-back (round 5: adopted after the whole GPU suite ran green on the variant library and a same-box
+                                 //    A/B: default workload 16,141 -> 16,191 pairs/s, forward 2.191 -> 2.169 ms; yolov5l shard 3,726 -> 3,803, 9.34 -> 9.10 ms); 0: round 4's loop
+#endif
+#ifndef ICAF_PRE_WB
+#define ICAF_PRE_WB 1            // 1: the pre-activation term is added in the write-back phase from an fp32-staged tile (0: round 4's per-lane taps; A/B builds)
 #endif
 // ---- epilogue shared by both pipelines: bias + activation in registers, LDS staging, 16-byte write-back --------
 // row_to_m(tile_row) -> linear output pixel index (b, ho, wo), or -1 when the tile row lies outside the tensor.
@@ -66,6 +70,114 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
     const float alpha_acc = SECOND ? 1.0f : p.alpha_acc[g], alpha_res = p.alpha_res[g];
     const float* __restrict__ bias = SECOND ? (p.bias2 ? p.bias2 + g * p.bias2_gs : nullptr) : (p.bias ? p.bias + g * p.bias_gs : nullptr);
     const int Cout = SECOND ? p.Cout2 : p.Cout, ldy = SECOND ? p.ldy2 : p.ldy, vec_y = SECOND ? p.vec_y2 : p.vec_y;
+    if constexpr (PRE && ICAF_PRE_WB) {
+        // Round 5 — the pre-activation term is added in the WRITE-BACK phase.  With the lane = pixel mapping of the accumulators every tap load was 64
+        // lanes x 16 bytes in 64 different rows of the fp32 map (a row is Cout * 4 = 512 - 2048 bytes): uncoalesced, 16 * TN * TM such loads per lane —
+        // the three fuse convolutions of yolov5s took 154 us where plain 1x1 layers of their shapes take ~60.  Here the tile is staged as FP32
+        // (acc + bias, exactly the sum the old path formed first), and the thread that writes a 16-byte output vector adds the term: the VPR threads of
+        // a pixel read 4 taps x (BN * 4) CONTIGUOUS bytes.  Same expressions in the same order ((acc + bias) + term, fp contraction off in the
+        // bilinear arithmetic) => the same bits as before (tests: every configuration of a pre-term launch against the others and against torch).
+        constexpr int SOF = BN * 4 + 16;                   // fp32 staging row stride (bytes)
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            f32x4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * WN + a * 32 + 8 * q + 4 * hi;
+                const bool okn = bias && n < Cout;
+                const float* bp = okn ? bias + n : (const float*)p.w;
+                const f32x4 t = *(const f32x4*)bp;
+                bq[q] = okn ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wn * WN + a * 32 + 8 * q + 4 * hi;
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const int ml = wm * WM + b * 32 + l31;
+                    f32x4 t;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] = acc[a][b][4 * q + j] + bq[q][j];
+                    *(f32x4*)(lds + ml * SOF + nl * 4) = t;
+                }
+            }
+        }
+        __syncthreads();
+        typename EO::type* __restrict__ yg2 = SECOND ? (typename EO::type*)p.y2 + g * p.y2_gs : (typename EO::type*)p.y + g * p.y_gs;
+        const typename E::type* __restrict__ rg2 = (!SECOND && p.res) ? (const typename E::type*)p.res + g * p.res_gs : nullptr;
+        constexpr int VPR2 = BN / VO, NVEC2 = BM * VPR2, NIT2 = (NVEC2 + NT - 1) / NT;
+        const float sy = (float)p.pre_h / (float)p.Ho, sx = (float)p.pre_w / (float)p.Wo;
+#pragma unroll 2
+        for (int it = 0; it < NIT2; ++it) {
+            const int idx = tid + it * NT;
+            if (idx >= NVEC2) break;
+            const int row = idx / VPR2, cv = idx - row * VPR2;
+            const int m = row_to_m(row), n = n0 + cv * VO;
+            if (m < 0 || n >= Cout) continue;
+            const float* pt4[4];
+            float lx, ly;
+            {
+#pragma clang fp contract(off)
+                const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, bi = t / p.Ho;
+                float fy = ((float)ho + 0.5f) * sy - 0.5f, fx = ((float)wo + 0.5f) * sx - 0.5f;
+                fy = fy < 0.0f ? 0.0f : fy;
+                fx = fx < 0.0f ? 0.0f : fx;
+                int y0 = (int)fy, x0 = (int)fx;
+                y0 = y0 < p.pre_h - 1 ? y0 : p.pre_h - 1;
+                x0 = x0 < p.pre_w - 1 ? x0 : p.pre_w - 1;
+                int y1 = y0 < p.pre_h - 1 ? y0 + 1 : y0, x1 = x0 < p.pre_w - 1 ? x0 + 1 : x0;
+                ly = fy - (float)y0;
+                lx = fx - (float)x0;
+                if (p.pre_mode == 1) {             // nearest: one tap with weight 1 — the sequence below returns it exactly
+                    y0 = y1 = (int)((long long)ho * p.pre_h / p.Ho);
+                    x0 = x1 = (int)((long long)wo * p.pre_w / p.Wo);
+                    ly = lx = 0.0f;
+                }
+                const float* base = p.pre + (long long)bi * p.pre_h * p.pre_w * p.ldpre + n;
+                pt4[0] = base + (long long)(y0 * p.pre_w + x0) * p.ldpre;
+                pt4[1] = base + (long long)(y0 * p.pre_w + x1) * p.ldpre;
+                pt4[2] = base + (long long)(y1 * p.pre_w + x0) * p.ldpre;
+                pt4[3] = base + (long long)(y1 * p.pre_w + x1) * p.ldpre;
+            }
+            const int nvalid = (Cout - n) < VO ? (Cout - n) : VO;
+            float v[VO];
+#pragma unroll
+            for (int k4 = 0; k4 < VO / 4; ++k4) {
+                const f32x4 t = *(const f32x4*)(lds + row * SOF + (cv * VO + 4 * k4) * 4);
+                float pv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (n + 4 * k4 < Cout) {           // (the old path's guard, per accumulator quad: ldpre >= Cout rounded up to 4)
+                    const f32x4 t00 = *(const f32x4*)(pt4[0] + 4 * k4), t01 = *(const f32x4*)(pt4[1] + 4 * k4);
+                    const f32x4 t10 = *(const f32x4*)(pt4[2] + 4 * k4), t11 = *(const f32x4*)(pt4[3] + 4 * k4);
+                    {
+#pragma clang fp contract(off)
+                        const float wx0 = 1.0f - lx, wy0 = 1.0f - ly;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float top = t00[j] * wx0 + t01[j] * lx;
+                            const float bot = t10[j] * wx0 + t11[j] * lx;
+                            pv[j] = top * wy0 + bot * ly;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[4 * k4 + j] = apply_act<ACT, DT>(t[j] + pv[j]) * alpha_acc;
+            }
+            u32x4 o = pack16<ODT>(v);                      // rounded to the storage type, as the staged tile of the other path is
+            typename EO::type* yp = yg2 + (long long)m * ldy + n;
+            if (rg2) {
+                unpack16<ODT>(o, v);
+                const typename E::type* rp = rg2 + (long long)m * p.ldr + n;
+                for (int j = 0; j < nvalid; ++j) v[j] = __builtin_fmaf(alpha_res, E::ld(rp + j), v[j]);
+                o = pack16<ODT>(v);
+            }
+            if (vec_y && nvalid == VO) *(u32x4*)yp = o;
+            else {
+                unpack16<ODT>(o, v);
+                for (int j = 0; j < nvalid; ++j) EO::st(yp + j, v[j]);
+            }
+        }
+        return;
+    }
     // pre-activation bilinear term: the four source taps and weights of this lane's TM pixels (align_corners=False:
     // src = max(0, (dst + 0.5) * in/out - 0.5), neighbours clamped), exactly as upsample_merge_kernel computes them
     const float* pt[PRE ? TM : 1][4];
@@ -173,8 +285,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
         return;
     }
 #if ICAF_EPI_FAST
-    // A/B build (tools/build_variant.py ... -DICAF_EPI_FAST=1; NOT the product library yet: prepared at the end of round 4, to be measured): the write-back as
-    // two checked fast loops — whole tiles in 16-byte vectors, without / with a vector residual — and ONE compact general loop (not unrolled, nothing held
+    // The write-back as two checked fast loops — whole tiles in 16-byte vectors, without / with a vector residual — and ONE compact general loop (not unrolled, nothing held
     // across iterations) for everything else, instead of the unrolled general loop below whose four fall-back paths cost ~30 instructions of branching
     // per 16-byte store.  Same arithmetic in every path (staged vector + alpha_res * residual, fma per element).
     if constexpr (VO == E::VEC && NVEC % NT == 0 && (VPR & (VPR - 1)) == 0) {
@@ -300,6 +411,7 @@ template <int DT, int ODT, int BM, int BN>
 struct TileLds {
     static constexpr int SO = BN * Elem<ODT>::BYTES + 16;
     static constexpr int OUT_BYTES = BM * SO;
+    static constexpr int PRE_BYTES = ICAF_PRE_WB ? BM * (BN * 4 + 16) : OUT_BYTES;      // pre-term launches stage the tile as fp32 (epilogue)
     static constexpr int REG_BYTES = 2 * (BM + BN) * ROWS;
 };
 

@@ -516,7 +516,7 @@ static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
 
 template <int DT, int ODT, int BM, int BN, int WM, int WN, int ACT, int RB, int NS, int MODE, bool PRE = false, bool CHAIN = false>
 static int launch_dma_mode(const ConvP& q, dim3 grid, hipStream_t s) {
-    constexpr int ring_only = NS * (BM + BN) * RB, stage_out = TileLds<DT, ODT, BM, BN>::OUT_BYTES;
+    constexpr int ring_only = NS * (BM + BN) * RB, stage_out = PRE ? TileLds<DT, ODT, BM, BN>::PRE_BYTES : TileLds<DT, ODT, BM, BN>::OUT_BYTES;
     constexpr int ring0 = ring_only > stage_out ? ring_only : stage_out;
     constexpr int ring = CHAIN ? (ring0 + 1023) / 1024 * 1024 + BN * BN * 2 : ring0;      // + the chained layer's weights
     static_assert(ring <= 160 * 1024, "LDS capacity");

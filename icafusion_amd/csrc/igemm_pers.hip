@@ -24,10 +24,22 @@
 // all channel tiles of a span side by side, so taps and halo rows are shared through ONE L2 and the weights of a stream stay in its own XCDs' L2s.
 #include "conv_common.h"
 
+// Ablation switches for timing studies (tools/quick_variant.py <tag> igemm_pers.hip -DICAF_PERS_ABL=n; results are then meaningless):
+//   1 = no weight loads, 2 = no pixel DMA, 4 = no LDS fragment reads, 8 = no workgroup barrier in the K step, 16 = no epilogue, 32 = no MFMAs
+#ifndef ICAF_PERS_ABL
+#define ICAF_PERS_ABL 0
+#endif
+// 1: every wave waits, at the top of step q, for ITS portion of pixel slice q + 1 as well (two slices in flight instead of three), so the barrier of step q
+//    publishes slice q + 1 too and the first fragment group of the next slice is read at the END of a step, under its last MFMAs — nothing but the barrier
+//    itself stands between the MFMAs of two slices.  0: slice q only, the first group of a slice is read behind its barrier (A/B builds).
+#ifndef ICAF_PERS_EARLY
+#define ICAF_PERS_EARLY 1
+#endif
+
 namespace icaf {
 
-constexpr int PERS_BN = 256, PERS_TMAX = 8, PERS_NW = 8, PERS_NS = 4, PERS_RB = 128;
-constexpr int PERS_STAGE = PERS_TMAX * 32 * PERS_RB;                 // 32 KiB: 256 pixel rows x 128 bytes of K
+constexpr int PERS_BN = 256, PERS_TMAX = 7, PERS_NW = 8, PERS_NS = 4, PERS_RB = 128;      // (TMAX = 8 fits alone — 244 registers — but not beside the other seven loop bodies)
+constexpr int PERS_STAGE = 8 * 32 * PERS_RB;                         // 32 KiB: room for 256 pixel rows x 128 bytes of K (every wave issues 4 DMA instructions per slice)
 constexpr int PERS_EPITCH = 80;                                      // bytes per pixel row of a wave's private transposition buffer (64 + 16)
 constexpr int PERS_EBUF = 32 * PERS_EPITCH;                          // 2560 bytes per wave
 constexpr int PERS_LDS = PERS_NS * PERS_STAGE + PERS_NW * PERS_EBUF; // 151,552 bytes: one workgroup per CU
@@ -119,7 +131,8 @@ __global__ __launch_bounds__(PERS_NW * 64) void igemm_pers_kernel(const ConvP p,
                 const bool ok = tap < ntaps && ((a_mask[i >> 1] >> ((i & 1) * 16 + tap)) & 1u);          // (tap == ntaps: a padding slice past K)
                 voff = ok ? a_off[i] + tap_delta : OOB;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
+            if constexpr (!(ICAF_PERS_ABL & 2))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
         }
     };
     auto issue_advance = [&]() {                                      // (wave-uniform)
@@ -137,15 +150,19 @@ __global__ __launch_bounds__(PERS_NW * 64) void igemm_pers_kernel(const ConvP p,
 
     // ---- weight operand: fragment-major [channel block of 32][MFMA step of 16 K][lane][8 elements]; this wave's channel block -------------------
     const int ksteps = p.Kp / 16;                                     // MFMA steps per channel block row
-    const u32x4* __restrict__ wf = (const u32x4*)((const typename E::type*)wfrag + g * wf_gs)
-                                   + ((long long)(n0 / 32 + wave) * ksteps) * 64 + lane;
+    // (a wave-uniform 64-bit base in scalar registers + ONE 32-bit lane offset: global_load ... v_off, s[base] — per-load 64-bit vector addresses cost
+    //  this kernel the registers of its fragment double-buffer)
+    const unsigned char* __restrict__ wbase = (const unsigned char*)((const typename E::type*)wfrag + g * wf_gs)
+                                              + ((long long)(n0 / 32 + wave) * ksteps) * 1024;
+    const unsigned wlane = (unsigned)lane * 16u;
     const int last_step = ksteps - 1;
     auto load_w = [&](u32x4 (&dst)[NSTEP], int chunk) {               // unconditional, clamped: past the end the last fragments are re-read
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             int ks = chunk * NSTEP + s;
             ks = ks < last_step ? ks : last_step;
-            dst[s] = wf[(long long)ks * 64];
+            if constexpr (ICAF_PERS_ABL & 1) dst[s] = u32x4{(unsigned)ks, (unsigned)lane, 0x3f803f80u, 0x3f803f80u};
+            else dst[s] = *(const u32x4*)(wbase + (long long)ks * 1024 + wlane);
         }
     };
 
@@ -188,48 +205,56 @@ __global__ __launch_bounds__(PERS_NW * 64) void igemm_pers_kernel(const ConvP p,
         // One slice step.  P = c % NB selects the register buffer of the weight fragments of slice c (compile-time: the K loop is unrolled by NB; every
         // chunk starts at P = 0 — its slices 0 and 1 were requested into buffers 0 and 1 before the previous chunk's epilogue).  Issues, in this order,
         // the weight loads of slice c + 2 and the pixel DMA of stream slice q + NS - 1: exactly PER vector-memory operations per wave.
+        constexpr int TA = TM > 4 ? 4 : TM, TB = TM - TA, GPS = TB > 0 ? 2 : 1, NG = NSTEP * GPS;      // fragment groups per step, per slice
+        u32x4 fa[TA], fb[TB > 0 ? TB : TA];            // (fa carries the NEXT slice's first group across the step boundary: ICAF_PERS_EARLY)
         auto step = [&](auto Ptag, int c) {
             constexpr int P = decltype(Ptag)::value;
-            // stream slice q was issued three steps ago (or in the prologue): complete once at most the 2 * PER operations of the last two steps are
-            // outstanding.  Whatever else may be outstanding (a previous chunk's weight pre-loads and epilogue stores) is YOUNGER than that slice, so
-            // it can only make this wait stricter, never let it pass early (loads complete in order).
-            wait_vmcnt<2 * PER>();
+            // stream slice q (EARLY: q + 1) was issued three (two) steps ago or in the prologue: complete once at most the 2 * PER (PER) operations of the
+            // last two steps (last step) are outstanding.  Whatever else may be outstanding (a previous chunk's weight pre-loads and epilogue stores) is
+            // YOUNGER than that slice, so it can only make this wait stricter, never let it pass early (loads complete in order).
+            wait_vmcnt<ICAF_PERS_EARLY ? PER : 2 * PER>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();          // (a) slice q visible to every wave, (b) stage (q - 1) % NS is free
+            if constexpr (!(ICAF_PERS_ABL & 8))
+                __builtin_amdgcn_s_barrier();      // (a) slice q (and q + 1) visible to every wave, (b) stage (q - 1) % NS is free
             const unsigned char* a_s = lds + (q & (NS - 1)) * STAGE;
+            const unsigned char* a_n = lds + ((q + 1) & (NS - 1)) * STAGE;
             load_w(fw[(P + NB - 1) % NB], c + NB - 1);
             const int sfree = (q + NS - 1) & (NS - 1);
             // fragment reads in GROUPS of up to four 32-pixel blocks, two groups in flight: the reads of group k + 1 are issued before the MFMAs of
             // group k (left to itself under this register budget the compiler read two fragments at a time and waited for each)
-            constexpr int TA = TM > 4 ? 4 : TM, TB = TM - TA, GPS = TB > 0 ? 2 : 1, NG = NSTEP * GPS;      // groups per step, per slice
-            u32x4 fa[TA], fb[TB > 0 ? TB : TA];
-            auto rd = [&](auto& dst, auto Ktag) {
+            auto rd = [&](auto& dst, auto Ktag, const unsigned char* base) {
                 constexpr int k = decltype(Ktag)::value, s = k / GPS, b0 = (k % GPS) * TA, n = (k % GPS) ? TB : TA;
 #pragma unroll
-                for (int b = 0; b < n; ++b) dst[b] = *(const u32x4*)(a_s + ((b0 + b) * 32) * RB + foff[s]);
+                for (int b = 0; b < n; ++b) {
+                    if constexpr (ICAF_PERS_ABL & 4) dst[b] = u32x4{(unsigned)(q + b), (unsigned)foff[s], 0x3f803f80u, 0x3f803f80u};
+                    else dst[b] = *(const u32x4*)(base + ((b0 + b) * 32) * RB + foff[s]);
+                }
             };
             auto mm = [&](auto& src, auto Ktag) {
                 constexpr int k = decltype(Ktag)::value, s = k / GPS, b0 = (k % GPS) * TA, n = (k % GPS) ? TB : TA;
 #pragma unroll
-                for (int b = 0; b < n; ++b) mma_step<DT>(acc[b0 + b], fw[P][s], src[b]);
+                for (int b = 0; b < n; ++b) {
+                    if constexpr (ICAF_PERS_ABL & 32) acc[b0 + b][0] += __uint_as_float(fw[P][s][0] ^ src[b][0]);
+                    else mma_step<DT>(acc[b0 + b], fw[P][s], src[b]);
+                }
                 if constexpr (k % GPS == GPS - 1) issue_part(sfree, s);
             };
-            auto grp = [&](auto Ktag, auto& self) -> void {       // (compile-time recursion over the groups of the slice)
+            using K0 = std::integral_constant<int, 0>;
+            auto grp = [&](auto Ktag, auto& self) -> void {       // (compile-time recursion over the groups of the slice; NG is even: the last group reads fb)
                 constexpr int k = decltype(Ktag)::value;
                 if constexpr (k < NG) {
                     using K1 = std::integral_constant<int, k + 1>;
-                    if constexpr (GPS == 2) {
-                        if constexpr (k % 2 == 0) { rd(fb, K1{}); mm(fa, Ktag); }
-                        else { if constexpr (k + 1 < NG) rd(fa, K1{}); mm(fb, Ktag); }
-                    } else {                                   // one group per step: the two buffers alternate
-                        if constexpr (k % 2 == 0) { if constexpr (k + 1 < NG) rd(fb, K1{}); mm(fa, Ktag); }
-                        else { if constexpr (k + 1 < NG) rd(fa, K1{}); mm(fb, Ktag); }
+                    if constexpr (k % 2 == 0) { rd(fb, K1{}, a_s); mm(fa, Ktag); }
+                    else {
+                        if constexpr (k + 1 < NG) rd(fa, K1{}, a_s);
+                        else if (ICAF_PERS_EARLY && c + 1 < nchp) rd(fa, K0{}, a_n);          // the next slice's first group (same chunk: same TM)
+                        mm(fb, Ktag);
                     }
                     self(K1{}, self);
                 }
             };
-            rd(fa, std::integral_constant<int, 0>{});
-            grp(std::integral_constant<int, 0>{}, grp);
+            if (!ICAF_PERS_EARLY || c == 0) rd(fa, K0{}, a_s);    // (a chunk's first slice: nothing was read ahead)
+            grp(K0{}, grp);
             issue_advance();
             ++q;
         };
@@ -255,7 +280,7 @@ __global__ __launch_bounds__(PERS_NW * 64) void igemm_pers_kernel(const ConvP p,
         }
         const int m_base = cblk * 32;
 #pragma unroll
-        for (int b = 0; b < TM; ++b) {
+        for (int b = 0; b < ((ICAF_PERS_ABL & 16) ? 1 : TM); ++b) {
             // this tile's two output vectors per lane: pixel row r_ = (lane + 64 j) >> 2, 16-byte channel vector cv = lane & 3
             int mrow[2];
             u32x4 rv[2];
@@ -306,8 +331,7 @@ __global__ __launch_bounds__(PERS_NW * 64) void igemm_pers_kernel(const ConvP p,
             case 4: run_chunk(std::integral_constant<int, 4>{}, has_next); break;
             case 5: run_chunk(std::integral_constant<int, 5>{}, has_next); break;
             case 6: run_chunk(std::integral_constant<int, 6>{}, has_next); break;
-            case 7: run_chunk(std::integral_constant<int, 7>{}, has_next); break;
-            default: run_chunk(std::integral_constant<int, 8>{}, has_next); break;
+            default: run_chunk(std::integral_constant<int, 7>{}, has_next); break;
         }
     }
     wait_vmcnt<0>();                               // zero-fill slices issued past the end of the stream

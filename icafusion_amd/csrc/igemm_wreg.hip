@@ -214,7 +214,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && TN == 2) ? 2 : 1) void igemm
     __syncthreads();
     // (workgroup-uniform: most launches write whole tiles in vectors without a residual — the checked fast write-back of conv_common.h.  Carrying
     //  both loops costs the 128-pixel / 32-channel-per-wave tiles a workgroup per CU in registers, so only the 64-pixel and the 64-channel forms do)
-    constexpr bool FAST_WB = (BM == 64 || TN == 2) && !ICAF_EPI_FAST;          // (the A/B build's general epilogue has its own fast loops)
+    constexpr bool FAST_WB = (BM == 64 || TN == 2) && !ICAF_EPI_FAST;          // (only the ICAF_EPI_FAST=0 build: the shared epilogue has its own fast loops now)
     if (FAST_WB && !p.res && p.vec_y && p.Cout % BN == 0)
         epilogue<DT, DT, BM, BN, BM, 32 * TN, ACT, false, false, false, true>(acc, lds, p, g, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; }, n0);
     else

@@ -7,9 +7,11 @@ image (32 of 256 CUs at batch 32), so here batch i's NMS runs concurrently with 
     forward stream : graph(i) -> snapshot z(i) -> graph(i+1) -> snapshot z(i+1) -> ...
     nms stream     :              wait snapshot(i) -> candidates / sort / greedy (i) [-> all_gather(i)] -> ...
 
-With `depth` > 1 (bench default 2) that many batches are in flight: batch n replays plan n % depth (own buffers, own hipGraph) on
+With `depth` > 1 (bench default 2) that many batches are in flight: batch n replays plan n % nplans (own buffers, own hipGraph) on
 forward stream n % depth, so the low-occupancy tail of one forward overlaps the full-width layers of the next (+13 % throughput on one
-MI355X); NMS then reads each plan's own `z` and the plan is not replayed before its NMS has finished.
+MI355X); NMS then reads each plan's own `z` and the plan is not replayed before its NMS has finished.  nplans = depth,
+or depth + 1 when the pipeline is fed from host memory (u8=True): the host -> device copy of batch n + 1 then lands DIRECTLY in the input
+buffer of a plan that no forward in flight is reading — one PCIe copy per batch and no device-to-device hop.
 
 With depth 1, `z` is snapshotted into one of two staging buffers because the plan's output buffer is overwritten by the next
 replay; events order snapshot -> NMS -> reuse.  Each of the two slots also owns its NMS runner (workspace + det / count /
@@ -40,19 +42,21 @@ class DetectionPipeline:
         # depth > 1: that many batches in flight, each with its own plan (buffers, hipGraph) and forward stream — the tails of one
         # forward (20x20 layers, DMFF, Detect: launches that leave CUs idle) overlap the full-width layers of the next
         self.depth = max(1, int(depth)) if overlap else 1         # overlap=False is the strictly sequential baseline: one batch, one stream
-        self.plans = [model.plan_for(batch, height, width, self.device, u8=self.u8, slot=s) for s in range(self.depth)]
+        # host-fed pipelines own ONE MORE plan than batches in flight: the copy of the next batch goes straight into the input of the plan that
+        # is not in flight (round 4 copied into depth + 1 staging buffers and moved the batch into the plan's input device-to-device: 20 % of
+        # the no-feed rate was lost to that hop and to the queue it shared)
+        self.nplans = self.depth + 1 if (self.u8 and overlap) else self.depth
+        self.plans = [model.plan_for(batch, height, width, self.device, u8=self.u8, slot=s) for s in range(self.nplans)]
         # (a HIGH-PRIORITY stream: HIP maps the streams of a process onto a few hardware queues, and a copy stream that shares its queue with
         #  a forward stream waits behind that stream's graph — the copies then do not overlap the forwards at all; priority streams get
         #  queues of their own)
         self.copy_stream = torch.cuda.Stream(device=self.device, priority=-1) if self.u8 else None
-        self.stage = [torch.empty_like(self.plans[0].inputs[0]) for _ in range(self.depth + 1)] if self.u8 else []
-        self.copied = [torch.cuda.Event() for _ in self.stage]
-        self.stage_free = [torch.cuda.Event() for _ in self.stage]
+        self.copied = [torch.cuda.Event() for _ in self.plans]
         self.plan = self.plans[0]
         self.z = self.plan.outputs[0]
         self.fwd_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         self.fwd_stream = self.fwd_streams[0]
-        self.fwd_done = [torch.cuda.Event() for _ in range(self.depth)]
+        self.fwd_done = [torch.cuda.Event() for _ in range(self.nplans)]
         self.nms_stream = torch.cuda.Stream(device=self.device) if overlap else self.fwd_stream
         self.overlap = overlap
         self.zbuf = [torch.empty_like(self.z) for _ in range(2)] if overlap else [self.z]
@@ -64,12 +68,12 @@ class DetectionPipeline:
         self.runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False) for _ in range(nslots)]
         self.gathered = [torch.empty((world * (batch * max_det * 6 + batch),), dtype=torch.float32, device=self.device)
                          for _ in range(nslots)] if self.gather else None
-        if self.depth > 1:
+        if self.nplans > 1:
             self.nms_stream = torch.cuda.Stream(device=self.device)
-            self.deep_runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False) for _ in range(self.depth)]
-            self.nms_done_deep = [torch.cuda.Event() for _ in range(self.depth)]
+            self.deep_runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False) for _ in range(self.nplans)]
+            self.nms_done_deep = [torch.cuda.Event() for _ in range(self.nplans)]
             self.deep_gathered = [torch.empty((world * (batch * max_det * 6 + batch),), dtype=torch.float32, device=self.device)
-                                  for _ in range(self.depth)] if self.gather else None
+                                  for _ in range(self.nplans)] if self.gather else None
         self.n = 0
         self.last = None
 
@@ -79,15 +83,17 @@ class DetectionPipeline:
         staging tensors: they must be refilled before EVERY step (filling them once and stepping repeatedly would run every
         other batch on another slot's stale inputs), and the caller's copy must be ordered against the slot's forward stream —
         `submit()` does both."""
-        return self.plans[self.n % self.depth].inputs
+        return self.plans[self.n % self.nplans].inputs
 
     def submit(self, rgb, ir):
-        """Copy one batch into the next step's staging tensors ON that slot's forward stream (after the slot's previous forward —
-        same stream — so a forward still reading them is never overwritten), then enqueue the step."""
-        d = self.n % self.depth
-        fs = self.fwd_streams[d]
-        ins = self.plans[d].inputs
+        """Copy one batch into the next step's staging tensors ON that step's forward stream, behind the plan's previous forward (the same
+        stream when nplans == depth; an event otherwise) so a forward still reading them is never overwritten, then enqueue the step."""
+        pi = self.n % self.nplans
+        fs = self.fwd_streams[self.n % self.depth]
+        ins = self.plans[pi].inputs
         fs.wait_stream(torch.cuda.current_stream(self.device))     # rgb / ir may have been produced on the caller's stream
+        if self.nplans != self.depth and self.n >= self.nplans:
+            fs.wait_event(self.fwd_done[pi])
         with torch.cuda.stream(fs):
             ins[0].copy_(rgb, non_blocking=True)
             ins[1].copy_(ir, non_blocking=True)
@@ -98,29 +104,24 @@ class DetectionPipeline:
 
     def submit_u8(self, img6):
         """One uint8 (B, 6, H, W) batch — pinned host memory (the reference's dataloader output, test.py:116) or a device tensor — through
-        the pipeline.  The host -> device copy runs on the pipeline's COPY stream into one of depth + 1 device staging buffers, so it only
-        waits for the (long finished) batch that used that buffer depth + 1 steps ago — NOT for the slot's previous forward, which is
-        still running: a copy straight into the plan's own input buffer could not start before that forward had ended and measured
-        9,960 pairs/s where the forward alone does 15,600.  The slot's forward stream then moves the batch into the plan's input with a
-        device-to-device copy (79 MB at HBM speed: ~40 us) right in front of the graph replay.  The host buffer must stay untouched
-        until its copy has run (rotate >= depth + 2 pinned buffers, or wait for `pipe.copied[k]`)."""
+        the pipeline.  The copy runs on the pipeline's COPY stream straight into the input buffer of plan n % (depth + 1): the plan that ran
+        depth + 1 steps ago, so the copy only waits for a forward that has long finished — NOT for one of the `depth` forwards in flight (a
+        copy into the input of a plan that is still running could not start before that forward had ended: 9,960 pairs/s where the forward
+        alone does 15,600; round 4's extra staging buffers + device-to-device hop: 13,059 of 16,238).  The host buffer must stay untouched
+        until its copy has run (rotate >= depth + 2 pinned buffers, or wait for `pipe.copied[n % pipe.nplans]`)."""
         assert self.u8, "DetectionPipeline(u8=True) takes uint8 batches"
-        d = self.n % self.depth
-        k = self.n % len(self.stage)
-        cs, fs = self.copy_stream, self.fwd_streams[d]
-        if self.n >= len(self.stage):
-            cs.wait_event(self.stage_free[k])                     # the forward stream has drained this staging buffer (depth + 1 steps ago)
+        pi = self.n % self.nplans
+        cs, fs = self.copy_stream, self.fwd_streams[self.n % self.depth]
+        if self.n >= self.nplans:
+            cs.wait_event(self.fwd_done[pi])                      # this plan's previous forward (nplans steps ago) has consumed its input
         if img6.is_cuda:
             cs.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(cs):
-            self.stage[k].copy_(img6, non_blocking=True)
+            self.plans[pi].inputs[0].copy_(img6, non_blocking=True)
         if img6.is_cuda:
             img6.record_stream(cs)
-        self.copied[k].record(cs)
-        fs.wait_event(self.copied[k])
-        with torch.cuda.stream(fs):                               # same stream as the slot's previous forward: it has consumed the plan's input
-            self.plans[d].inputs[0].copy_(self.stage[k], non_blocking=True)
-        self.stage_free[k].record(fs)
+        self.copied[pi].record(cs)
+        fs.wait_event(self.copied[pi])
         return self.step()
 
     def step(self):
@@ -128,7 +129,7 @@ class DetectionPipeline:
         the nms stream has drained (see synchronize()) — ALWAYS rank-major: det (world, B, max_det, 6) fp32, count (world, B) int32, i.e.
         global batch order for contiguous shards (dist.flatten_gathered gives the (world * B, ...) form).  Without a gather (one rank)
         the leading axis has length 1 and the tensors are views of the slot's NMS output block."""
-        if self.depth > 1:
+        if self.nplans > 1:
             return self._step_deep()
         i = (self.n & 1) if self.overlap else 0
         fs, ns = self.fwd_stream, self.nms_stream
@@ -152,21 +153,21 @@ class DetectionPipeline:
         return out
 
     def _step_deep(self):
-        """depth batches in flight: batch n runs plan n % depth on its own stream; its NMS reads that plan's z directly (no
-        snapshot: the plan is not replayed before its NMS has finished)."""
-        d = self.n % self.depth
-        fs, ns, plan = self.fwd_streams[d], self.nms_stream, self.plans[d]
-        if self.n >= self.depth:
-            fs.wait_event(self.nms_done_deep[d])           # NMS of batch n - depth has finished reading this plan's z
+        """Several plans: batch n runs plan n % nplans on forward stream n % depth; its NMS reads that plan's z directly (no snapshot: the
+        plan is not replayed before its NMS has finished — which also orders the replay behind the plan's previous forward)."""
+        pi = self.n % self.nplans
+        fs, ns, plan = self.fwd_streams[self.n % self.depth], self.nms_stream, self.plans[pi]
+        if self.n >= self.nplans:
+            fs.wait_event(self.nms_done_deep[pi])          # NMS of batch n - nplans has finished reading this plan's z
         plan.run(fs.cuda_stream)
-        self.fwd_done[d].record(fs)
-        ns.wait_event(self.fwd_done[d])
-        det, count, keep = nms_device(plan.outputs[0], stream_ptr=ns.cuda_stream, runner=self.deep_runners[d], **self.nms_args)
+        self.fwd_done[pi].record(fs)
+        ns.wait_event(self.fwd_done[pi])
+        det, count, keep = nms_device(plan.outputs[0], stream_ptr=ns.cuda_stream, runner=self.deep_runners[pi], **self.nms_args)
         out = (det[None], count[None])
         if self.gather:
             with torch.cuda.stream(ns):
-                out = D.gather_detections(det, count, out=self.deep_gathered[d], force_collective=True, block=self.deep_runners[d].block)
-        self.nms_done_deep[d].record(ns)
+                out = D.gather_detections(det, count, out=self.deep_gathered[pi], force_collective=True, block=self.deep_runners[pi].block)
+        self.nms_done_deep[pi].record(ns)
         self.n += 1
         self.last = out
         return out

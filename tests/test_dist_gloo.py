@@ -2,6 +2,8 @@
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.multiprocessing as mp
 
@@ -107,3 +109,34 @@ def test_bench_strong_scaling_launch_with_four_ranks_and_an_uneven_split():
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 4 and rec["gather_ok"] and rec["backend"] == "gloo" and rec["global_batch"] == 10
     assert rec["local_batches"] == [3, 3, 2, 2]
+
+
+CONFIG3 = ["--model", "l", "--global-batch", "256"]                                                            # BASELINE configs[2]: yolov5l bf16, batch 256 over 8 GPUs
+CONFIG5 = ["--model", "l", "--dataset", "VEDAI", "--dtype", "f16", "--height", "1280", "--width", "1280", "--global-batch", "128", "--conf", "0.3"]   # configs[4]
+
+
+@pytest.mark.parametrize("name,cfg_args,shard", [("config3", CONFIG3, 32), ("config5", CONFIG5, 16)])
+def test_bench_world8_dry_run_of_the_eight_gpu_baseline_configurations(name, cfg_args, shard):
+    """The exact command lines of BASELINE configs 3 and 5 at eight ranks (gloo here, RCCL on a node), `--dry-run`: every rank starts, binds, joins the
+    process group, takes its contiguous shard (256 -> 8 x 32, 128 -> 8 x 16: even, no padding), ONE all-gather of the detection blocks, the global view
+    holds the pairs in order.  Both launch forms: bench.py spawning its own ranks, and the driver's `python -m torch.distributed.run ... bench.py`."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    bench = os.path.join(repo, "bench.py")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    forms = {"self-spawn": [sys.executable, bench, "--gpus", "8"] + cfg_args + ["--dry-run"],
+             "torchrun": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), bench, "--gpus", "8"] + cfg_args + ["--dry-run"]}
+    for form, cmd in forms.items():
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, (name, form, r.stdout[-1000:] + r.stderr[-3000:])
+        rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert rec["n_gpus"] == 8 and rec["requested_gpus"] == 8 and rec["gather_ok"] and rec["backend"] == "gloo", (name, form, rec)
+        assert rec["global_batch"] == shard * 8 and rec["local_batches"] == [shard] * 8, (name, form, rec)

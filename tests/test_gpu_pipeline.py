@@ -88,19 +88,21 @@ def test_pipeline_with_several_batches_in_flight(depth):
 
 @pytest.mark.parametrize("depth", [1, 2])
 def test_pipeline_fed_with_pinned_uint8_host_batches(depth):
-    """DetectionPipeline(u8=True).submit_u8: pinned host uint8 (B, 6, H, W) batches through the copy stream and the staging buffers
-    (reference test.py:116-123 copies, casts, divides and splits every batch).  Seven different batches, none of them waited for before
-    the next is submitted: every step's detections equal Model.forward_u8 + NMS of that batch run on their own."""
+    """DetectionPipeline(u8=True).submit_u8: pinned host uint8 (B, 6, H, W) batches through the copy stream STRAIGHT into the input buffer of
+    one of depth + 1 plans — the one no forward in flight is reading: one PCIe copy per batch, no device-to-device hop (reference
+    test.py:116-123 copies, casts, divides and splits every batch).  Seven different batches, none of them waited for before the next is
+    submitted: every step's detections equal Model.forward_u8 + NMS of that batch run on their own."""
     m = build("yolov5s_Transfusion_FLIR.yaml", torch.bfloat16)
     m.use_graph = True
     B, H, W = 4, 320, 352
     pipe = DetectionPipeline(m, B, H, W, DEV, conf_thres=0.25, iou_thres=0.45, depth=depth, u8=True)
+    assert pipe.nplans == depth + 1 and len({p.inputs[0].data_ptr() for p in pipe.plans}) == depth + 1 and not hasattr(pipe, "stage")
     g = torch.Generator().manual_seed(5)
     host = [torch.randint(0, 256, (B, 6, H, W), dtype=torch.uint8, generator=g).pin_memory() for _ in range(7)]
     outs = [tuple(t[0] for t in pipe.submit_u8(h)) for h in host]
     pipe.synchronize()
     ref = build("yolov5s_Transfusion_FLIR.yaml", torch.bfloat16)
-    for k in range(len(host) - pipe.depth, len(host)):                            # the last `depth` steps still own their output buffers
+    for k in range(len(host) - pipe.nplans, len(host)):                           # the last `nplans` steps still own their output buffers
         want = non_max_suppression(ref.forward_u8(host[k].to(DEV))[0], 0.25, 0.45)
         det, count = outs[k]
         assert sum(count.tolist()) > 0
