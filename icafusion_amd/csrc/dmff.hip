@@ -5,6 +5,7 @@
 //   upsample_merge   bilinear resize of the token maps + residual + channel concat            (HBM-bound)
 // The Linear layers around them (QKV / out-proj / MLP) run on the implicit-GEMM kernel (igemm.hip) with the
 // LearnableCoefficient mixes folded into its epilogue.
+#include <cstdlib>
 #include "icaf_common.h"
 #include "attn_core.h"
 
@@ -433,6 +434,10 @@ static int launch_attn(const void* qkv, void* out, int B, int N, int C, int DK, 
     // small batches: fewer workgroups exist, keep the split; large batches already fill the chip, so let every
     // workgroup amortise its K/V staging over two query tiles per wavefront
     if ((long long)2 * B * heads * qsplit >= 4096 && qsplit > 1) qsplit = (qsplit + 1) / 2;
+    {   // A/B switch (timing studies): ICAF_ATTN_QSPLIT=n forces n query splits per head (1 = a workgroup stages a head's K / V^T once for ALL its query tiles)
+        static const int forced = [] { const char* e = getenv("ICAF_ATTN_QSPLIT"); return e ? atoi(e) : 0; }();
+        if (forced > 0) qsplit = forced < nqt ? forced : nqt;
+    }
     const float scale_l2e = (float)((1.0 / sqrt((double)DK)) * 1.4426950408889634);
     const bool remap = (2 * B) % 8 == 0 && heads * DK == C;          // whole (direction, image) groups per XCD
     dim3 grid((unsigned)qsplit, (unsigned)heads, (unsigned)(2 * B));
