@@ -430,10 +430,16 @@ static int launch_attn(const void* qkv, void* out, int B, int N, int C, int DK, 
         attr_set[dev] = true;
     }
     const int nqt = NP / 32;
-    int qsplit = (nqt + 3) / 4;
-    // small batches: fewer workgroups exist, keep the split; large batches already fill the chip, so let every
-    // workgroup amortise its K/V staging over two query tiles per wavefront
-    if ((long long)2 * B * heads * qsplit >= 4096 && qsplit > 1) qsplit = (qsplit + 1) / 2;
+    // Query splits per head: every split stages the head's K / V^T again (25 - 100 KB through scalar LDS transposition writes), so as FEW as
+    // the chip needs: two workgroups per CU (512) must exist, beyond that one split — except at d_k <= 16 with many query tiles, where a wave
+    // walking seven tiles alone is the longer pole (round 5, same box, batch 32: yolov5s P3 28.5 us with 4 splits, 25.5 with 2, 26.5 with 1;
+    // yolov5l P3 44.3 -> 33.3 and P4 27.1 -> 22.1 with ONE split; P5 levels already ran one).  Small batches keep the splits: they are the
+    // only parallelism there.
+    const int qs_max = (nqt + 3) / 4;
+    int qsplit = (DK <= 16 && nqt > 8) ? 2 : 1;
+    const long long wgs1 = (long long)2 * B * heads;                  // workgroups with one split
+    if (wgs1 * qsplit < 512) qsplit = (int)((512 + wgs1 - 1) / wgs1);
+    if (qsplit > qs_max) qsplit = qs_max;
     {   // A/B switch (timing studies): ICAF_ATTN_QSPLIT=n forces n query splits per head (1 = a workgroup stages a head's K / V^T once for ALL its query tiles)
         static const int forced = [] { const char* e = getenv("ICAF_ATTN_QSPLIT"); return e ? atoi(e) : 0; }();
         if (forced > 0) qsplit = forced < nqt ? forced : nqt;

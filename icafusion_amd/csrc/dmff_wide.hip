@@ -65,8 +65,10 @@ template <int NW_, int SL_> struct WG {
     static constexpr int NW = NW_, SL = SL_;
     static constexpr int WT = 64 * NW;           // threads per workgroup
     static constexpr int WPASS = 32 * NW;        // output channels per pass
-    static constexpr int KSL = 16 * SL;          // K elements per slice
-    static constexpr int NSL2 = WPASS / KSL;     // slices of an fc2 pass over one hidden chunk
+    // (an MFMA K step is 32 BYTES of a row in every type: 16 elements of a 16-bit type, 8 of fp32 — the parity instantiation)
+    template <int DT> static constexpr int kstep() { return 32 / Elem<DT>::BYTES; }          // K elements per MFMA step
+    template <int DT> static constexpr int ksl() { return kstep<DT>() * SL; }                // K elements per slice
+    template <int DT> static constexpr int nsl2() { return WPASS / ksl<DT>(); }              // slices of an fc2 pass over one hidden chunk
     static constexpr int TPR = WT / WROWS;       // threads per row in the tile LayerNorm
 };
 using WG8 = WG<8, 4>;
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_ln_qkv_kernel(const WideP p) 
     if (idx >= ntiles * ngrp) return;
     const int tile_i = idx / ngrp, grp = idx - tile_i * ngrp;
     const long long r0 = (long long)tile_i * WROWS;
-    const int ks_row = p.Kp / 16, nsl = C / G::KSL;
+    const int ks_row = p.Kp / G::template kstep<DT>(), nsl = C / G::template ksl<DT>();
 
     const u32x4* wf = (const u32x4*)((const T*)p.wqkv + g * p.wqkv_gs) + lane;
     auto next = [&](WCursor& c) {
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p
     constexpr int VEC = E::VEC, EB = E::BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int C = p.C, SA = C * EB + 16;
-    constexpr int WPASS = G::WPASS, WT = G::WT, NSL2 = G::NSL2;
+    constexpr int WPASS = G::WPASS, WT = G::WT, NSL2 = G::template nsl2<DT>(), KST = G::template kstep<DT>();
     constexpr int SH = WPASS * EB + 16;
     unsigned char* T0 = smem;                                      // attention output -> later the LayerNorm'ed MLP input
     unsigned char* Hb = T0 + (size_t)WROWS * SA;                   // hidden chunk [64][256]
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p
     else wide_place_ks<KS>(blockIdx.x, g, ksl, tile_i);
     if (tile_i >= ntiles) return;
     const long long r0 = (long long)tile_i * WROWS;
-    const int ks_row = p.Kp / 16, ks_row4 = p.Kp4 / 16, nsl = C / G::KSL, nchunk = p.hid / WPASS / KS, chunk0 = ksl * nchunk;
+    const int ks_row = p.Kp / KST, ks_row4 = p.Kp4 / KST, nsl = C / G::template ksl<DT>(), nchunk = p.hid / WPASS / KS, chunk0 = ksl * nchunk;
 
     // the wave's stream: NPW out-projection passes, then per hidden chunk one fc1 pass and NPW fc2 passes
     const u32x4* wof = (const u32x4*)((const T*)p.wo + g * p.wo_gs) + lane;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p
         const int m = s - NPW, chunk = m / (1 + NPW), r = m - chunk * (1 + NPW);
         if (chunk >= nchunk) { c.left = 0; return; }
         if (r == 0) { c.base = w1f + (long long)((chunk0 + chunk) * G::NW + wn) * ks_row * 64; c.left = nsl; }
-        else { c.base = w2f + ((long long)((r - 1) * G::NW + wn) * ks_row4 + (chunk0 + chunk) * (WPASS / 16)) * 64; c.left = NSL2; }
+        else { c.base = w2f + ((long long)((r - 1) * G::NW + wn) * ks_row4 + (chunk0 + chunk) * (WPASS / KST)) * 64; c.left = NSL2; }
     };
     WCursor cur; cur.seg = 0; next(cur);
     u32x4 wq[WDEPTH][G::SL];
@@ -509,10 +511,13 @@ __global__ __launch_bounds__(256) void dmff_wide_reduce_kernel(const WideP p) {
 // ---------------------------------------------------------------------------------------------------------------
 static int wide_fill(const icaf_dmff_args* a, WideP& p, const char* who) {
     if (!a || !a->x) return fail(ICAF_ERR_ARG, "%s: null pointer", who);
-    if (a->dtype != ICAF_BF16 && a->dtype != ICAF_F16) return fail(ICAF_ERR_UNSUPPORTED, "%s: 16-bit types only (dtype %d)", who, a->dtype);
+    // fp32: the PARITY instantiation of the C = 128 build (v_mfma_f32_32x32x2_f32, erff): the same indexing, masks, LayerNorm and hidden-chunk loop as the
+    // 16-bit kernels the bench runs, held to the reference's DMFF goldens at fp32 accuracy (tests/test_gpu_dmff_fused.py)
+    if (a->dtype != ICAF_BF16 && a->dtype != ICAF_F16 && !(a->dtype == ICAF_F32 && a->C == 128))
+        return fail(ICAF_ERR_UNSUPPORTED, "%s: 16-bit types (fp32: the C = 128 parity build only; dtype %d, C = %d)", who, a->dtype, a->C);
     if (a->B < 1 || a->N < 1) return fail(ICAF_ERR_ARG, "%s: bad B/N", who);
     if (a->C != 128 && a->C != 256 && a->C != 512) return fail(ICAF_ERR_UNSUPPORTED, "%s: C=%d (built for 128 [four wavefronts, 128-channel passes] and 256 / 512 [eight, 256-channel passes])", who, a->C);
-    if (a->Kp < a->C || a->Kp % 64) return fail(ICAF_ERR_ARG, "%s: Kp=%d", who, a->Kp);
+    if (a->Kp < a->C || a->Kp % (a->dtype == ICAF_F32 ? 32 : 64)) return fail(ICAF_ERR_ARG, "%s: Kp=%d", who, a->Kp);
     p.x = a->x; p.qkv = a->qkv; p.y = a->y; p.att = nullptr; p.part = nullptr;
     p.wqkv = a->wqkv; p.bqkv = a->bqkv; p.wo = a->wo; p.bo = a->bo; p.w1 = a->w1; p.b1 = a->b1; p.w2 = a->w2; p.b2 = a->b2;
     p.ln_a_g[0] = a->ln_attn_gamma[0]; p.ln_a_g[1] = a->ln_attn_gamma[1]; p.ln_a_b[0] = a->ln_attn_beta[0]; p.ln_a_b[1] = a->ln_attn_beta[1];
@@ -534,7 +539,7 @@ static int wide_fill(const icaf_dmff_args* a, WideP& p, const char* who) {
 
 template <int DT, class G>
 static int launch_wide_ln_qkv(const WideP& p, hipStream_t s) {
-    const size_t lds = (size_t)WROWS * (p.C * 2 + 16);
+    const size_t lds = (size_t)WROWS * (p.C * Elem<DT>::BYTES + 16);
     ICAF_LDS_OPTIN((dmff_wide_ln_qkv_kernel<DT, G>), lds);        // (size checked on EVERY call, attribute raised per device as needed)
     const long long work = ((p.rows + WROWS - 1) / WROWS) * (3 * (p.C / G::WPASS) / p.qkv_npass);
     hipLaunchKernelGGL((dmff_wide_ln_qkv_kernel<DT, G>), dim3((unsigned)(8 * ((work + 3) / 4))), dim3(G::WT), lds, s, p);
@@ -543,13 +548,13 @@ static int launch_wide_ln_qkv(const WideP& p, hipStream_t s) {
 }
 
 template <class G>
-static size_t wide_proj_mlp_lds(int C, int hid) {
-    return (size_t)WROWS * (C * 2 + 16) + (size_t)WROWS * (G::WPASS * 2 + 16) + G::NW * 64 * sizeof(float) + (size_t)hid * sizeof(float);
+static size_t wide_proj_mlp_lds(int C, int hid, int eb = 2) {
+    return (size_t)WROWS * (C * eb + 16) + (size_t)WROWS * (G::WPASS * eb + 16) + G::NW * 64 * sizeof(float) + (size_t)hid * sizeof(float);
 }
 
 template <int DT, int NPW, class G>
 static int launch_wide_proj_mlp(const WideP& p, hipStream_t s) {
-    const size_t lds = wide_proj_mlp_lds<G>(p.C, p.hid);
+    const size_t lds = wide_proj_mlp_lds<G>(p.C, p.hid, Elem<DT>::BYTES);
     ICAF_LDS_OPTIN((dmff_wide_proj_mlp_kernel<DT, NPW, 1, G>), lds);
     const long long ntiles = (p.rows + WROWS - 1) / WROWS;
     hipLaunchKernelGGL((dmff_wide_proj_mlp_kernel<DT, NPW, 1, G>), dim3((unsigned)(8 * ((ntiles + 3) / 4))), dim3(G::WT), lds, s, p);
@@ -605,6 +610,7 @@ extern "C" int icaf_dmff_wide_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s) {
     if (st) return st;
     if (!a->qkv || !a->wqkv || !a->bqkv || !a->ln_attn_gamma[0] || !a->ln_attn_gamma[1] || !a->ln_attn_beta[0] || !a->ln_attn_beta[1])
         return fail(ICAF_ERR_ARG, "icaf_dmff_wide_ln_qkv: null pointer");
+    if (a->dtype == ICAF_F32) return launch_wide_ln_qkv<ICAF_F32, WG4>(p, S(s));
     return a->dtype == ICAF_BF16 ? dispatch_wide_ln_qkv<ICAF_BF16>(p, S(s)) : dispatch_wide_ln_qkv<ICAF_F16>(p, S(s));
 }
 
@@ -614,9 +620,10 @@ extern "C" int icaf_dmff_wide_proj_mlp(const icaf_dmff_args* a, const void* att,
     if (st) return st;
     if (!att || !a->y || !a->wo || !a->bo || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ln_mlp_gamma || !a->ln_mlp_beta) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp: null pointer");
     const int wpass = a->C == 128 ? WG4::WPASS : WG8::WPASS;
-    if (a->hidden % wpass || a->hidden < wpass || a->Kp4 < a->hidden || a->Kp4 % 64) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp: hidden width %d must be a multiple of %d", a->hidden, wpass);
+    if (a->hidden % wpass || a->hidden < wpass || a->Kp4 < a->hidden || a->Kp4 % (a->dtype == ICAF_F32 ? 32 : 64)) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp: hidden width %d must be a multiple of %d", a->hidden, wpass);
     if (a->ldy < a->C || a->ldy % 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp: ldy=%d", a->ldy);
     p.att = att;
+    if (a->dtype == ICAF_F32) return launch_wide_proj_mlp<ICAF_F32, 1, WG4>(p, S(s));
     return a->dtype == ICAF_BF16 ? dispatch_wide_proj_mlp<ICAF_BF16>(p, S(s)) : dispatch_wide_proj_mlp<ICAF_F16>(p, S(s));
 }
 
@@ -626,7 +633,7 @@ extern "C" int icaf_dmff_wide_proj_mlp_split(const icaf_dmff_args* a, const void
     if (st) return st;
     if (!att || !partial || !a->y || !a->wo || !a->bo || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ln_mlp_gamma || !a->ln_mlp_beta) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp_split: null pointer");
     if (ksplit != 2 && ksplit != 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp_split: ksplit %d (2 or 4)", ksplit);
-    if (a->C == 128) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp_split: C = 128 has no hidden split (its weights are 0.3 MB)");
+    if (a->C == 128 || a->dtype == ICAF_F32) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp_split: C = 128 has no hidden split (its weights are 0.3 MB)");
     if (a->hidden % (WG8::WPASS * ksplit) || a->Kp4 < a->hidden || a->Kp4 % 64) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp_split: hidden width %d must be a multiple of %d", a->hidden, WG8::WPASS * ksplit);
     if (a->ldy < a->C || a->ldy % 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_proj_mlp_split: ldy=%d", a->ldy);
     p.att = att;
@@ -640,6 +647,7 @@ extern "C" int icaf_dmff_wide_reduce(const icaf_dmff_args* a, const float* parti
     if (st) return st;
     if (!partial || !a->y || !a->b2) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_reduce: null pointer");
     if (ksplit != 2 && ksplit != 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_reduce: ksplit %d (2 or 4)", ksplit);
+    if (a->dtype == ICAF_F32) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_reduce: 16-bit types only");
     if (a->ldy < a->C || a->ldy % 4) return fail(ICAF_ERR_ARG, "icaf_dmff_wide_reduce: ldy=%d", a->ldy);
     p.part = const_cast<float*>(partial);
     return a->dtype == ICAF_BF16 ? launch_wide_reduce<ICAF_BF16>(p, ksplit, S(s)) : launch_wide_reduce<ICAF_F16>(p, ksplit, S(s));

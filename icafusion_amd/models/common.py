@@ -758,7 +758,8 @@ class CrossTransformerBlock(HipModule):
     # ICAF_DMFF_FUSE_MAX_C=128 restores the two-launch form at P3 (A/B, tests).
     fuse_max_c = int(os.environ.get("ICAF_DMFF_FUSE_MAX_C", "64"))
     # fp32 plans keep the per-layer launches (the goldens then cover them); True runs the fp32 INSTANTIATION of the fused kernels where
-    # it exists (C <= 128): the same template the 16-bit path runs, held to the reference's fp32 goldens (tests/test_gpu_dmff_fused.py)
+    # it exists: the same templates the 16-bit path runs, held to the reference's fp32 goldens (tests/test_gpu_dmff_fused.py) — the two-launch
+    # form at C <= fuse_max_c <= 128, and (round 5) the THREE-launch form every yolov5s level runs by default, at C = 128 (dmff_wide.hip)
     fuse_fp32 = os.environ.get("ICAF_DMFF_FUSE_FP32", "0") == "1"
 
     def fusable(self, plan, C, N):
@@ -775,6 +776,8 @@ class CrossTransformerBlock(HipModule):
 
     def wide_fusable(self, plan, C):
         hid, h = self.mlp_vis[0].out_features, self.crossatt.h
+        if plan.dtype == torch.float32 and not self.fuse_fp32:         # fp32 plans keep the per-layer launches unless the parity instantiation is asked for
+            return False
         return (self.fuse_wide and self.fuse_block and self.fuse_max_c < C <= self.wide_max_c and ops.dmff_wide_ok(C, hid, plan.dtype)
                 and (C // h) % 8 == 0 and self.mlp_vis[2].in_features == hid)
 

@@ -120,9 +120,10 @@ def frag_weights(w_packed):
         return hit[1]
     w = w_packed if w_packed.dim() == 3 else w_packed[None]
     G, np_, kp = w.shape
-    assert np_ % 32 == 0 and kp % 16 == 0 and w.element_size() == 2
-    f = w.reshape(G, np_ // 32, 32, kp // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()      # g, nb, ks, hi, r, e
-    f = f.reshape(G, np_ // 32, kp // 16, 64, 8)
+    ve = 16 // w.element_size()                     # elements per 16-byte fragment: 8 (16-bit types), 4 (fp32: the parity instantiation of dmff_wide.hip)
+    assert np_ % 32 == 0 and kp % (2 * ve) == 0 and w.element_size() in (2, 4)
+    f = w.reshape(G, np_ // 32, 32, kp // (2 * ve), 2, ve).permute(0, 1, 3, 4, 2, 5).contiguous()      # g, nb, ks, hi, r, e
+    f = f.reshape(G, np_ // 32, kp // (2 * ve), 64, ve)
     if w_packed.dim() == 2:
         f = f[0]
     # The copy lives exactly as long as the packed tensor it mirrors: HipModule.invalidate() / .to() / load_state_dict drop the module's
@@ -666,7 +667,10 @@ def dmff_wide_ok(C_, hidden, dt):
     """The three-launch block kernels (dmff_wide.hip) cover this shape: C = 128 (four wavefronts, 128-channel passes) / 256 / 512 (eight,
     256-channel passes), 16-bit types, hidden a multiple of the pass width."""
     wpass = 128 if C_ == 128 else 256
-    lds = 64 * (C_ * 2 + 16) + 64 * (wpass * 2 + 16) + 8 * 64 * 4 + hidden * 4
+    es = 4 if dt == torch.float32 else 2
+    lds = 64 * (C_ * es + 16) + 64 * (wpass * es + 16) + 8 * 64 * 4 + hidden * 4
+    if dt == torch.float32:                          # the parity instantiation: C = 128 only (same code, fp32 MFMAs, erff)
+        return C_ == 128 and hidden % wpass == 0 and lds <= 160 * 1024
     return dt in (torch.bfloat16, torch.float16) and C_ in (128, 256, 512) and hidden % wpass == 0 and lds <= 160 * 1024
 
 

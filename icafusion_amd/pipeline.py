@@ -7,8 +7,8 @@ image (32 of 256 CUs at batch 32), so here batch i's NMS runs concurrently with 
     forward stream : graph(i) -> snapshot z(i) -> graph(i+1) -> snapshot z(i+1) -> ...
     nms stream     :              wait snapshot(i) -> candidates / sort / greedy (i) [-> all_gather(i)] -> ...
 
-With `depth` > 1 (bench default 2) that many batches are in flight: batch n replays plan n % nplans (own buffers, own hipGraph) on
-forward stream n % depth, so the low-occupancy tail of one forward overlaps the full-width layers of the next (+13 % throughput on one
+With `depth` > 1 (bench default 2) that many batches are in flight: batch n replays plan n % nplans (own buffers, own hipGraph, own
+forward stream), so the low-occupancy tail of one forward overlaps the full-width layers of the next (+13 % throughput on one
 MI355X); NMS then reads each plan's own `z` and the plan is not replayed before its NMS has finished.  nplans = depth,
 or depth + 1 when the pipeline is fed from host memory (u8=True): the host -> device copy of batch n + 1 then lands DIRECTLY in the input
 buffer of a plan that no forward in flight is reading — one PCIe copy per batch and no device-to-device hop.
@@ -54,7 +54,9 @@ class DetectionPipeline:
         self.copied = [torch.cuda.Event() for _ in self.plans]
         self.plan = self.plans[0]
         self.z = self.plan.outputs[0]
-        self.fwd_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        # one forward stream PER PLAN (a plan's hipGraph always replays on the same stream: alternating a graph between two streams cost the
+        # host-fed loop a third of its rate); at most `depth` forwards run at once — forward n waits for forward n - depth (an event)
+        self.fwd_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.nplans)]
         self.fwd_stream = self.fwd_streams[0]
         self.fwd_done = [torch.cuda.Event() for _ in range(self.nplans)]
         self.nms_stream = torch.cuda.Stream(device=self.device) if overlap else self.fwd_stream
@@ -89,12 +91,10 @@ class DetectionPipeline:
         """Copy one batch into the next step's staging tensors ON that step's forward stream, behind the plan's previous forward (the same
         stream when nplans == depth; an event otherwise) so a forward still reading them is never overwritten, then enqueue the step."""
         pi = self.n % self.nplans
-        fs = self.fwd_streams[self.n % self.depth]
+        fs = self.fwd_streams[pi]
         ins = self.plans[pi].inputs
         fs.wait_stream(torch.cuda.current_stream(self.device))     # rgb / ir may have been produced on the caller's stream
-        if self.nplans != self.depth and self.n >= self.nplans:
-            fs.wait_event(self.fwd_done[pi])
-        with torch.cuda.stream(fs):
+        with torch.cuda.stream(fs):                                # (the plan's own stream: behind its previous forward)
             ins[0].copy_(rgb, non_blocking=True)
             ins[1].copy_(ir, non_blocking=True)
         for t in (rgb, ir):                                        # the copies run on `fs`, possibly long after this call returns: tell the
@@ -111,7 +111,7 @@ class DetectionPipeline:
         until its copy has run (rotate >= depth + 2 pinned buffers, or wait for `pipe.copied[n % pipe.nplans]`)."""
         assert self.u8, "DetectionPipeline(u8=True) takes uint8 batches"
         pi = self.n % self.nplans
-        cs, fs = self.copy_stream, self.fwd_streams[self.n % self.depth]
+        cs, fs = self.copy_stream, self.fwd_streams[pi]
         if self.n >= self.nplans:
             cs.wait_event(self.fwd_done[pi])                      # this plan's previous forward (nplans steps ago) has consumed its input
         if img6.is_cuda:
@@ -153,12 +153,14 @@ class DetectionPipeline:
         return out
 
     def _step_deep(self):
-        """Several plans: batch n runs plan n % nplans on forward stream n % depth; its NMS reads that plan's z directly (no snapshot: the
+        """Several plans: batch n runs plan n % nplans on that plan's own forward stream; its NMS reads that plan's z directly (no snapshot: the
         plan is not replayed before its NMS has finished — which also orders the replay behind the plan's previous forward)."""
         pi = self.n % self.nplans
-        fs, ns, plan = self.fwd_streams[self.n % self.depth], self.nms_stream, self.plans[pi]
+        fs, ns, plan = self.fwd_streams[pi], self.nms_stream, self.plans[pi]
         if self.n >= self.nplans:
             fs.wait_event(self.nms_done_deep[pi])          # NMS of batch n - nplans has finished reading this plan's z
+        if self.nplans > self.depth and self.n >= self.depth:
+            fs.wait_event(self.fwd_done[(self.n - self.depth) % self.nplans])     # at most `depth` forwards in flight
         plan.run(fs.cuda_stream)
         self.fwd_done[pi].record(fs)
         ns.wait_event(self.fwd_done[pi])
