@@ -296,6 +296,39 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const typename Elem<DT>
 
     // ---- stage K (row-major) and V^T (key-permuted) of this head into LDS ----------------------------------------
     constexpr int NVK = DKP / VEC;
+    if constexpr (EB == 2) {
+        // Round 5: FOUR consecutive keys per item.  vt_phys keeps the keys 4i .. 4i + 3 of a 16-key group adjacent (8 bytes of a V^T row), so the eight
+        // d-rows of a 16-byte V vector take ONE 8-byte store each for four keys — 8 ds_write_b64 + 4 ds_write_b128 (K) per item where the key-by-key
+        // loop issued 32 two-byte stores + 4: the staging was half of a workgroup's life (SQ wave-wait 0.48 in round 4).
+        for (int idx = tid; idx < (NP >> 2) * NVK; idx += 256) {
+            const int k4 = idx / NVK, v = idx - k4 * NVK, key0 = k4 * 4;
+            u32x4 kq[4], vq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                kq[i] = u32x4{0u, 0u, 0u, 0u};
+                vq[i] = u32x4{0u, 0u, 0u, 0u};
+                if (key0 + i < N && v * VEC < DK) {
+                    kq[i] = *(const u32x4*)(kvbase + (key0 + i) * row3 + C + v * VEC);
+                    vq[i] = *(const u32x4*)(kvbase + (key0 + i) * row3 + 2 * C + v * VEC);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4*)(Ks + (size_t)(key0 + i) * KS + v * 16) = kq[i];
+            const int pk = vt_phys<DT>(key0);                      // (= the physical position of the group's first key; the other three follow it)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                          // d-row v * 8 + j: element j of each key's vector
+                u32x2 w;
+                if (j & 1) {
+                    w[0] = (vq[0][j >> 1] >> 16) | (vq[1][j >> 1] & 0xffff0000u);
+                    w[1] = (vq[2][j >> 1] >> 16) | (vq[3][j >> 1] & 0xffff0000u);
+                } else {
+                    w[0] = (vq[0][j >> 1] & 0xffffu) | (vq[1][j >> 1] << 16);
+                    w[1] = (vq[2][j >> 1] & 0xffffu) | (vq[3][j >> 1] << 16);
+                }
+                *(u32x2*)(Vt + (size_t)(v * 8 + j) * VS + pk * 2) = w;
+            }
+        }
+    } else
     for (int idx = tid; idx < NP * NVK; idx += 256) {
         const int key = idx / NVK, v = idx - key * NVK;
         u32x4 kvv = {0u, 0u, 0u, 0u}, vvv = {0u, 0u, 0u, 0u};
@@ -305,14 +338,8 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const typename Elem<DT>
         }
         *(u32x4*)(Ks + (size_t)key * KS + v * 16) = kvv;
         const int pk = vt_phys<DT>(key);
-        if constexpr (EB == 4) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(unsigned int*)(Vt + (size_t)(v * 4 + j) * VS + pk * 4) = vvv[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                *(unsigned short*)(Vt + (size_t)(v * 8 + j) * VS + pk * 2) = (unsigned short)((vvv[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
-        }
+        for (int j = 0; j < 4; ++j) *(unsigned int*)(Vt + (size_t)(v * 4 + j) * VS + pk * 4) = vvv[j];
     }
     if constexpr (AC::FREE) {
         const u32x4 of = ones_frag<DT>();

@@ -105,7 +105,11 @@ TAIL_8X16_MINPIX = int(os.environ.get("ICAF_TAIL_8X16_MINPIX", 200_000))     # c
 CWIDE = os.environ.get("ICAF_CWIDE", "1") != "0"               # A/B switch: resident-patch / streamed-weights 3x3 kernel (cwide.hip) as a tuner candidate
 CSTREAM = os.environ.get("ICAF_CSTREAM", "1") != "0"           # A/B switch: persistent resident-filter 3x3 kernel as a tuner candidate
 WREG_GEMM = os.environ.get("ICAF_WREG_GEMM", "1") != "0"       # A/B switch: weights-from-registers kernels as tuner candidates
-PERS_GEMM = os.environ.get("ICAF_PERS_GEMM", "1") != "0"       # A/B switch: the persistent long-K GEMM (launch configuration 67) as a tuner candidate
+# The persistent long-K GEMM (launch configuration 67, igemm_pers.hip) as a tuner candidate: OFF by default.  Isolated, it beats the round-4 choices on
+# the paired 3x3 256 -> 256 layers of yolov5l (132 -> 119 us) and on long-K 1x1 layers (-12 ... -16 %), and a forward run alone gets 1 - 2.6 % shorter; but
+# its one workgroup per CU (148 KB of LDS) cannot share a CU with the second forward in flight, and the bench's throughput mode LOSES with it (same box, whole
+# bench: yolov5l shard 3,813 -> 3,778, VEDAI shard 986 -> 975, default workload 16,140 -> 15,995 pairs/s).  ICAF_PERS_GEMM=1 offers it (one batch at a time).
+PERS_GEMM = os.environ.get("ICAF_PERS_GEMM", "0") != "0"
 PERS_MIN_K = int(os.environ.get("ICAF_PERS_MIN_K", "512"))      # ... offered to layers with at least this many K elements (eight 64-element slices)
 WREG64_MAXPIX = int(os.environ.get("ICAF_WREG64_MAXPIX", str(128 * 1024)))     # launches with at most this many pixels are offered the 64-pixel wreg tiles
 

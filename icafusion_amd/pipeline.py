@@ -19,11 +19,18 @@ keep output buffers) and its gathered block, so the tensors step n returned stay
 slot — and two pipelines of the same shape never share buffers.  Results of step i are valid after `synchronize()`.
 PyTorch streams / events are used as plumbing only; every kernel on both streams is ours (plus RCCL).
 """
+import os
+
 import torch
 
 from . import dist as D
 from . import ops
 from .utils.general import nms_device
+
+
+# plans a host-fed pipeline owns beyond its batches in flight: the copy of batch n waits for the END of the forward that used its target plan
+# (depth + EXTRA_PLANS steps earlier) — with one extra plan that forward has only just finished, with two it finished a whole step ago
+EXTRA_PLANS = max(1, int(os.environ.get("ICAF_PIPE_EXTRA_PLANS", "2")))
 
 
 class DetectionPipeline:
@@ -45,7 +52,7 @@ class DetectionPipeline:
         # host-fed pipelines own ONE MORE plan than batches in flight: the copy of the next batch goes straight into the input of the plan that
         # is not in flight (round 4 copied into depth + 1 staging buffers and moved the batch into the plan's input device-to-device: 20 % of
         # the no-feed rate was lost to that hop and to the queue it shared)
-        self.nplans = self.depth + 1 if (self.u8 and overlap) else self.depth
+        self.nplans = self.depth + EXTRA_PLANS if (self.u8 and overlap) else self.depth
         self.plans = [model.plan_for(batch, height, width, self.device, u8=self.u8, slot=s) for s in range(self.nplans)]
         # (a HIGH-PRIORITY stream: HIP maps the streams of a process onto a few hardware queues, and a copy stream that shares its queue with
         #  a forward stream waits behind that stream's graph — the copies then do not overlap the forwards at all; priority streams get
