@@ -65,7 +65,8 @@ class DmffArgs(C.Structure):
                 ("Kp4", C.c_int), ("hidden", C.c_int), ("ldy", C.c_int), ("reserved", C.c_int),
                 ("eps_attn", C.c_float), ("eps_mlp", C.c_float),
                 ("coef_res_attn", C.c_float * 2), ("coef_acc_attn", C.c_float * 2),
-                ("coef_res_mlp", C.c_float * 2), ("coef_acc_mlp", C.c_float * 2), ("debug_clock", C.c_void_p)]
+                ("coef_res_mlp", C.c_float * 2), ("coef_acc_mlp", C.c_float * 2), ("debug_clock", C.c_void_p),
+                ("x32", C.c_void_p), ("y32", C.c_void_p)]          # fp32 residual stream across iterations (icaf.h)
 
 
 _p, _i, _ll, _f, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t

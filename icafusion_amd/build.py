@@ -10,7 +10,7 @@ Every compile also asks the backend for its per-kernel resource usage (-Rpass-an
 summary lands in lib/kernel_resources.json, and the build FAILS if a kernel that synchronises its LDS-DMA ring with
 counted `s_waitcnt vmcnt(N)` waits (igemm_dma / ctile / bneck / stem / stem2 / dmff_* kernels) uses scratch memory: a register
 spill is a VMEM operation too, it bumps the same counter, and the counted wait would then let a wave read a slice of
-the ring that has not landed yet — silently, and only at large grids.
+the ring that has not landed yet — silently, and only at large grids (docs/HISTORY.md §10).
 """
 import concurrent.futures as cf
 import hashlib

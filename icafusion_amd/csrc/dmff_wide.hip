@@ -30,6 +30,7 @@
 // LayerNorm: 1/9 of the FLOPs), writes its fc2 partial sums in fp32, and a second, tiny launch (dmff_wide_reduce_kernel) adds the
 // partials in FIXED order (deterministic, no atomics, no in-kernel fences: the agent-scope release / acquire of round 3's one-launch
 // attempt emptied the L2 of the very weights being streamed) and applies bias + coefficient mix.
+#include <type_traits>
 #include "icaf_common.h"
 #include "conv_common.h"
 
@@ -39,6 +40,8 @@ struct WideP {
     const void* x;            // tokens [2][rows][C]: LN + QKV input / residual of the attention mix
     const void* att;          // proj_mlp: attention output [2][rows][C]
     float* part;              // hidden split: fc2 partial sums [KS][2][rows][C] fp32
+    const float* x32;         // R32 (round 5): the token stream of the PREVIOUS iteration in fp32 [2][rows][C] (NULL: first iteration, x is all there is)
+    float* y32;               // R32: this iteration's tokens in fp32 [2][rows][C] (the 16-bit y is written as well: LayerNorm + QKV read it)
     void* qkv;                // ln_qkv: [2][rows][3C]
     void* y;                  // proj_mlp: element (g, row, c) at y + g * y_gs + row * ldy + c
     const void* wqkv; const float* bqkv;      // FRAGMENT-MAJOR weights [2][Np/32][Kp/16][64][8]; biases fp32 [2][Np]
@@ -241,7 +244,10 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_ln_qkv_kernel(const WideP p) 
 // ---------------------------------------------------------------------------------------------------------------
 // out-projection + LayerNorm + MLP: a workgroup = 64 token rows of one modality.  grid = 8 * ceil(tiles / 4)
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT, int NPW, int KS = 1, class G = WG8>          // NPW = C / WPASS passes per C-wide product; KS = workgroups sharing a tile (hidden split)
+// R32 (round 5, blocks with loops > 1): the residual chain x -> x_att -> x' stays in FP32 across iterations — x is read from p.x32 where it exists,
+// x_att is kept (and parked) in fp32, x' is written to p.y32 beside the 16-bit y.  Without it every iteration rounds the token stream twice to the
+// storage type, and three iterations had used up the 16-bit parity margin of the 3-iteration configuration (0.91 x the reference's own bf16 error).
+template <int DT, int NPW, int KS = 1, class G = WG8, bool R32 = false>          // NPW = C / WPASS passes per C-wide product; KS = workgroups sharing a tile (hidden split)
 __global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p) {
     using E = Elem<DT>;
     using T = typename E::type;
@@ -299,6 +305,8 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p
     bool rok[2];
     const T* xres[2];
     T* yrow[2];
+    const float* x32row[2];
+    float* y32row[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const long long row = r0 + t * 32 + l31;
@@ -306,11 +314,22 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p
         const long long grow = rok[t] ? row : p.rows - 1;
         xres[t] = (const T*)p.x + g * p.x_gs + grow * C;
         yrow[t] = (T*)p.y + g * p.y_gs + grow * p.ldy;
+        x32row[t] = (R32 && p.x32) ? p.x32 + ((long long)g * p.rows + grow) * C : nullptr;
+        y32row[t] = R32 ? p.y32 + ((long long)g * p.rows + grow) * C : nullptr;
     }
+    using XQ = typename std::conditional<R32, f32x4, typename Quad<DT>::type>::type;      // x_att per (pass, row half, channel quad): fp32, or rounded to the storage type
+    auto xq_pack = [](float a, float b, float c, float d) -> XQ {
+        if constexpr (R32) return f32x4{a, b, c, d};
+        else return pack4<DT>(a, b, c, d);
+    };
+    auto xq_unpack = [](const XQ& q, float* f) {
+        if constexpr (R32) { f[0] = q[0]; f[1] = q[1]; f[2] = q[2]; f[3] = q[3]; }
+        else unpack4<DT>(q, f);
+    };
 
     // ---- out-projection + coefficient mix: x_att = c_res * x + c_acc * (att W_o^T + b), rounded to the storage type, in registers ----
     constexpr bool PARK = NPW >= 2 || KS > 1;          // (hidden split: the reduce launch reads x_att from the output rows)
-    typename Quad<DT>::type xatt[NPW][2][4];
+    XQ xatt[NPW][2][4];
     {
         const float* bias = p.bo + g * p.bo_gs;
         const float ca = p.c_acc_a[g], cr = p.c_res_a[g];
@@ -329,10 +348,11 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p
                     const int n = i * WPASS + wn * 32 + 8 * q + 4 * hi;
                     const f32x4 bv = *(const f32x4*)(bias + n);
                     float rv[4], v[4];
-                    unpack4<DT>(*(const typename Quad<DT>::type*)(xres[t] + n), rv);
+                    if (R32 && x32row[t]) { const f32x4 r4 = *(const f32x4*)(x32row[t] + n); rv[0] = r4[0]; rv[1] = r4[1]; rv[2] = r4[2]; rv[3] = r4[3]; }
+                    else unpack4<DT>(*(const typename Quad<DT>::type*)(xres[t] + n), rv);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (acc[t][4 * q + j] + bv[j]) * ca);
-                    xatt[i][t][q] = pack4<DT>(v[0], v[1], v[2], v[3]);
+                    xatt[i][t][q] = xq_pack(v[0], v[1], v[2], v[3]);
                 }
         }
     }
@@ -349,7 +369,7 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v[4];
-                    unpack4<DT>(xatt[i][t][q], v);
+                    xq_unpack(xatt[i][t][q], v);
                     sum[t] += (v[0] + v[1]) + (v[2] + v[3]);
                 }
 #pragma unroll
@@ -374,7 +394,7 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v[4];
-                    unpack4<DT>(xatt[i][t][q], v);
+                    xq_unpack(xatt[i][t][q], v);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { const float d = v[j] - mean[t]; sq[t] += d * d; }
                 }
@@ -400,13 +420,18 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     float v[4], o[4];
-                    unpack4<DT>(xatt[i][t][q], v);
+                    xq_unpack(xatt[i][t][q], v);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean[t]) * rstd[t] * gv[j] + bv[j];
                     *(typename Quad<DT>::type*)(T0 + (size_t)(t * 32 + l31) * SA + n * EB) = pack4<DT>(o[0], o[1], o[2], o[3]);
                     // C = 512: x_att is needed once more, as the residual of the final mix — parked in the workgroup's own rows of the
                     // output tensor (read back by the same lane) instead of holding 32 more registers through the MLP (spills otherwise)
-                    if constexpr (PARK) { if (rok[t] && ksl == 0) *(typename Quad<DT>::type*)(yrow[t] + n) = xatt[i][t][q]; }
+                    if constexpr (PARK) {
+                        if (rok[t] && ksl == 0) {
+                            if constexpr (R32) *(f32x4*)(y32row[t] + n) = xatt[i][t][q];          // (fp32 x_att parks in the fp32 output rows)
+                            else *(typename Quad<DT>::type*)(yrow[t] + n) = xatt[i][t][q];
+                        }
+                    }
                 }
             }
         lds_barrier();
@@ -466,11 +491,15 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     float rv[4], v[4];
-                    if constexpr (PARK) unpack4<DT>(*(const typename Quad<DT>::type*)(yrow[t] + n), rv);     // (clamped row when !rok: never stored)
-                    else unpack4<DT>(xatt[i][t][q], rv);
+                    if constexpr (PARK && R32) { const f32x4 r4 = *(const f32x4*)(y32row[t] + n); rv[0] = r4[0]; rv[1] = r4[1]; rv[2] = r4[2]; rv[3] = r4[3]; }
+                    else if constexpr (PARK) unpack4<DT>(*(const typename Quad<DT>::type*)(yrow[t] + n), rv);     // (clamped row when !rok: never stored)
+                    else xq_unpack(xatt[i][t][q], rv);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (acc2[i][t][4 * q + j] + bv[j]) * ca);
-                    if (rok[t]) *(typename Quad<DT>::type*)(yrow[t] + n) = pack4<DT>(v[0], v[1], v[2], v[3]);
+                    if (rok[t]) {
+                        *(typename Quad<DT>::type*)(yrow[t] + n) = pack4<DT>(v[0], v[1], v[2], v[3]);
+                        if constexpr (R32) *(f32x4*)(y32row[t] + n) = f32x4{v[0], v[1], v[2], v[3]};
+                    }
                 }
             }
     }
@@ -478,7 +507,7 @@ __global__ __launch_bounds__(G::WT) void dmff_wide_proj_mlp_kernel(const WideP p
 
 // y = c_res2 * x_att + c_acc2 * (sum_ks part[ks] + b2): x_att was parked in y by the ks = 0 workgroups; the partial sums are added in
 // slice order (a fixed association: the result does not depend on which workgroup finished first).  One thread = 4 channels of one row.
-template <int DT, int KS>
+template <int DT, int KS, bool R32 = false>
 __global__ __launch_bounds__(256) void dmff_wide_reduce_kernel(const WideP p) {
     using T = typename Elem<DT>::type;
     const int C = p.C, nq = C >> 2;
@@ -497,12 +526,15 @@ __global__ __launch_bounds__(256) void dmff_wide_reduce_kernel(const WideP p) {
         }
         const f32x4 bv = *(const f32x4*)(p.b2 + g * p.b2_gs + n);
         T* y = (T*)p.y + g * p.y_gs + row * p.ldy + n;
+        float* y32 = R32 ? p.y32 + ((long long)g * p.rows + row) * C + n : nullptr;
         float rv[4], v[4];
-        unpack4<DT>(*(const typename Quad<DT>::type*)y, rv);
+        if constexpr (R32) { const f32x4 r4 = *(const f32x4*)y32; rv[0] = r4[0]; rv[1] = r4[1]; rv[2] = r4[2]; rv[3] = r4[3]; }      // x_att parked in fp32
+        else unpack4<DT>(*(const typename Quad<DT>::type*)y, rv);
         const float ca = p.c_acc_m[g], cr = p.c_res_m[g];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(cr, rv[j], (sum[j] + bv[j]) * ca);
         *(typename Quad<DT>::type*)y = pack4<DT>(v[0], v[1], v[2], v[3]);
+        if constexpr (R32) *(f32x4*)y32 = f32x4{v[0], v[1], v[2], v[3]};
     }
 }
 
@@ -519,6 +551,10 @@ static int wide_fill(const icaf_dmff_args* a, WideP& p, const char* who) {
     if (a->C != 128 && a->C != 256 && a->C != 512) return fail(ICAF_ERR_UNSUPPORTED, "%s: C=%d (built for 128 [four wavefronts, 128-channel passes] and 256 / 512 [eight, 256-channel passes])", who, a->C);
     if (a->Kp < a->C || a->Kp % (a->dtype == ICAF_F32 ? 32 : 64)) return fail(ICAF_ERR_ARG, "%s: Kp=%d", who, a->Kp);
     p.x = a->x; p.qkv = a->qkv; p.y = a->y; p.att = nullptr; p.part = nullptr;
+    p.x32 = a->x32; p.y32 = a->y32;
+    if (a->x32 && !a->y32) return fail(ICAF_ERR_ARG, "%s: x32 without y32 (the fp32 residual stream is read AND written by every iteration but the first)", who);
+    if (a->y32 && a->dtype == ICAF_F32) return fail(ICAF_ERR_ARG, "%s: the fp32 residual stream belongs to the 16-bit builds", who);
+    if ((a->x32 && ((uintptr_t)a->x32 & 15)) || (a->y32 && ((uintptr_t)a->y32 & 15))) return fail(ICAF_ERR_ARG, "%s: x32 / y32 must be 16-byte aligned", who);
     p.wqkv = a->wqkv; p.bqkv = a->bqkv; p.wo = a->wo; p.bo = a->bo; p.w1 = a->w1; p.b1 = a->b1; p.w2 = a->w2; p.b2 = a->b2;
     p.ln_a_g[0] = a->ln_attn_gamma[0]; p.ln_a_g[1] = a->ln_attn_gamma[1]; p.ln_a_b[0] = a->ln_attn_beta[0]; p.ln_a_b[1] = a->ln_attn_beta[1];
     p.ln_m_g = a->ln_mlp_gamma; p.ln_m_b = a->ln_mlp_beta;
@@ -552,28 +588,32 @@ static size_t wide_proj_mlp_lds(int C, int hid, int eb = 2) {
     return (size_t)WROWS * (C * eb + 16) + (size_t)WROWS * (G::WPASS * eb + 16) + G::NW * 64 * sizeof(float) + (size_t)hid * sizeof(float);
 }
 
-template <int DT, int NPW, class G>
+template <int DT, int NPW, class G, bool R32 = false>
 static int launch_wide_proj_mlp(const WideP& p, hipStream_t s) {
     const size_t lds = wide_proj_mlp_lds<G>(p.C, p.hid, Elem<DT>::BYTES);
-    ICAF_LDS_OPTIN((dmff_wide_proj_mlp_kernel<DT, NPW, 1, G>), lds);
+    ICAF_LDS_OPTIN((dmff_wide_proj_mlp_kernel<DT, NPW, 1, G, R32>), lds);
     const long long ntiles = (p.rows + WROWS - 1) / WROWS;
-    hipLaunchKernelGGL((dmff_wide_proj_mlp_kernel<DT, NPW, 1, G>), dim3((unsigned)(8 * ((ntiles + 3) / 4))), dim3(G::WT), lds, s, p);
+    hipLaunchKernelGGL((dmff_wide_proj_mlp_kernel<DT, NPW, 1, G, R32>), dim3((unsigned)(8 * ((ntiles + 3) / 4))), dim3(G::WT), lds, s, p);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
 
-template <int DT, int NPW, int KS>
+template <int DT, int NPW, int KS, bool R32 = false>
 static int launch_wide_proj_mlp_split(const WideP& p, hipStream_t s) {
     const size_t lds = wide_proj_mlp_lds<WG8>(p.C, p.hid / KS);
-    ICAF_LDS_OPTIN((dmff_wide_proj_mlp_kernel<DT, NPW, KS, WG8>), lds);
+    ICAF_LDS_OPTIN((dmff_wide_proj_mlp_kernel<DT, NPW, KS, WG8, R32>), lds);
     const long long ntiles = (p.rows + WROWS - 1) / WROWS, per = 4 / KS;
-    hipLaunchKernelGGL((dmff_wide_proj_mlp_kernel<DT, NPW, KS, WG8>), dim3((unsigned)(8 * ((ntiles + per - 1) / per))), dim3(WG8::WT), lds, s, p);
+    hipLaunchKernelGGL((dmff_wide_proj_mlp_kernel<DT, NPW, KS, WG8, R32>), dim3((unsigned)(8 * ((ntiles + per - 1) / per))), dim3(WG8::WT), lds, s, p);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
 
 template <int DT>
 static int dispatch_wide_split(const WideP& p, int ksplit, hipStream_t s) {
+    if (p.y32) {                                   // fp32 residual stream (loops > 1): built for the two-way split only
+        if (ksplit != 2) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp_split: the fp32 residual stream is built for ksplit = 2");
+        return p.C == 256 ? launch_wide_proj_mlp_split<DT, 1, 2, true>(p, s) : launch_wide_proj_mlp_split<DT, 2, 2, true>(p, s);
+    }
     if (p.C == 256) return ksplit == 2 ? launch_wide_proj_mlp_split<DT, 1, 2>(p, s) : launch_wide_proj_mlp_split<DT, 1, 4>(p, s);
     return ksplit == 2 ? launch_wide_proj_mlp_split<DT, 2, 2>(p, s) : launch_wide_proj_mlp_split<DT, 2, 4>(p, s);
 }
@@ -585,6 +625,12 @@ static int dispatch_wide_ln_qkv(const WideP& p, hipStream_t s) {
 
 template <int DT>
 static int dispatch_wide_proj_mlp(const WideP& p, hipStream_t s) {
+    if (p.y32) {                                   // fp32 residual stream (loops > 1)
+        if (p.C == 128) return launch_wide_proj_mlp<DT, 1, WG4, true>(p, s);
+        if (p.C == 256) return launch_wide_proj_mlp<DT, 1, WG8, true>(p, s);
+        // (C = 512 unsplit with fp32 x_att: 258 registers — not built; callers keep the 16-bit stream there: ops / CrossTransformerBlock.emit_tokens)
+        return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_proj_mlp: the fp32 residual stream at C = 512 is built for the hidden split (ksplit = 2) only");
+    }
     if (p.C == 128) return launch_wide_proj_mlp<DT, 1, WG4>(p, s);
     return p.C == 256 ? launch_wide_proj_mlp<DT, 1, WG8>(p, s) : launch_wide_proj_mlp<DT, 2, WG8>(p, s);
 }
@@ -594,7 +640,10 @@ static int launch_wide_reduce(const WideP& p, int ksplit, hipStream_t s) {
     const long long items = 2 * p.rows * (p.C / 4);
     long long blocks = (items + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    if (ksplit == 2) hipLaunchKernelGGL((dmff_wide_reduce_kernel<DT, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    if (p.y32) {
+        if (ksplit != 2) return fail(ICAF_ERR_UNSUPPORTED, "icaf_dmff_wide_reduce: the fp32 residual stream is built for ksplit = 2");
+        hipLaunchKernelGGL((dmff_wide_reduce_kernel<DT, 2, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    } else if (ksplit == 2) hipLaunchKernelGGL((dmff_wide_reduce_kernel<DT, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((dmff_wide_reduce_kernel<DT, 4>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;

@@ -772,6 +772,7 @@ class CrossTransformerBlock(HipModule):
 
     # wide levels, 16-bit types: three launches per iteration (ICAF_DMFF_WIDE=0: the seven per-layer launches, A/B switch)
     fuse_wide = os.environ.get("ICAF_DMFF_WIDE", "1") != "0"
+    res32 = os.environ.get("ICAF_DMFF_RES32", "1") != "0"       # loops > 1: the token stream between iterations in fp32 (A/B switch)
     wide_max_c = int(os.environ.get("ICAF_DMFF_WIDE_MAX_C", "512"))
 
     def wide_fusable(self, plan, C):
@@ -809,11 +810,17 @@ class CrossTransformerBlock(HipModule):
             att = plan.tokens(2, rows, C)
             ks = ops.dmff_wide_ksplit(N, C, hid)                   # few tokens per image, weights beyond an XCD's L2: hidden columns split over ks workgroups
             part = plan.empty((ks, 2, rows, C), torch.float32) if ks > 1 else None
+            # several iterations: the residual chain x -> x_att -> x' is carried in FP32 from one iteration to the next (two ping-pong buffers); the
+            # 16-bit tokens are still written (LayerNorm + QKV read them).  Rounding the stream to 16 bits twice per iteration had used up the parity
+            # margin of the 3-iteration configuration (0.91 x the reference's own bf16 error)
+            r32 = self.res32 and nloops > 1 and plan.dtype != torch.float32 and ks in (1, 2) and not (C == 512 and ks == 1)      # (not built: dmff_wide.hip)
+            t32 = [plan.empty((2, rows, C), torch.float32) for _ in range(2)] if r32 else None
             for it in range(nloops):
                 plan.add(ops.dmff_wide_ln_qkv(tok, qkv, p, ln, coef, p["eps"], B, N, self.crossatt.h))
                 plan.add(ops.cross_attention(qkv, att, B, N, self.crossatt.h))
                 nxt = final_out if (final_out is not None and it == nloops - 1) else plan.tokens(2, rows, C)
-                ls = ops.dmff_wide_proj_mlp(tok, att, nxt, p, ln, coef, p["eps"], B, N, self.crossatt.h, partial=part, ksplit=ks)
+                ls = ops.dmff_wide_proj_mlp(tok, att, nxt, p, ln, coef, p["eps"], B, N, self.crossatt.h, partial=part, ksplit=ks,
+                                            x32=(t32[(it - 1) & 1] if (r32 and it > 0) else None), y32=(t32[it & 1] if r32 else None))
                 for l in (ls if isinstance(ls, list) else [ls]):
                     plan.add(l)
                 tok = nxt

@@ -711,7 +711,7 @@ def dmff_wide_ksplit(N, C_, hidden):
     return 2 if (9 * C_ * C_ * 2 > 3 * 2 ** 20 and N <= 128 and hidden % 512 == 0) else 1
 
 
-def dmff_wide_proj_mlp(x, att, y, packs, ln, coef, eps, B, N, heads, name="dmff_proj_mlp", partial=None, ksplit=1):
+def dmff_wide_proj_mlp(x, att, y, packs, ln, coef, eps, B, N, heads, name="dmff_proj_mlp", partial=None, ksplit=1, x32=None, y32=None):
     """Out-projection + LayerNorm + MLP of one block iteration as one launch behind cross_attention (icaf_dmff_wide_proj_mlp); with
     ksplit > 1 (partial: fp32 (ksplit, 2, rows, C) scratch) the hidden columns are split over ksplit workgroups per tile and a second
     small launch reduces the partial sums: returns the LIST [icaf_dmff_wide_proj_mlp_split, icaf_dmff_wide_reduce]."""
@@ -722,16 +722,24 @@ def dmff_wide_proj_mlp(x, att, y, packs, ln, coef, eps, B, N, heads, name="dmff_
     es, hid = x.element_size(), coef["hidden"]
     flops = 2.0 * 2 * rows * (Cc * Cc + 2 * Cc * hid)
     nbytes = 2 * (3 * rows * Cc * es + (Cc * Cc + 2 * Cc * hid) * es)
+    if y32 is not None:                # fp32 residual stream across the block's iterations (icaf.h: icaf_dmff_args.x32 / y32)
+        for t in (x32, y32):
+            assert t is None or (t.dtype == torch.float32 and t.shape == (2, rows, Cc) and t.is_contiguous())
+        a.y32 = y32.data_ptr()
+        a.x32 = x32.data_ptr() if x32 is not None else None
+        nbytes += (2 if x32 is not None else 1) * 2 * rows * Cc * 4
+    else:
+        assert x32 is None
     if ksplit > 1:
         assert partial is not None and partial.dtype == torch.float32 and partial.is_contiguous() and partial.shape == (ksplit, 2, rows, Cc)
         flops += 2.0 * 2 * rows * Cc * Cc * (ksplit - 1)                         # the repeated out-projection
         nbytes += partial.numel() * 4
         main = Launch(lib().icaf_dmff_wide_proj_mlp_split, (C.byref(a), att.data_ptr(), partial.data_ptr(), int(ksplit)),
-                      keep=(a, x, att, y, wp, packs, ln, partial), name=name, flops=flops, nbytes=nbytes)
-        red = Launch(lib().icaf_dmff_wide_reduce, (C.byref(a), partial.data_ptr(), int(ksplit)), keep=(a, y, partial, wp, packs),
+                      keep=(a, x, att, y, wp, packs, ln, partial, x32, y32), name=name, flops=flops, nbytes=nbytes)
+        red = Launch(lib().icaf_dmff_wide_reduce, (C.byref(a), partial.data_ptr(), int(ksplit)), keep=(a, y, partial, wp, packs, y32),
                      name=name + "_reduce", nbytes=partial.numel() * 4 + 2 * 2 * rows * Cc * es)
         return [main, red]
-    return Launch(lib().icaf_dmff_wide_proj_mlp, (C.byref(a), att.data_ptr()), keep=(a, x, att, y, wp, packs, ln), name=name, flops=flops, nbytes=nbytes)
+    return Launch(lib().icaf_dmff_wide_proj_mlp, (C.byref(a), att.data_ptr()), keep=(a, x, att, y, wp, packs, ln, x32, y32), name=name, flops=flops, nbytes=nbytes)
 
 
 def dmff_upsample_merge(tokens, fea_rgb, fea_ir, out, th, tw, name="dmff_upsample_merge"):

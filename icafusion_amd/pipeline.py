@@ -31,6 +31,7 @@ from .utils.general import nms_device
 # plans a host-fed pipeline owns beyond its batches in flight: the copy of batch n waits for the END of the forward that used its target plan
 # (depth + EXTRA_PLANS steps earlier) — with one extra plan that forward has only just finished, with two it finished a whole step ago
 EXTRA_PLANS = max(1, int(os.environ.get("ICAF_PIPE_EXTRA_PLANS", "2")))
+COPY_STREAMS = max(1, int(os.environ.get("ICAF_PIPE_COPY_STREAMS", "1")))      # a batch's host -> device copy in this many slices, one high-priority stream each
 
 
 class DetectionPipeline:
@@ -57,8 +58,9 @@ class DetectionPipeline:
         # (a HIGH-PRIORITY stream: HIP maps the streams of a process onto a few hardware queues, and a copy stream that shares its queue with
         #  a forward stream waits behind that stream's graph — the copies then do not overlap the forwards at all; priority streams get
         #  queues of their own)
-        self.copy_stream = torch.cuda.Stream(device=self.device, priority=-1) if self.u8 else None
-        self.copied = [torch.cuda.Event() for _ in self.plans]
+        self.copy_streams = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(COPY_STREAMS)] if self.u8 else []
+        self.copy_stream = self.copy_streams[0] if self.u8 else None
+        self.copied = [[torch.cuda.Event() for _ in self.copy_streams] for _ in self.plans]
         self.plan = self.plans[0]
         self.z = self.plan.outputs[0]
         # one forward stream PER PLAN (a plan's hipGraph always replays on the same stream: alternating a graph between two streams cost the
@@ -118,17 +120,23 @@ class DetectionPipeline:
         until its copy has run (rotate >= depth + 2 pinned buffers, or wait for `pipe.copied[n % pipe.nplans]`)."""
         assert self.u8, "DetectionPipeline(u8=True) takes uint8 batches"
         pi = self.n % self.nplans
-        cs, fs = self.copy_stream, self.fwd_streams[pi]
-        if self.n >= self.nplans:
-            cs.wait_event(self.fwd_done[pi])                      # this plan's previous forward (nplans steps ago) has consumed its input
-        if img6.is_cuda:
-            cs.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(cs):
-            self.plans[pi].inputs[0].copy_(img6, non_blocking=True)
-        if img6.is_cuda:
-            img6.record_stream(cs)
-        self.copied[pi].record(cs)
-        fs.wait_event(self.copied[pi])
+        fs = self.fwd_streams[pi]
+        dst = self.plans[pi].inputs[0]
+        B, ncs = img6.shape[0], len(self.copy_streams)
+        for k, cs in enumerate(self.copy_streams):                # the batch in `ncs` slices of images, one copy stream (DMA queue) each
+            lo, hi = B * k // ncs, B * (k + 1) // ncs
+            if hi <= lo:
+                continue
+            if self.n >= self.nplans:
+                cs.wait_event(self.fwd_done[pi])                  # this plan's previous forward (nplans steps ago) has consumed its input
+            if img6.is_cuda:
+                cs.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(cs):
+                dst[lo:hi].copy_(img6[lo:hi], non_blocking=True)
+            if img6.is_cuda:
+                img6.record_stream(cs)
+            self.copied[pi][k].record(cs)
+            fs.wait_event(self.copied[pi][k])
         return self.step()
 
     def step(self):

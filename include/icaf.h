@@ -274,6 +274,11 @@ typedef struct icaf_dmff_args {
     void* debug_clock;   /* NULL, or 8 int64 slots: workgroup (0,0,0) of icaf_dmff_attn_mlp stores the shader clock at its phase boundaries */
     /* reserved: icaf_dmff_wide_ln_qkv reads it as "output-channel passes per workgroup": 1 = one (A/B switch; measured slower), anything else =
      * three; other entry points ignore it */
+    /* fp32 RESIDUAL STREAM across the shared-weight iterations (models/common.py:744-752 run `loops` times: x = block(x)); read by
+     * icaf_dmff_wide_proj_mlp / _split / icaf_dmff_wide_reduce only.  y32 != NULL: this iteration's tokens are ALSO written in fp32 to
+     * y32 [2][B*N][C] (x_att is then kept in fp32 inside the step); x32 != NULL: the residual x of this iteration is read from the previous
+     * iteration's fp32 tokens instead of the 16-bit x (LayerNorm + QKV keep reading the 16-bit tokens).  16-bit dtypes, 16-byte aligned. */
+    const float* x32; float* y32;
 } icaf_dmff_args;
 int icaf_dmff_ln_qkv(const icaf_dmff_args* a, icaf_stream_t s);
 int icaf_dmff_attn_mlp(const icaf_dmff_args* a, icaf_stream_t s);

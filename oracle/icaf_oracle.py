@@ -188,25 +188,30 @@ def cross_attention(v, i, sd, pre, heads, store=None):
     return linear(o_v, sd, pre + ".out_proj_vis"), linear(o_i, sd, pre + ".out_proj_ir")
 
 
-def cross_transformer(v, i, sd, pre, heads, loops, store=None):
+def cross_transformer(v, i, sd, pre, heads, loops, store=None, res32=False):
     """models/common.py:737-759: parameter-shared loop; ONE LN2 normalises both modalities before their MLPs.
     store (optional; tests/test_gpu_dmff_fused.py): a function applied at every point where a 16-bit implementation STORES a tensor
     (normalised tokens, q / k / v, attention output, x_att, the MLP's normalised input, the hidden activations, the block's output).
     With float64 tensors / parameters and store = round-trip through bf16 / f16 this is the reference's arithmetic evaluated exactly,
     with the storage roundings of the HIP kernels and nothing else: what remains between it and a kernel is the kernel's own
-    arithmetic error (fp32 accumulation order, exp2 / erf approximations, the rounding of the attention probabilities)."""
+    arithmetic error (fp32 accumulation order, exp2 / erf approximations, the rounding of the attention probabilities).
+    res32 (with store): the storage pattern of the HIP kernels for loops > 1 since round 5 — the residual chain x -> x_att -> x' is carried
+    UNROUNDED from one iteration to the next (an fp32 token stream beside the 16-bit one); attention still reads the stored (rounded) tokens."""
     st = store or (lambda t: t)
     co = [sd[f"{pre}.coefficient{k}.bias"] for k in range(1, 9)]
     ln_w, ln_b = sd[pre + ".LN2.weight"], sd[pre + ".LN2.bias"]
+    keep = (lambda t: t) if res32 else st          # what happens to a tensor of the residual chain
+    vs, is_ = v, i                                 # the stored (rounded) tokens attention reads
     for _ in range(loops):
-        o_v, o_i = cross_attention(v, i, sd, pre + ".crossatt", heads, store)
-        va = st(co[0] * v + co[1] * o_v)
-        ia = st(co[2] * i + co[3] * o_i)
+        o_v, o_i = cross_attention(vs, is_, sd, pre + ".crossatt", heads, store)
+        va = keep(co[0] * v + co[1] * o_v)
+        ia = keep(co[2] * i + co[3] * o_i)
         hv = linear(st(gelu_erf(linear(st(layer_norm(va, ln_w, ln_b)), sd, pre + ".mlp_vis.0"))), sd, pre + ".mlp_vis.2")
         hi = linear(st(gelu_erf(linear(st(layer_norm(ia, ln_w, ln_b)), sd, pre + ".mlp_ir.0"))), sd, pre + ".mlp_ir.2")
-        v = st(co[4] * va + co[5] * hv)
-        i = st(co[6] * ia + co[7] * hi)
-    return v, i
+        v = keep(co[4] * va + co[5] * hv)
+        i = keep(co[6] * ia + co[7] * hi)
+        vs, is_ = st(v), st(i)
+    return vs, is_
 
 
 def bilinear_resize(t, out_h, out_w):

@@ -23,8 +23,9 @@ def make_block(C, heads, loops, seed):
     return blk, {"b." + k: v for k, v in sd.items()}
 
 
-def run_block(blk, tok, B, N, dtype, fused, max_c=512):
+def run_block(blk, tok, B, N, dtype, fused, max_c=512, res32=True):
     blk.fuse_block, blk.fuse_max_c = fused, max_c        # (the plan uses the two-launch kernels up to C = 128 by default; they are built to 512)
+    blk.res32 = res32                                     # loops > 1, three-launch form: fp32 token stream between iterations (round 5)
     blk.fuse_fp32 = fused                                 # fp32: the parity instantiation of the same template (C <= 128)
     blk.invalidate()
     plan = Plan(DEV, dtype)
@@ -95,7 +96,7 @@ def test_wide_block_three_launches_vs_oracle_and_per_layer_launches(shape, dtype
     assert (wide - plain).abs().max().item() / scale <= 24 * ulp
 
 
-def rounded_reference(tok, sd, heads, loops, dtype, B, N, C):
+def rounded_reference(tok, sd, heads, loops, dtype, B, N, C, res32=False):
     """oracle.cross_transformer in float64 with the storage roundings of a 16-bit implementation and nothing else: parameters of the
     Linear layers rounded to the storage type (the packed weights), LayerNorm parameters / biases / coefficients in fp32 as the kernels
     hold them, every stored tensor round-tripped through the type."""
@@ -106,7 +107,7 @@ def rounded_reference(tok, sd, heads, loops, dtype, B, N, C):
         is_w = k.endswith(".weight") and v.dim() == 2
         sd64[k] = rt(v.float()) if is_w else v.double()
     tq = rt(tok)
-    rv, ri = oracle.cross_transformer(tq[0].reshape(B, N, C), tq[1].reshape(B, N, C), sd64, "b", heads, loops, store=rt)
+    rv, ri = oracle.cross_transformer(tq[0].reshape(B, N, C), tq[1].reshape(B, N, C), sd64, "b", heads, loops, store=rt, res32=res32)
     return torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
 
 
@@ -129,7 +130,7 @@ def test_wide_block_against_the_oracle_in_absolute_terms(shape, dtype):
     blk = blk.to(DEV)
     g = np.random.default_rng(C * 1000 + N + 3)
     tok = torch.from_numpy(g.normal(0.2, 0.8, (2, B * N, C)).astype(np.float32))
-    ref_r = rounded_reference(tok, sd, heads, loops, dtype, B, N, C)
+    ref_r = rounded_reference(tok, sd, heads, loops, dtype, B, N, C, res32=loops > 1)      # (these shapes all take the fp32 token stream when loops > 1)
     tq = tok.to(dtype).float()
     rv, ri = oracle.cross_transformer(tq[0].reshape(B, N, C), tq[1].reshape(B, N, C), sd, "b", heads, loops)
     ref = torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
@@ -159,11 +160,12 @@ def test_wide_block_hidden_split_equals_unsplit(shape, ksplit, monkeypatch):
     tq = tok.to(torch.bfloat16).float()
     rv, ri = oracle.cross_transformer(tq[0].reshape(B, N, C), tq[1].reshape(B, N, C), sd, "b", heads, loops)
     ref = torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
+    # (res32 off: the fp32 token stream of loops > 1 is not built for every split — this test is about the split alone)
     monkeypatch.setattr(ops, "DMFF_KSPLIT", 1)
-    base, _ = run_block(blk, tok, B, N, torch.bfloat16, True, max_c=128)
+    base, _ = run_block(blk, tok, B, N, torch.bfloat16, True, max_c=128, res32=False)
     monkeypatch.setattr(ops, "DMFF_KSPLIT", ksplit)
-    got, names_k = run_block(blk, tok, B, N, torch.bfloat16, True, max_c=128)
-    again, _ = run_block(blk, tok, B, N, torch.bfloat16, True, max_c=128)
+    got, names_k = run_block(blk, tok, B, N, torch.bfloat16, True, max_c=128, res32=False)
+    again, _ = run_block(blk, tok, B, N, torch.bfloat16, True, max_c=128, res32=False)
     assert ("dmff_proj_mlp_reduce" in names_k) == (ksplit > 1)
     assert torch.equal(got, again)
     scale = ref.abs().max().item()
@@ -298,3 +300,34 @@ def test_fp32_wide_dmff_block_vs_reference_golden(name):
     err = np.abs(got - g["out"]).max()
     print(f"{name} fp32 three-launch: max abs error {err:.3e}, |out| max {np.abs(g['out']).max():.3f}")
     assert err <= 2e-4
+
+
+
+# ---- round 5: the token stream between the iterations of a block in fp32 (loops > 1) --------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(128, 8, 400, 2, 3), (256, 8, 256, 2, 3), (512, 8, 100, 2, 3), (256, 4, 77, 3, 2)])
+def test_wide_block_fp32_token_stream_between_iterations(shape, dtype):
+    """loops > 1 (BASELINE config 4 runs three): icaf_dmff_wide_proj_mlp (and the split + reduce pair at P5) keep x -> x_att -> x' in fp32 from
+    one iteration to the next (icaf_dmff_args.x32 / y32) instead of rounding the stream to 16 bits twice per iteration.  Against the fp32
+    oracle the error must not grow beyond the 16-bit stream's and should shrink; against the float64 oracle with the SAME storage pattern
+    (oracle.cross_transformer(res32=True)) it stays within the absolute bound of the kernels' own arithmetic."""
+    C, heads, N, B, loops = shape
+    blk, sd = make_block(C, heads, loops, seed=C + N + 11)
+    blk = blk.to(DEV)
+    g = np.random.default_rng(C * 1000 + N + 11)
+    tok = torch.from_numpy(g.normal(0.2, 0.8, (2, B * N, C)).astype(np.float32))
+    tq = tok.to(dtype).float()
+    rv, ri = oracle.cross_transformer(tq[0].reshape(B, N, C), tq[1].reshape(B, N, C), sd, "b", heads, loops)
+    ref = torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
+    ref_r = rounded_reference(tok, sd, heads, loops, dtype, B, N, C, res32=True)
+    on, names = run_block(blk, tok, B, N, dtype, True, max_c=64, res32=True)
+    off, _ = run_block(blk, tok, B, N, dtype, True, max_c=64, res32=False)
+    assert names.count("dmff_proj_mlp") == loops
+    scale = ref.abs().max().item()
+    e_on, e_off = (on - ref).abs().max().item() / scale, (off - ref).abs().max().item() / scale
+    m_on, m_off = (on - ref).abs().mean().item() / scale, (off - ref).abs().mean().item() / scale
+    d = (on.double() - ref_r).abs()
+    print(f"C={C} N={N} loops={loops} {dtype}: fp32 stream max {e_on:.3e} mean {m_on:.3e} | 16-bit stream max {e_off:.3e} mean {m_off:.3e} | vs same-storage float64 oracle max {d.max().item() / scale:.3e}")
+    assert torch.isfinite(on).all()
+    assert m_on <= 1.02 * m_off + 1e-6 and e_on <= 1.25 * e_off + 1e-4
+    assert d.max().item() / scale <= ABS_BOUND[dtype][0] and d.mean().item() / scale <= ABS_BOUND[dtype][1]

@@ -138,7 +138,7 @@ def test_resident_patch_kernel_shape_table():
 
 def test_c3_tail_launch_configurations_follow_the_map_size():
     """ops.conv_candidates for a C3 tail (cv3 chained behind the last Bottleneck's 3x3, icaf_conv_args.x2): only cwide.hip's two forms, and below
-    TAIL_8X16_MINPIX pixels per stream only the 8 x 8 form (the 8 x 16 form wins isolated timings there and loses the bench: DESIGN.md section 15);
+    TAIL_8X16_MINPIX pixels per stream only the 8 x 8 form (the 8 x 16 form wins isolated timings there and loses the bench: docs/HISTORY.md section 15);
     the tuner signature keeps tails apart from chain_keep launches of the same shape."""
     from types import SimpleNamespace
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static instruction mix of the kernels a workload launches — the analysis behind DESIGN.md section 15's "bound by vector-instruction issue":
+"""Static instruction mix of the kernels a workload launches — the analysis behind docs/HISTORY.md section 15's "bound by vector-instruction issue":
 
     python tools/isa_mix.py [profiles/r04_bench_s_bf16_b32_depth1_kernel_stats.csv] > profiles/r04_isa_mix_s_bf16_b32.txt
 
