@@ -257,6 +257,7 @@ def bottleneck(x, w1_packed, kp1, bias1, w2_packed, kp2, bias2, y, c, add, shape
 
 _TUNE_CACHE = {}
 RETUNE_TILES = {int(t) for t in os.environ.get("ICAF_RETUNE_TILES", "").split(",") if t.strip()}     # e.g. "63,64": see autotune_conv
+RETUNE_PRE = os.environ.get("ICAF_RETUNE_PRE", "0") == "1"       # every configuration of the pre-activation-term launches gets its chance against the cached one
 _RETUNED = set()
 CTILE_SHAPES = {1: (32, 1), 2: (64, 1), 3: (64, 1), 4: (64, 2), 5: (128, 1)}     # shape id -> (BN, stride), ctile.hip
 STREAM_GEMM = os.environ.get("ICAF_STREAM_GEMM", "1") != "0"      # A/B switch for the persistent 1x1 kernel as a tuner candidate
@@ -373,7 +374,7 @@ def autotune_conv(launch, stream_ptr, reps=3, context=()):
         # for THIS launch and the library's own check for that configuration accepts it; otherwise it is dropped and the launch re-tuned.
         if tile_valid(launch, _TUNE_CACHE[sig], cands):
             cached = _TUNE_CACHE[sig]
-            fresh = [c for c in cands if c in RETUNE_TILES and c != cached]
+            fresh = [c for c in cands if (c in RETUNE_TILES or (RETUNE_PRE and a.pre)) and c != cached]
             if not fresh or sig in _RETUNED:
                 a.tile = cached
                 return a.tile

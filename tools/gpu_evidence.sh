@@ -13,6 +13,11 @@
 #   5. default only: the per-layer profiles (fused and per-layer DMFF); PARITY=1: the 16-bit parity table with the small-object mAP recipe (tools/parity16.py).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
+if [ "$TESTS" = 1 ]; then      # the whole GPU suite + smoke on the library the evidence is taken with
+  timeout 900 python -m pytest tests -q -m gpu --timeout=300 --tb=short -p no:cacheprovider > /tmp/ev_tests.log 2>&1
+  echo "== GPU suite: $(tail -1 /tmp/ev_tests.log)"; grep -E "^(FAILED|ERROR)" /tmp/ev_tests.log | head -20
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+fi
 [ "$KEEP" = 1 ] || find gpurun_out -mindepth 1 -maxdepth 1 ! -name '.last_call.json' -exec rm -rf {} +     # the snapshot's old scratch: gpurun_out/ is capped at 64 MiB
 WORKLOADS=${WORKLOADS:-"default c3 c4 c5"}
 line () { python - "$1" "$2" <<'PY'
@@ -63,6 +68,10 @@ for w in $WORKLOADS; do
     cd $R && timeout 900 python bench.py --no-cpu-baseline $ARGS > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err; line $name gpurun_out/bench_$name.json
     trace $name $ARGS
     { [ "$w" = c3 ] && [ "${SQ:-1}" = 1 ]; } && sq c3 $ARGS
+    if [ "$w" = c3 ] && [ "$PERS_SQ" = 1 ]; then      # the persistent long-K GEMM (opt-in, launch configuration 67) under the same counters: its own retuned cache copy
+      cp $R/profiles/tune_cache_$name.json /tmp/tune_pers.json
+      ICAF_PERS_GEMM=1 ICAF_RETUNE_TILES=67 sq c3_pers --model l --batch 32 --tune-cache /tmp/tune_pers.json
+    fi
     cp /tmp/tune_$name.json gpurun_out/tune_cache_$name.json
   fi
 done
