@@ -7,11 +7,11 @@ image (32 of 256 CUs at batch 32), so here batch i's NMS runs concurrently with 
     forward stream : graph(i) -> snapshot z(i) -> graph(i+1) -> snapshot z(i+1) -> ...
     nms stream     :              wait snapshot(i) -> candidates / sort / greedy (i) [-> all_gather(i)] -> ...
 
-With `depth` > 1 (bench default 2) that many batches are in flight: batch n replays plan n % nplans (own buffers, own hipGraph, own
-forward stream), so the low-occupancy tail of one forward overlaps the full-width layers of the next (+13 % throughput on one
+With `depth` > 1 (bench default 2) that many batches are in flight: batch n replays plan n % nplans (own buffers, own hipGraph) on
+forward stream n % depth, so the low-occupancy tail of one forward overlaps the full-width layers of the next (+13 % throughput on one
 MI355X); NMS then reads each plan's own `z` and the plan is not replayed before its NMS has finished.  nplans = depth,
-or depth + 1 when the pipeline is fed from host memory (u8=True): the host -> device copy of batch n + 1 then lands DIRECTLY in the input
-buffer of a plan that no forward in flight is reading — one PCIe copy per batch and no device-to-device hop.
+or a multiple of it when the pipeline is fed from host memory (u8=True): the host -> device copy of a batch then lands DIRECTLY in the
+input buffer of a plan that no forward in flight is reading — one PCIe copy per batch and no device-to-device hop.
 
 With depth 1, `z` is snapshotted into one of two staging buffers because the plan's output buffer is overwritten by the next
 replay; events order snapshot -> NMS -> reuse.  Each of the two slots also owns its NMS runner (workspace + det / count /
@@ -28,9 +28,9 @@ from . import ops
 from .utils.general import nms_device
 
 
-# plans a host-fed pipeline owns beyond its batches in flight: the copy of batch n waits for the END of the forward that used its target plan
-# (depth + EXTRA_PLANS steps earlier) — with one extra plan that forward has only just finished, with two it finished a whole step ago
-EXTRA_PLANS = max(1, int(os.environ.get("ICAF_PIPE_EXTRA_PLANS", "2")))
+# further SETS of `depth` plans a host-fed pipeline owns: the copy of batch n waits for the END of the forward that used its target plan,
+# depth * (1 + EXTRA_PLANS) steps earlier — with one extra set (4 plans at depth 2) that forward finished a whole step ago
+EXTRA_PLANS = max(1, int(os.environ.get("ICAF_PIPE_EXTRA_PLANS", "1")))
 COPY_STREAMS = max(1, int(os.environ.get("ICAF_PIPE_COPY_STREAMS", "1")))      # a batch's host -> device copy in this many slices, one high-priority stream each
 
 
@@ -53,7 +53,10 @@ class DetectionPipeline:
         # host-fed pipelines own ONE MORE plan than batches in flight: the copy of the next batch goes straight into the input of the plan that
         # is not in flight (round 4 copied into depth + 1 staging buffers and moved the batch into the plan's input device-to-device: 20 % of
         # the no-feed rate was lost to that hop and to the queue it shared)
-        self.nplans = self.depth + EXTRA_PLANS if (self.u8 and overlap) else self.depth
+        # (a MULTIPLE of depth: plan p then always replays on forward stream p % depth — a hipGraph keeps its stream — and the pipeline owns no more
+        #  forward streams than forwards in flight: HIP deals a process's streams over a few hardware queues, and every extra stream is one more
+        #  chance that two of them that should overlap share one)
+        self.nplans = self.depth * (1 + EXTRA_PLANS) if (self.u8 and overlap) else self.depth
         self.plans = [model.plan_for(batch, height, width, self.device, u8=self.u8, slot=s) for s in range(self.nplans)]
         # (a HIGH-PRIORITY stream: HIP maps the streams of a process onto a few hardware queues, and a copy stream that shares its queue with
         #  a forward stream waits behind that stream's graph — the copies then do not overlap the forwards at all; priority streams get
@@ -63,9 +66,9 @@ class DetectionPipeline:
         self.copied = [[torch.cuda.Event() for _ in self.copy_streams] for _ in self.plans]
         self.plan = self.plans[0]
         self.z = self.plan.outputs[0]
-        # one forward stream PER PLAN (a plan's hipGraph always replays on the same stream: alternating a graph between two streams cost the
-        # host-fed loop a third of its rate); at most `depth` forwards run at once — forward n waits for forward n - depth (an event)
-        self.fwd_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.nplans)]
+        # `depth` forward streams; plan p always replays on stream p % depth (alternating a graph between two streams cost the host-fed loop a
+        # third of its rate), so at most `depth` forwards run at once by construction
+        self.fwd_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         self.fwd_stream = self.fwd_streams[0]
         self.fwd_done = [torch.cuda.Event() for _ in range(self.nplans)]
         self.nms_stream = torch.cuda.Stream(device=self.device) if overlap else self.fwd_stream
@@ -100,7 +103,7 @@ class DetectionPipeline:
         """Copy one batch into the next step's staging tensors ON that step's forward stream, behind the plan's previous forward (the same
         stream when nplans == depth; an event otherwise) so a forward still reading them is never overwritten, then enqueue the step."""
         pi = self.n % self.nplans
-        fs = self.fwd_streams[pi]
+        fs = self.fwd_streams[pi % self.depth]
         ins = self.plans[pi].inputs
         fs.wait_stream(torch.cuda.current_stream(self.device))     # rgb / ir may have been produced on the caller's stream
         with torch.cuda.stream(fs):                                # (the plan's own stream: behind its previous forward)
@@ -113,14 +116,14 @@ class DetectionPipeline:
 
     def submit_u8(self, img6):
         """One uint8 (B, 6, H, W) batch — pinned host memory (the reference's dataloader output, test.py:116) or a device tensor — through
-        the pipeline.  The copy runs on the pipeline's COPY stream straight into the input buffer of plan n % (depth + 1): the plan that ran
-        depth + 1 steps ago, so the copy only waits for a forward that has long finished — NOT for one of the `depth` forwards in flight (a
+        the pipeline.  The copy runs on the pipeline's COPY stream straight into the input buffer of plan n % nplans: the plan that ran
+        nplans (= 2 * depth) steps ago, so the copy only waits for a forward that has long finished — NOT for one of the `depth` forwards in flight (a
         copy into the input of a plan that is still running could not start before that forward had ended: 9,960 pairs/s where the forward
         alone does 15,600; round 4's extra staging buffers + device-to-device hop: 13,059 of 16,238).  The host buffer must stay untouched
         until its copy has run (rotate >= depth + 2 pinned buffers, or wait for `pipe.copied[n % pipe.nplans]`)."""
         assert self.u8, "DetectionPipeline(u8=True) takes uint8 batches"
         pi = self.n % self.nplans
-        fs = self.fwd_streams[pi]
+        fs = self.fwd_streams[pi % self.depth]
         dst = self.plans[pi].inputs[0]
         B, ncs = img6.shape[0], len(self.copy_streams)
         for k, cs in enumerate(self.copy_streams):                # the batch in `ncs` slices of images, one copy stream (DMA queue) each
@@ -168,14 +171,12 @@ class DetectionPipeline:
         return out
 
     def _step_deep(self):
-        """Several plans: batch n runs plan n % nplans on that plan's own forward stream; its NMS reads that plan's z directly (no snapshot: the
+        """Several plans: batch n runs plan n % nplans on forward stream n % depth (nplans is a multiple of depth: a plan keeps its stream); its NMS reads that plan's z directly (no snapshot: the
         plan is not replayed before its NMS has finished — which also orders the replay behind the plan's previous forward)."""
         pi = self.n % self.nplans
-        fs, ns, plan = self.fwd_streams[pi], self.nms_stream, self.plans[pi]
+        fs, ns, plan = self.fwd_streams[pi % self.depth], self.nms_stream, self.plans[pi]
         if self.n >= self.nplans:
             fs.wait_event(self.nms_done_deep[pi])          # NMS of batch n - nplans has finished reading this plan's z
-        if self.nplans > self.depth and self.n >= self.depth:
-            fs.wait_event(self.fwd_done[(self.n - self.depth) % self.nplans])     # at most `depth` forwards in flight
         plan.run(fs.cuda_stream)
         self.fwd_done[pi].record(fs)
         ns.wait_event(self.fwd_done[pi])
