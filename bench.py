@@ -412,7 +412,8 @@ def main():
                        "parallelism": f"dp{world} (pairs sharded, one all-gather of detections)",
                        "world_size_of_process_group": tdist.get_world_size() if world > 1 else 1,
                        "backend": tdist.get_backend() if world > 1 else None,
-                       "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap, "batches_in_flight": pipe.depth},
+                       "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap, "batches_in_flight": pipe.depth,
+                       "fused_paths": pipe.plans[0].fusion_report()},
             "per_rank_pairs_per_s": {"min": round(min(rank_rates), 2), "max": round(max(rank_rates), 2),
                                      "note": "each rank's own clock around K steps of its shard (value = all ranks, max-over-ranks time)"},
             "forward_only_pairs_per_s": round(B / (fwd_tp_ms * 1e-3), 2),       # same batches-in-flight as `value`, no NMS

@@ -126,6 +126,19 @@ class Plan:
         self.graph = g
         return self
 
+    def fusion_report(self):
+        """Which of the width-specialised fused launches this plan runs, read off its launch names — so that a model whose widths fall outside a
+        specialisation (icaf_stem2: 3 -> 32 -> 64 -> 2 x 32; icaf_bottleneck: c_ in {32, 64}; the three-launch DMFF block: C in {128, 256, 512})
+        shows it instead of silently running the slower per-layer launches.  bench.py prints it as config.fused_paths."""
+        names = [l.name for l in self.launches]
+        n = names.count
+        dmff = ("three-launch" if n("dmff_proj_mlp") else "") + ("+two-launch" if n("dmff_attn_mlp") else "") + ("+per-layer" if n("mlp_fc1") else "")
+        return {"launches": len(names), "stem": "stem2 (stem + 3x3/s2 + 1x1)" if n("stem+conv3x3s2+1x1") else "stem" if n("stem") else "staging + conv",
+                "bottleneck_fused": sum(1 for x in names if x.startswith("bottleneck")), "c3_tails": sum(1 for x in names if x.endswith("+cv3")),
+                "chained_1x1": sum(1 for x in names if x.endswith("+1x1") and not x.startswith("stem")),
+                "dmff_blocks": dmff.strip("+") or "none", "dmff_levels_three_launch": n("dmff_proj_mlp"), "dmff_levels_per_layer": n("mlp_fc1"),
+                "detect": "conv+decode fused" if n("detect_conv+decode") else "conv, decode"}
+
     def timed_run(self, stream_ptr=None):
         """Run launch by launch with a HIP event pair around every kernel; returns [(name, ms, flops, bytes)]."""
         sp = stream_ptr if stream_ptr is not None else ops.current_stream_ptr()

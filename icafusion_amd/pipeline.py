@@ -29,8 +29,9 @@ from .utils.general import nms_device
 
 
 # further SETS of `depth` plans a host-fed pipeline owns: the copy of batch n waits for the END of the forward that used its target plan,
-# depth * (1 + EXTRA_PLANS) steps earlier — with one extra set (4 plans at depth 2) that forward finished a whole step ago
-EXTRA_PLANS = max(1, int(os.environ.get("ICAF_PIPE_EXTRA_PLANS", "1")))
+# depth * (1 + EXTRA_PLANS) steps earlier.  Measured inside a full bench.py run, same box: one extra set (4 plans at depth 2) 10,742 pairs/s,
+# two (6 plans: 11 GB of plan buffers for yolov5s batch 32) 13,407 = the PCIe rate the copy sustains under two forwards (33 GB/s)
+EXTRA_PLANS = max(1, int(os.environ.get("ICAF_PIPE_EXTRA_PLANS", "2")))
 COPY_STREAMS = max(1, int(os.environ.get("ICAF_PIPE_COPY_STREAMS", "1")))      # a batch's host -> device copy in this many slices, one high-priority stream each
 
 
@@ -117,7 +118,7 @@ class DetectionPipeline:
     def submit_u8(self, img6):
         """One uint8 (B, 6, H, W) batch — pinned host memory (the reference's dataloader output, test.py:116) or a device tensor — through
         the pipeline.  The copy runs on the pipeline's COPY stream straight into the input buffer of plan n % nplans: the plan that ran
-        nplans (= 2 * depth) steps ago, so the copy only waits for a forward that has long finished — NOT for one of the `depth` forwards in flight (a
+        nplans (= 3 * depth) steps ago, so the copy only waits for a forward that has long finished — NOT for one of the `depth` forwards in flight (a
         copy into the input of a plan that is still running could not start before that forward had ended: 9,960 pairs/s where the forward
         alone does 15,600; round 4's extra staging buffers + device-to-device hop: 13,059 of 16,238).  The host buffer must stay untouched
         until its copy has run (rotate >= depth + 2 pinned buffers, or wait for `pipe.copied[n % pipe.nplans]`)."""

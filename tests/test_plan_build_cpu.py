@@ -153,3 +153,16 @@ def test_c3_tail_launch_configurations_follow_the_map_size():
     a = tail(51200)
     b = SimpleNamespace(**{**vars(a), "x2": False, "chain_keep": 1})
     assert ops._conv_signature(a) != ops._conv_signature(b) and ops._conv_signature(a)[-1] == 2
+
+
+def test_fusion_report_shows_which_width_specialised_launches_a_plan_runs():
+    """Plan.fusion_report() (bench.py: config.fused_paths): yolov5s runs the fused stem, the fused Bottleneck + cv3 and the three-launch DMFF block
+    at every level; yolov5l's widths fall outside icaf_stem2 / icaf_bottleneck and its P5 level (C = 1024) outside the three-launch form — the
+    report says so instead of the slower launches running silently (VERDICT r4 weak #14)."""
+    rs = Model(load_cfg("yolov5s_Transfusion_kaist.yaml")).eval().build_plan(2, 320, 320, "cpu", torch.bfloat16).fusion_report()
+    assert rs["launches"] == 63 and rs["stem"].startswith("stem2") and rs["bottleneck_fused"] == 1 and rs["dmff_blocks"] == "three-launch"
+    assert rs["dmff_levels_three_launch"] == 3 and rs["dmff_levels_per_layer"] == 0 and rs["detect"].startswith("conv+decode")
+    rl = Model(load_cfg("yolov5l_Transfusion_VEDAI.yaml")).eval().build_plan(1, 320, 320, "cpu", torch.float16).fusion_report()
+    assert rl["stem"] == "stem" and rl["bottleneck_fused"] == 0 and rl["dmff_levels_three_launch"] == 2 and rl["dmff_levels_per_layer"] == 1
+    r32 = Model(load_cfg("yolov5s_Transfusion_kaist.yaml")).eval().build_plan(1, 320, 320, "cpu", torch.float32).fusion_report()
+    assert r32["stem"] == "staging + conv" and r32["dmff_blocks"] == "per-layer" and r32["detect"] == "conv, decode"
