@@ -9,19 +9,24 @@
 //   * WEIGHT STREAM: a 128-pixel tile re-uses a weight byte for 128 MACs; both co-resident workgroups stream the same fragments out of L2;
 //   * two co-resident workgroups re-fetch each other's taps (PMC 1.97 x).
 // Here ONE workgroup of eight waves per CU owns a contiguous SPAN of 32-pixel blocks of one (stream, 256-channel tile), sized so that every CU gets the
-// same number of blocks to within one (3200 blocks over 256 CUs = 12 or 13 each: 96 % full instead of 78 %), and walks it in CHUNKS of up to 256 pixels:
-//   * wave w = output channels [32 w, 32 w + 32) x ALL pixels of the chunk (TM <= 8 accumulator tiles): a weight fragment, fetched once per workgroup
-//     straight into registers (fragment-major copy, igemm_wreg's scheme, two slices ahead), feeds up to eight MFMAs — half the weight bytes per MAC of
-//     the 128-pixel tiles; the pixel operand (<= 32 KiB per 64-element K slice) goes through a four-stage LDS-DMA ring, three slices in flight;
-//   * the K slices of ALL chunks form ONE stream: the first three slices of chunk u + 1 are issued during the last three steps of chunk u, and its first
-//     two weight slices before the epilogue of chunk u — no memory round trip is ever exposed between chunks;
+// same number of blocks to within one (3200 blocks over 256 CUs = 12 or 13 each: 96 % full instead of 78 %), and walks it in CHUNKS of up to 224 pixels:
+//   * wave w = output channels [32 w, 32 w + 32) x ALL pixels of the chunk (TM <= 7 accumulator tiles): a weight fragment, fetched once per workgroup
+//     straight into registers (fragment-major copy, igemm_wreg's scheme, one slice ahead), feeds up to seven MFMAs — about half the weight bytes per
+//     MAC of the 128-pixel tiles; the pixel operand (<= 28 KiB per 64-element K slice) goes through a four-stage LDS-DMA ring;
+//   * the K slices of ALL chunks form ONE stream: the first slices of chunk u + 1 are issued during the last steps of chunk u, and its first weight
+//     slice before the epilogue of chunk u — no memory round trip is ever exposed between chunks;
 //   * the epilogue is PER WAVE (a 32 x 32 tile is transposed through a private 2.5 KiB LDS buffer into 64-byte runs per pixel): no workgroup barrier, no
 //     staging buffer the size of the tile, so the ring keeps its 128 KiB and stays busy through it;
-//   * chunk sizes are balanced inside a span (13 blocks = 7 + 6, not 8 + 5), every TM in 1 .. 8 has its own unrolled loop (selected per chunk, uniform
-//     for the workgroup), and every wave issues the SAME number of vector-memory operations per K step whatever TM is (rows beyond the chunk are
-//     out-of-range DMA: zero fill, no traffic) — the counted `s_waitcnt vmcnt` below relies on that.
+//   * chunk sizes are balanced inside a span (13 blocks = 7 + 6), every TM in 1 .. 7 has its own unrolled loop (selected per chunk, uniform for the
+//     workgroup), and every wave issues the SAME number of vector-memory operations per K step whatever TM is (rows beyond the chunk are out-of-range
+//     DMA: zero fill, no traffic) — the counted `s_waitcnt vmcnt` below relies on that.
 // XCD placement: the two streams (groups = 2) take four XCDs each; an XCD owns a contiguous range of a stream's pixels and runs the workgroups of
 // all channel tiles of a span side by side, so taps and halo rows are shared through ONE L2 and the weights of a stream stay in its own XCDs' L2s.
+//
+// MEASURED (round 5): bit-identical on first run; isolated, 5 - 16 % faster than the round-4 choices on the paired long-K layers
+// (0.41 of the MFMA roof on the 3x3 256 -> 256 layer), slower on the single-stream head layers; a forward run alone gets 1 - 2.6 % shorter, but with two
+// forwards in flight (the bench) it LOSES 1 %: a workgroup that owns a CU shares it with nothing.  Ablations put the pixel operand's LDS-DMA first
+// (16 bytes / clock / CU: the feed limit) — bytes per MAC that no tile height changes.  Hence opt-in: ICAF_PERS_GEMM=1 (ops.conv_candidates).
 #include "conv_common.h"
 
 // Ablation switches for timing studies (tools/quick_variant.py <tag> igemm_pers.hip -DICAF_PERS_ABL=n; results are then meaningless):
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(PERS_NW * 64) void igemm_pers_kernel(const ConvP p,
     static_assert(DT != ICAF_F32, "16-bit types");
     constexpr int RB = PERS_RB, NS = PERS_NS, NW = PERS_NW, STAGE = PERS_STAGE;
     constexpr int VEC = E::VEC, BK = RB / E::BYTES;                  // 8 elements per 16 bytes, 64 K elements per slice
-    constexpr int NA = 4;                                            // DMA instructions per wave and slice: 32 x 1 KiB = 256 rows (TM = 8) — always issued
+    constexpr int NA = 4;                                            // DMA instructions per wave and slice: 32 x 1 KiB = 256 rows of ring stage — always issued
     constexpr int NSTEP = RB / 32;                                   // 4 MFMA steps (= weight fragments) per slice
     constexpr int PER = NA + NSTEP;                                  // vector-memory operations per wave and K step
     constexpr int NB = 2;                                            // weight register buffers = unroll of the K loop: slices c, c + 1 (one slice = up to
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(PERS_NW * 64) void igemm_pers_kernel(const ConvP p,
     unsigned char* ebuf = lds + NS * STAGE + wave * PERS_EBUF;        // this wave's transposition buffer
     const int nw0 = n0 + wave * 32;                                   // the wave's first output channel
 
-    // ---- prologue: weight fragments of slices 0, 1 -> registers; pixel slices 0 .. NS - 2 -> ring ------------------------------------------------
+    // ---- prologue: weight fragments of slice 0 -> registers; pixel slices 0 .. NS - 2 -> ring ---------------------------------------------------
     u32x4 fw[NB][NSTEP];
     load_w(fw[0], 0);
     issue_setup();
@@ -203,8 +208,8 @@ __global__ __launch_bounds__(PERS_NW * 64) void igemm_pers_kernel(const ConvP p,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
         // One slice step.  P = c % NB selects the register buffer of the weight fragments of slice c (compile-time: the K loop is unrolled by NB; every
-        // chunk starts at P = 0 — its slices 0 and 1 were requested into buffers 0 and 1 before the previous chunk's epilogue).  Issues, in this order,
-        // the weight loads of slice c + 2 and the pixel DMA of stream slice q + NS - 1: exactly PER vector-memory operations per wave.
+        // chunk starts at P = 0 — its slice 0 was requested into buffer 0 before the previous chunk's epilogue).  Issues, in this order, the weight loads
+        // of slice c + 1 and the pixel DMA of stream slice q + NS - 1: exactly PER vector-memory operations per wave.
         constexpr int TA = TM > 4 ? 4 : TM, TB = TM - TA, GPS = TB > 0 ? 2 : 1, NG = NSTEP * GPS;      // fragment groups per step, per slice
         u32x4 fa[TA], fb[TB > 0 ? TB : TA];            // (fa carries the NEXT slice's first group across the step boundary: ICAF_PERS_EARLY)
         auto step = [&](auto Ptag, int c) {
@@ -261,13 +266,13 @@ __global__ __launch_bounds__(PERS_NW * 64) void igemm_pers_kernel(const ConvP p,
         using P0 = std::integral_constant<int, 0>;
         using P1 = std::integral_constant<int, 1>;
         // (NB step bodies per TM and ONE loop exit: a chunk always runs a multiple of NB steps — slices past K are zero-fill DMA against clamped weight
-        //  fragments, i.e. exact zeros added to the accumulators: 3x3 layers have 9 Cin / 64 slices, a multiple of three, so only odd 1x1 depths pad)
+        //  fragments, i.e. exact zeros added to the accumulators: only layers with an odd number of 64-element slices pad, by one)
         for (int c = 0; c < nchp; c += NB) {
             step(P0{}, c);
             step(P1{}, c + 1);
         }
 
-        // the next chunk's first two weight slices: in flight through this chunk's epilogue (all three buffers are dead now)
+        // the next chunk's first weight slice: in flight through this chunk's epilogue (both buffers are dead now)
         if (has_next) load_w(fw[0], 0);
 
         // ---- per-wave epilogue: bias + activation in registers (conv_common.h's expressions), 32 x 32 tile -> private LDS buffer -> 64-byte runs ----
