@@ -121,7 +121,7 @@ class DetectionPipeline:
         nplans (= 3 * depth) steps ago, so the copy only waits for a forward that has long finished — NOT for one of the `depth` forwards in flight (a
         copy into the input of a plan that is still running could not start before that forward had ended: 9,960 pairs/s where the forward
         alone does 15,600; round 4's extra staging buffers + device-to-device hop: 13,059 of 16,238).  The host buffer must stay untouched
-        until its copy has run (rotate >= depth + 2 pinned buffers, or wait for `pipe.copied[n % pipe.nplans]`)."""
+        until its copy has run (rotate >= nplans + 2 pinned buffers, or wait for the events in `pipe.copied[n % pipe.nplans]`, one per copy stream)."""
         assert self.u8, "DetectionPipeline(u8=True) takes uint8 batches"
         pi = self.n % self.nplans
         fs = self.fwd_streams[pi % self.depth]
