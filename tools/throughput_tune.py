@@ -91,6 +91,7 @@ for sig, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:a.top]:
     args0 = g["launches"][0].keep[0]
     cur = args0.tile
     sp = streams[0].cuda_stream
+    base = rate(reps=2)                           # re-measured per group, right before its candidates: the chip's clock drifts over a long run
     best_c, best_t = cur, base
     for c in [c for c in ops.conv_candidates(args0) if c != cur]:
         for l in g["launches"]:
@@ -116,8 +117,7 @@ for sig, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:a.top]:
         l.keep[0].tile = best_c if accept else cur
     if accept:
         ops._TUNE_CACHE[sig] = best_c
-        print(f"  M={sig[0]:8d} N={sig[1]:4d} Cin={sig[2]:4d} k={sig[3]} x{len(g['launches']) // 2}: {cur} -> {best_c}   {base:.4f} -> {best_t:.4f} ms")
-        base = best_t
+        print(f"  M={sig[0]:8d} N={sig[1]:4d} Cin={sig[2]:4d} k={sig[3]} x{len(g['launches']) // 2}: {cur} -> {best_c}   {b2:.4f} -> {t2:.4f} ms (interleaved)")
 final = rate()
 print(f"final: {final:.4f} ms per batch with two in flight ({a.batch / final * 1e3:.0f} pairs/s forward only)")
 os.makedirs(os.path.dirname(a.out), exist_ok=True)
