@@ -971,7 +971,7 @@ def test_preprocess_u8_matches_float_path(dt, mode):
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(2, 48, 96, 32, True, False), (1, 44, 72, 64, False, False), (2, 64, 128, 32, True, True),
-                                  (3, 36, 40, 64, True, True)])
+                                  (3, 36, 40, 64, True, True), (2, 96, 200, 64, True, False), (4, 160, 160, 64, True, True)])      # (64 channels: the tile is written back in two halves)
 def test_persistent_stem_equals_staging_plus_conv(case, dt):
     """icaf_stem (staging + 6x6/s2 conv in one persistent kernel, image read directly) vs icaf_preprocess_* followed by
     the 3x3 space-to-depth convolution on the implicit-GEMM kernel: bit-identical."""
