@@ -114,11 +114,8 @@ __device__ __forceinline__ void store_entry(unsigned char* patch, int idx, const
     *(u32x4*)(patch + (((idx << 1) + (1 ^ key)) << 4)) = pack16<DT>(hi4);
 }
 
-// BN = 64 (yolov5l / m widths): 261 registers and 82 KB of LDS left ONE four-wave workgroup per CU — 2.5 TB/s for a kernel that streams 1.15 GB (round 5:
-// 462 us = 5 % of the yolov5l forward).  The tile is written back in two halves of 128 pixels (half the staging buffer: 65.5 KB) and the register
-// allocation is held to two workgroups per CU; the arithmetic and its order are untouched (the same accumulators go through the same epilogue).
 template <int DT, int BN, bool U8>
-__global__ __launch_bounds__(NTHREADS, BN == 64 ? 2 : 1) void stem_kernel(const StemP q) {
+__global__ __launch_bounds__(NTHREADS) void stem_kernel(const StemP q) {
     using E = Elem<DT>;
     static_assert(DT != ICAF_F32, "16-bit types");
     constexpr int RB = 128, TM = 2, TN = BN / 32, BM = ST_TH * ST_TW, WM = BM / 4;
@@ -234,27 +231,10 @@ __global__ __launch_bounds__(NTHREADS, BN == 64 ? 2 : 1) void stem_kernel(const 
 #pragma unroll
                 for (int bb = 0; bb < TM; ++bb) mma_step<DT>(acc[a][bb], fw[a], fp[bb]);
         }
-        if constexpr (BN == 64) {
-            auto half = [&](auto Htag) {           // half h = accumulator tile h of every wave: tile rows wave * 64 + h * 32 + (0 .. 31)
-                constexpr int h = decltype(Htag)::value;
-                f32x16 ah[TN][1];
-#pragma unroll
-                for (int a = 0; a < TN; ++a) ah[a][0] = acc[a][h];
-                if constexpr (h > 0) lds_barrier();                  // the first half's staging reads are done
-                epilogue<DT, DT, BM / 2, BN, WM / 2, BN, ICAF_ACT_SILU, false>(ah, stage, p, stream, [&](int row) {
-                    const int r = ((row >> 5) << 6) + (h << 5) + (row & 31);
-                    const int gy = y0 + (r >> 5), gx = x0 + (r & 31);
-                    return (gy < p.Ho && gx < p.Wo) ? (b * p.Ho + gy) * p.Wo + gx : -1;
-                }, 0);
-            };
-            half(std::integral_constant<int, 0>{});
-            half(std::integral_constant<int, 1>{});
-        } else {
-            epilogue<DT, DT, BM, BN, WM, BN, ICAF_ACT_SILU, false>(acc, stage, p, stream, [&](int row) {
-                const int gy = y0 + (row >> 5), gx = x0 + (row & 31);
-                return (gy < p.Ho && gx < p.Wo) ? (b * p.Ho + gy) * p.Wo + gx : -1;
-            }, 0);
-        }
+        epilogue<DT, DT, BM, BN, WM, BN, ICAF_ACT_SILU, false>(acc, stage, p, stream, [&](int row) {
+            const int gy = y0 + (row >> 5), gx = x0 + (row & 31);
+            return (gy < p.Ho && gx < p.Wo) ? (b * p.Ho + gy) * p.Wo + gx : -1;
+        }, 0);
         if (!more) break;
         commit(cur ? patch0 : patch1, v0, v1);     // (every wave passed the epilogue's barrier: nobody reads that buffer)
         cur ^= 1;
@@ -619,7 +599,7 @@ using namespace icaf;
 template <int DT, int BN, bool U8>
 static int launch_stem(const StemP& q, hipStream_t s) {
     constexpr int EB = Elem<DT>::BYTES;
-    const int lds = 2 * ST_PATCH_BYTES + 3 * BN * 128 + (BN == 64 ? ST_TH * ST_TW / 2 : ST_TH * ST_TW) * (BN * EB + 16);      // (BN = 64: staged in two halves)
+    const int lds = 2 * ST_PATCH_BYTES + 3 * BN * 128 + ST_TH * ST_TW * (BN * EB + 16);
     int dev = 0, cus = 256;
     ICAF_HIP(hipGetDevice(&dev));
     ICAF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
