@@ -191,13 +191,19 @@ def h2d_feed(model, args, B, H, W, dev):
     # the copy alone (no forward behind it): what the link gives this buffer size
     cs = torch.cuda.Stream(device=dev)
     dst = pipe.plans[0].inputs[0]
-    with torch.cuda.stream(cs):
-        dst.copy_(host[0], non_blocking=True)
+    from icafusion_amd import ops, pipeline as P
+
+    def copy(k):
+        if P.FEED_WGS > 0:
+            ops.feed_copy(host[k % nbuf], dst, cs.cuda_stream, P.FEED_WGS)
+        else:
+            with torch.cuda.stream(cs):
+                dst.copy_(host[k % nbuf], non_blocking=True)
+    copy(0)
     cs.synchronize()
     t0 = time.perf_counter()
-    with torch.cuda.stream(cs):
-        for k in range(20):
-            dst.copy_(host[k % nbuf], non_blocking=True)
+    for k in range(20):
+        copy(k)
     cs.synchronize()
     copy_s = (time.perf_counter() - t0) / 20
     nbytes = B * 6 * H * W
@@ -205,6 +211,8 @@ def h2d_feed(model, args, B, H, W, dev):
     return {"pairs_per_s_with_h2d": round(rate, 2), "min": round(min(rates), 2), "max": round(max(rates), 2),
             "host_bytes_per_batch": nbytes, "pcie_gbs_achieved_in_loop": round(rate / B * nbytes / 1e9, 2),
             "pcie_gbs_copy_alone": round(nbytes / copy_s / 1e9, 2), "copy_alone_ms_per_batch": round(1e3 * copy_s, 3),
+            "feed": f"icaf_feed_copy, {P.FEED_WGS} workgroups" if P.FEED_WGS > 0 else "DMA engine (Tensor.copy_)",
+            "streams": {"forward": [st.stream_id for st in pipe.fwd_streams], "nms": pipe.nms_stream.stream_id, "copy": [st.stream_id for st in pipe.copy_streams]},
             "note": f"pinned host uint8 (B,6,H,W) -> ONE copy on a high-priority copy stream straight into the input buffer of one of {pipe.nplans} plans "
                     f"(the one not in flight), {pipe.depth} batch(es) in flight, {nbuf} rotating host buffers; "
                     "forward from uint8 (icaf_stem2 / icaf_preprocess_u8) + NMS; median of 3 x K steps"}

@@ -77,6 +77,7 @@ SIGNATURES = {
     "icaf_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "icaf_preprocess_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_preprocess_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "icaf_feed_copy": (_i, [_p, _p, _ll, _i, _p]),
     "icaf_stem": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _p]),
     "icaf_stem2": (_i, [C.POINTER(Stem2Args), _p]),
     "icaf_conv2d": (_i, [C.POINTER(ConvArgs), _p]),

@@ -2,6 +2,8 @@
 // copy.  All use 16-byte vectors along the contiguous NHWC channel axis; one thread = one (pixel, channel-vector).
 #include "icaf_common.h"
 #include <cstdlib>
+#include <algorithm>
+#include <cstdint>
 
 namespace icaf {
 
@@ -73,6 +75,28 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char*
             *(u32x4*)(out + pix * Cpad + v * E::VEC) = pack16<DT>(f);
         }
     }
+}
+
+// ---- host -> device feed copy (the dataloader's pinned uint8 batch into a plan's input buffer) ----------------------
+// A few resident workgroups stream the batch over PCIe with plain loads from the mapped host allocation: each lane keeps FEED_U 16-byte
+// loads in flight (PCIe read latency is microseconds: nwg * 256 * 16 * FEED_U bytes outstanding cover it), stores go straight to HBM.
+// The copy then is ordinary wave traffic with a dispatch priority, instead of an SDMA transfer that the forwards in flight slow down.
+constexpr int FEED_U = 8;
+__global__ __launch_bounds__(256) void feed_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long long nvec) {
+    const long long step = (long long)gridDim.x * 256 * FEED_U;
+    long long base = (long long)blockIdx.x * 256 * FEED_U + threadIdx.x;
+    for (; base + (FEED_U - 1) * 256 < nvec; base += step) {         // whole chunks: FEED_U loads issued back to back, then FEED_U stores
+        u32x4 v[FEED_U];
+#pragma unroll
+        for (int u = 0; u < FEED_U; ++u) v[u] = __builtin_nontemporal_load(src + base + u * 256);
+#pragma unroll
+        for (int u = 0; u < FEED_U; ++u) __builtin_nontemporal_store(v[u], dst + base + u * 256);
+    }
+    for (int u = 0; u < FEED_U; ++u)                                   // the last, partial chunk (at most one lane set reaches it)
+        if (base + u * 256 < nvec) dst[base + u * 256] = src[base + u * 256];
+}
+__global__ __launch_bounds__(64) void feed_tail_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
 }
 
 // ---- SPPF: y1 = maxpool_k(x), y2 = maxpool_k(y1), y3 = maxpool_k(y2), stride 1, -inf padding ----------------------
@@ -329,6 +353,27 @@ extern "C" int icaf_preprocess_u8(const unsigned char* img, void* out, int dtype
     if (dtype == ICAF_F32) hipLaunchKernelGGL(preprocess_u8_kernel<ICAF_F32>, grid, block, 0, S(s), img, (float*)out, B, Ctot, c0, C, nstreams, H, W, Cpad, mode);
     else if (dtype == ICAF_BF16) hipLaunchKernelGGL(preprocess_u8_kernel<ICAF_BF16>, grid, block, 0, S(s), img, (unsigned short*)out, B, Ctot, c0, C, nstreams, H, W, Cpad, mode);
     else hipLaunchKernelGGL(preprocess_u8_kernel<ICAF_F16>, grid, block, 0, S(s), img, (unsigned short*)out, B, Ctot, c0, C, nstreams, H, W, Cpad, mode);
+    ICAF_LAUNCH_CHECK();
+    return ICAF_OK;
+}
+
+extern "C" int icaf_feed_copy(const void* host, void* dev, long long nbytes, int nwg, icaf_stream_t s) {
+    if (!host || !dev || nbytes < 0) return fail(ICAF_ERR_ARG, "icaf_feed_copy: null pointer / negative size");
+    if (nwg < 1 || nwg > 1024) return fail(ICAF_ERR_ARG, "icaf_feed_copy: nwg %d outside [1, 1024]", nwg);
+    if (((uintptr_t)host | (uintptr_t)dev) & 15) return fail(ICAF_ERR_ARG, "icaf_feed_copy: both pointers must be 16-byte aligned");
+    void* mapped = nullptr;                       // the device-side address of the pinned allocation (the same address under unified addressing)
+    if (hipHostGetDevicePointer(&mapped, const_cast<void*>(host), 0) != hipSuccess || !mapped) {
+        (void)hipGetLastError();
+        return fail(ICAF_ERR_ARG, "icaf_feed_copy: host pointer is not pinned, device-mapped memory");
+    }
+    const long long nvec = nbytes / 16;
+    if (nvec) {
+        const long long per = 256LL * FEED_U;
+        const int grid = (int)std::min<long long>(nwg, (nvec + per - 1) / per);
+        hipLaunchKernelGGL(feed_copy_kernel, dim3(grid), dim3(256), 0, S(s), (const u32x4*)mapped, (u32x4*)dev, nvec);
+    }
+    if (nbytes & 15)
+        hipLaunchKernelGGL(feed_tail_kernel, dim3(1), dim3(64), 0, S(s), (const unsigned char*)mapped + nvec * 16, (unsigned char*)dev + nvec * 16, (int)(nbytes & 15));
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }

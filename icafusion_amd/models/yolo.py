@@ -502,12 +502,15 @@ class Model(HipModule):
             return z, logits, raws
         return z.clone(), logits.clone(), [r.clone() for r in raws]
 
-    def plan_for(self, B, H, W, device="cuda", dtype=None, u8=False, slot=0):
+    def plan_for(self, B, H, W, device="cuda", dtype=None, u8=False, slot=0, branches=True):
         """Pre-build (and return) the execution plan; its .inputs are the static RGB / IR staging buffers (u8: the one
         uint8 6-channel staging buffer).  Plans live in a least-recently-used cache capped at `plan_cache_bytes` of plan-owned
         buffers: a validation run with rectangular batches and a ragged last batch (test.py) meets a new (B, H, W) every few
         batches, and each plan pins all of its intermediates (yolov5l 1280x1280 b16: ~40 GB).  Evicted plans are freed as
-        soon as nobody else (a DetectionPipeline, a caller) holds them; the newest plan is always kept."""
+        soon as nobody else (a DetectionPipeline, a caller) holds them; the newest plan is always kept.
+        branches=False: the plan's hipGraph is one chain (no parallel DMFF / Detect branches, whatever `branch_dmff` says) — what a
+        host-fed pipeline wants: a graph with branches runs them on streams of its own, and those share hardware queues with the
+        pipeline's copy and NMS streams."""
         dt = dtype or self.compute_dtype or next(self.parameters()).dtype
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:
@@ -515,6 +518,8 @@ class Model(HipModule):
         key = (B, H, W, dt, device, "u8") if u8 else (B, H, W, dt, device)
         if slot:                                    # further plans of the same shape (own buffers): batches in flight side by side
             key = key + ("slot", slot)
+        if not branches:
+            key = key + ("chain",)
         plans = self.__dict__.setdefault("_plans", {})
         plan = plans.pop(key, None)
         if plan is None:
@@ -524,6 +529,10 @@ class Model(HipModule):
                 while plans and sum(p.nbytes for p in plans.values()) > max(cap - hint, 0):
                     plans.pop(next(iter(plans)))
             plan = self.build_plan(B, H, W, device, dt, u8=u8)
+            if not branches and plan.branches:
+                for l in plan.launches:
+                    l.branch = 0
+                plan.branches = {}
             if device.type == "cuda":
                 if self.autotune:
                     plan.autotune()

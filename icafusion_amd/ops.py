@@ -478,6 +478,14 @@ def preprocess_u8(img, out, mode, c0=0, name="preprocess_u8"):
                                              H, W, cpad, mode), keep=(img, out), name=name, nbytes=nb)
 
 
+def feed_copy(host, dst, stream_ptr, nwg=16):
+    """The dataloader's PINNED uint8 batch -> a device buffer of the same size, by `nwg` resident workgroups reading host memory over PCIe
+    (icaf_feed_copy) on the given stream — the reference's `img.to(device, non_blocking=True)` (test.py:116) without the DMA engine."""
+    assert not host.is_cuda and host.is_pinned() and host.is_contiguous(), "feed_copy takes a pinned, contiguous host tensor"
+    assert dst.is_cuda and dst.is_contiguous() and dst.numel() * dst.element_size() == host.numel() * host.element_size()
+    check(lib().icaf_feed_copy(host.data_ptr(), dst.data_ptr(), host.numel() * host.element_size(), int(nwg), stream_ptr), "feed_copy")
+
+
 def stem(img, w_packed, kp, bias, y, cout, name="stem"):
     """Staging + 6x6/s2/p2 stem conv in one persistent kernel (icaf_stem).  img: fp32 (B, 3, H, W) / (2, B, 3, H, W)
     [both streams], or uint8 (B, 6, H, W) [both streams]; y: act or pair act of cout channels at half resolution."""

@@ -29,10 +29,15 @@ from .utils.general import nms_device
 
 
 # further SETS of `depth` plans a host-fed pipeline owns: the copy of batch n waits for the END of the forward that used its target plan,
-# depth * (1 + EXTRA_PLANS) steps earlier.  Measured inside a full bench.py run, same box: one extra set (4 plans at depth 2) 10,742 pairs/s,
-# two (6 plans: 11 GB of plan buffers for yolov5s batch 32) 13,407 = the PCIe rate the copy sustains under two forwards (33 GB/s)
-EXTRA_PLANS = max(1, int(os.environ.get("ICAF_PIPE_EXTRA_PLANS", "2")))
+# depth * (1 + EXTRA_PLANS) steps earlier.  With chain graphs (see HOST_FED_BRANCHES) one extra set is enough — one process each, same box:
+# 4 plans 14,745 / 14,983 pairs/s, 6 plans 14,605 (and 6 plans pin 11 GB for yolov5s batch 32); with branched graphs it took 6 plans to reach
+# 13,400 (4 plans: 10,742)
+EXTRA_PLANS = max(1, int(os.environ.get("ICAF_PIPE_EXTRA_PLANS", "1")))
 COPY_STREAMS = max(1, int(os.environ.get("ICAF_PIPE_COPY_STREAMS", "1")))      # a batch's host -> device copy in this many slices, one high-priority stream each
+COPY_PRIO = int(os.environ.get("ICAF_PIPE_COPY_PRIO", "-1"))     # the copy stream(s) on a high-priority queue: 15,600 / 15,501 pairs/s against 15,288 / 15,369 at normal priority
+HOST_FED_BRANCHES = os.environ.get("ICAF_PIPE_BRANCHES", "0") == "1"       # keep the hipGraph's parallel branches in host-fed pipelines (measured slower)
+# > 0: a pinned host batch is brought over by that many resident workgroups reading host memory (ops.feed_copy), not by the DMA engine
+FEED_WGS = int(os.environ.get("ICAF_FEED_WGS", "0"))
 
 
 class DetectionPipeline:
@@ -58,11 +63,15 @@ class DetectionPipeline:
         #  forward streams than forwards in flight: HIP deals a process's streams over a few hardware queues, and every extra stream is one more
         #  chance that two of them that should overlap share one)
         self.nplans = self.depth * (1 + EXTRA_PLANS) if (self.u8 and overlap) else self.depth
-        self.plans = [model.plan_for(batch, height, width, self.device, u8=self.u8, slot=s) for s in range(self.nplans)]
+        # (host-fed: chain graphs.  A graph with parallel branches replays them on streams of its own, which share hardware queues with the copy
+        #  and NMS streams: same box, one process each, 13,578 pairs/s with the branches, 15,153 without, 15,172 with no graph at all — and
+        #  16,100-16,500 with the inputs resident, where the branches are worth 3 %)
+        self.plans = [model.plan_for(batch, height, width, self.device, u8=self.u8, slot=s, branches=HOST_FED_BRANCHES or not (self.u8 and overlap))
+                      for s in range(self.nplans)]
         # (a HIGH-PRIORITY stream: HIP maps the streams of a process onto a few hardware queues, and a copy stream that shares its queue with
         #  a forward stream waits behind that stream's graph — the copies then do not overlap the forwards at all; priority streams get
         #  queues of their own)
-        self.copy_streams = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(COPY_STREAMS)] if self.u8 else []
+        self.copy_streams = [torch.cuda.Stream(device=self.device, priority=COPY_PRIO) for _ in range(COPY_STREAMS)] if self.u8 else []
         self.copy_stream = self.copy_streams[0] if self.u8 else None
         self.copied = [[torch.cuda.Event() for _ in self.copy_streams] for _ in self.plans]
         self.plan = self.plans[0]
@@ -84,7 +93,6 @@ class DetectionPipeline:
         self.gathered = [torch.empty((world * (batch * max_det * 6 + batch),), dtype=torch.float32, device=self.device)
                          for _ in range(nslots)] if self.gather else None
         if self.nplans > 1:
-            self.nms_stream = torch.cuda.Stream(device=self.device)
             self.deep_runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False) for _ in range(self.nplans)]
             self.nms_done_deep = [torch.cuda.Event() for _ in range(self.nplans)]
             self.deep_gathered = [torch.empty((world * (batch * max_det * 6 + batch),), dtype=torch.float32, device=self.device)
@@ -118,7 +126,7 @@ class DetectionPipeline:
     def submit_u8(self, img6):
         """One uint8 (B, 6, H, W) batch — pinned host memory (the reference's dataloader output, test.py:116) or a device tensor — through
         the pipeline.  The copy runs on the pipeline's COPY stream straight into the input buffer of plan n % nplans: the plan that ran
-        nplans (= 3 * depth) steps ago, so the copy only waits for a forward that has long finished — NOT for one of the `depth` forwards in flight (a
+        nplans (= 2 * depth) steps ago, so the copy only waits for a forward that has long finished — NOT for one of the `depth` forwards in flight (a
         copy into the input of a plan that is still running could not start before that forward had ended: 9,960 pairs/s where the forward
         alone does 15,600; round 4's extra staging buffers + device-to-device hop: 13,059 of 16,238).  The host buffer must stay untouched
         until its copy has run (rotate >= nplans + 2 pinned buffers, or wait for the events in `pipe.copied[n % pipe.nplans]`, one per copy stream)."""
@@ -135,8 +143,11 @@ class DetectionPipeline:
                 cs.wait_event(self.fwd_done[pi])                  # this plan's previous forward (nplans steps ago) has consumed its input
             if img6.is_cuda:
                 cs.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(cs):
-                dst[lo:hi].copy_(img6[lo:hi], non_blocking=True)
+            if FEED_WGS > 0 and not img6.is_cuda and img6.is_pinned():
+                ops.feed_copy(img6[lo:hi], dst[lo:hi], cs.cuda_stream, FEED_WGS)     # resident workgroups read the pinned batch over PCIe
+            else:
+                with torch.cuda.stream(cs):
+                    dst[lo:hi].copy_(img6[lo:hi], non_blocking=True)
             if img6.is_cuda:
                 img6.record_stream(cs)
             self.copied[pi][k].record(cs)

@@ -54,6 +54,12 @@ int icaf_preprocess_nchw(const float* img, void* out, int dtype, int B, int C, i
 int icaf_preprocess_u8(const unsigned char* img, void* out, int dtype, int B, int Ctot, int c0, int C, int nstreams,
                        int H, int W, int Cpad, int mode, icaf_stream_t s);
 
+/* The batch's way onto the device (reference test.py:116 / detect_twostream.py:76: `img.to(device, non_blocking=True)` of the dataloader's
+ * pinned uint8 batch): `nwg` resident workgroups read the PINNED, device-mapped host allocation over PCIe and store into HBM — a kernel on
+ * the caller's (high-priority) copy stream, not a DMA-engine transfer.  host, dev 16-byte aligned; host must come from hipHostMalloc
+ * (torch's pin_memory()); ICAF_ERR_ARG otherwise. */
+int icaf_feed_copy(const void* host, void* dev, long long nbytes, int nwg, icaf_stream_t s);
+
 /* Staging + stem convolution in one persistent kernel: the 6x6 / stride 2 / pad 2 Conv(+BN+SiLU) of yaml rows 0 and 10
  * (models/common.py:48-60) computed straight from the NCHW images (fp32 [nstreams*B][3][H][W], or img_u8 != 0: the
  * dataloader's uint8 [B][ctot][H][W] batch, stream s = channels [3s, 3s+3), value / 255) — no staged copy of the images

@@ -166,3 +166,17 @@ def test_fusion_report_shows_which_width_specialised_launches_a_plan_runs():
     assert rl["stem"] == "stem" and rl["bottleneck_fused"] == 0 and rl["dmff_levels_three_launch"] == 2 and rl["dmff_levels_per_layer"] == 1
     r32 = Model(load_cfg("yolov5s_Transfusion_kaist.yaml")).eval().build_plan(1, 320, 320, "cpu", torch.float32).fusion_report()
     assert r32["stem"] == "staging + conv" and r32["dmff_blocks"] == "per-layer" and r32["detect"] == "conv, decode"
+
+
+def test_chain_plans_for_host_fed_pipelines_have_no_graph_branches():
+    """Model.plan_for(branches=False): the same launches in the same order, none of them on a parallel branch of the hipGraph, cached beside
+    (not instead of) the branched plan of the same shape — DetectionPipeline(u8=True) builds its plans this way."""
+    m = Model(load_cfg("yolov5s_Transfusion_kaist.yaml")).eval()
+    m.compute_dtype = torch.bfloat16
+    m.autotune = False
+    a = m.plan_for(1, 320, 320, "cpu")
+    b = m.plan_for(1, 320, 320, "cpu", branches=False)
+    assert a is not b and a is m.plan_for(1, 320, 320, "cpu") and b is m.plan_for(1, 320, 320, "cpu", branches=False)
+    assert a.branches and any(l.branch for l in a.launches)
+    assert not b.branches and not any(l.branch for l in b.launches)
+    assert [l.name for l in a.launches] == [l.name for l in b.launches]
