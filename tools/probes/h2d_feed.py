@@ -13,7 +13,7 @@ feeds = [0, 8, 16, 32, 64]
 argv = sys.argv[1:]
 if "--feeds" in argv:
     i = argv.index("--feeds")
-    feeds = [int(x) for x in argv[i + 1].split(",")]
+    feeds = [int(x) for x in argv[i + 1].split(",") if x not in ("", "none")]
     del argv[i:i + 2]
 burn = 0
 if "--burn" in argv:                      # take that many streams from torch's pool first: shifts every later stream's place in the pool
