@@ -2,7 +2,7 @@
 """Build a VARIANT of libicaf.so from a copy of icafusion_amd/csrc with some files replaced (kernel A/B on one GPU box:
 run the same script twice with ICAF_LIB=<variant .so> / unset).
 
-    python tools/build_variant.py <tag> [file=path_or_git_rev ...] [-DNAME=VALUE ...]
+    python tools/build_variant.py <tag> [file=path_or_git_rev ...] [-DNAME=VALUE | -f<compiler flag> | <file>.hip:<flag for that file> ...]
 e.g. python tools/build_variant.py oldepi conv_common.h=HEAD igemm.hip=HEAD        python tools/build_variant.py epifast -DICAF_EPI_FAST=1
 writes icafusion_amd/lib/libicaf_<tag>.so (git-ignored, travels with the gpurun snapshot)."""
 import os
@@ -19,8 +19,12 @@ src = os.path.join(ROOT, f"_csrc_{tag}", "csrc")      # same depth as icafusion_
 shutil.rmtree(os.path.dirname(src), ignore_errors=True)
 shutil.copytree(B.CSRC, src)
 for spec in sys.argv[2:]:
-    if spec.startswith("-D"):
-        B.COMMON = B.COMMON + [spec]                # every file of the variant is compiled with the define
+    if ".hip:" in spec:                               # <file>.hip:<flag>: that file only
+        f, flag = spec.split(":", 1)
+        B.PER_FILE[f] = B.PER_FILE.get(f, []) + [flag]
+        continue
+    if spec.startswith("-"):
+        B.COMMON = B.COMMON + [spec]                # every file of the variant is compiled with the define / compiler flag
         continue
     name, what = spec.split("=", 1)
     dst = os.path.join(src, name)
