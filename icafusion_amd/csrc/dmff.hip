@@ -99,7 +99,13 @@ __global__ __launch_bounds__(256) void pool_tokens_kernel(const typename Elem<DT
 // 1024 threads and all R (>= kh for the windows in use) row loads of an item in flight: with 256 threads and four rows at a time a
 // workgroup was a chain of 15 dependent L2 round trips (5 items x 3 batches) and the P4 level took 42 us for 52 MB.  The loads are
 // unconditional (row index clamped; the duplicates hit L1) — a load under `if (d < kh)` makes the compiler wait for each one.
-template <int DT, int R>
+// TR token rows per workgroup (round 5): consecutive token rows share kh - sh input rows, so a workgroup that owns TR of them loads
+// kh + (TR - 1) * sh rows ONCE per item and reduces them into TR column sums / maxima — P4 of a 640x640 input (10x10 windows, stride 2):
+// 12 rows for two token rows instead of 2 x 10, half as many workgroups (two rounds of the chip instead of four), and the 1024 outputs of
+// the horizontal phase fill the workgroup.  The column maxima are kept in the STORAGE type (a maximum of bf16 / f16 values is one of
+// them: exact), 16 bytes per item beside the V fp32 sums: 6 bytes per (column, channel) instead of 8, which is what lets two token rows
+// of P4 (and one of yolov5l's 512-channel P4) fit the 160 KB.  Same additions in the same (dy, dx) order per token as before.
+template <int DT, int R, int TR>
 __global__ __launch_bounds__(1024) void pool_tokens_rows_kernel(const typename Elem<DT>::type* __restrict__ f0, int ld0,
                                                                 const typename Elem<DT>::type* __restrict__ f1, int ld1,
                                                                 const float* __restrict__ pos0, const float* __restrict__ pos1,
@@ -110,66 +116,81 @@ __global__ __launch_bounds__(1024) void pool_tokens_rows_kernel(const typename E
     constexpr int V = E::VEC;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int nv = C / V, nitem = W * nv;
-    float* csum = (float*)lds_raw;                     // [W * nv][V]
-    float* cmax = csum + (size_t)nitem * V;            // [W * nv][V]
+    float* csum = (float*)lds_raw;                                   // [TR][W * nv][V] fp32
+    u32x4* cmax = (u32x4*)(csum + (size_t)TR * nitem * V);           // [TR][W * nv] one packed vector each
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7, ix = bid >> 3;
     const int row = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + ix;      // (as conv_common.h: xcd_tile)
-    const int g = row / (B * th), r = row - g * (B * th), b = r / th, oy = r - b * th;
+    const int thb = (th + TR - 1) / TR;                              // blocks of TR token rows per image
+    const int g = row / (B * thb), r = row - g * (B * thb), b = r / thb, oy0 = (r - b * thb) * TR;
+    const int ntr = th - oy0 < TR ? th - oy0 : TR;                   // token rows of this block (the last block of an image may be short)
+    const int nrow = kh + (ntr - 1) * sh;                            // input rows the block reads
     const typename E::type* f = g ? f1 : f0;
     const int ld = g ? ld1 : ld0;
-    const typename E::type* frow = f + ((long long)b * H + oy * sh) * W * ld;
+    const typename E::type* frow = f + ((long long)b * H + oy0 * sh) * W * ld;
     const long long rstride = (long long)W * ld;
     for (int item = threadIdx.x; item < nitem; item += blockDim.x) {
         const int x = item / nv, v = item - x * nv;
         const typename E::type* p0 = frow + (long long)x * ld + v * V;
-        float sum[V], mx[V];
+        float sum[TR][V], mx[TR][V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) { sum[j] = 0.0f; mx[j] = -INFINITY; }
-        for (int d0 = 0; d0 < kh; d0 += R) {
+        for (int t = 0; t < TR; ++t)
+#pragma unroll
+            for (int j = 0; j < V; ++j) { sum[t][j] = 0.0f; mx[t][j] = -INFINITY; }
+        for (int d0 = 0; d0 < nrow; d0 += R) {
             u32x4 raw[R];
 #pragma unroll
             for (int u = 0; u < R; ++u) {
-                const int d = d0 + u < kh ? d0 + u : kh - 1;
+                const int d = d0 + u < nrow ? d0 + u : nrow - 1;
                 raw[u] = *(const u32x4*)(p0 + d * rstride);
             }
 #pragma unroll
             for (int u = 0; u < R; ++u) {
-                const bool on = d0 + u < kh;
                 float t[V];
                 unpack16<DT>(raw[u], t);
 #pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    sum[j] = on ? sum[j] + t[j] : sum[j];
-                    mx[j] = on ? fmaxf(mx[j], t[j]) : mx[j];
+                for (int k = 0; k < TR; ++k) {
+                    const int dd = d0 + u - k * sh;                  // the row's index inside token row k's window
+                    if (dd >= 0 && dd < kh && k < ntr) {             // wave-uniform: a BRANCH (the empty asm keeps the compiler from turning the
+                        asm volatile("");                            // block into 2 * V selects per row and token row — with them the kernel was
+#pragma unroll                                                       // VALU-bound: 72 instead of 24 instructions per loaded row)
+                        for (int j = 0; j < V; ++j) {
+                            sum[k][j] += t[j];
+                            mx[k][j] = fmaxf(mx[k][j], t[j]);
+                        }
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < V; j += 4) {
-            *(f32x4*)(csum + (size_t)item * V + j) = f32x4{sum[j], sum[j + 1], sum[j + 2], sum[j + 3]};
-            *(f32x4*)(cmax + (size_t)item * V + j) = f32x4{mx[j], mx[j + 1], mx[j + 2], mx[j + 3]};
+        for (int k = 0; k < TR; ++k) {
+#pragma unroll
+            for (int j = 0; j < V; j += 4)
+                *(f32x4*)(csum + ((size_t)k * nitem + item) * V + j) = f32x4{sum[k][j], sum[k][j + 1], sum[k][j + 2], sum[k][j + 3]};
+            cmax[(size_t)k * nitem + item] = pack16<DT>(mx[k]);
         }
     }
     __syncthreads();
     const float inv_area = 1.0f / (float)(kh * kw);
     const float w1 = g ? w1_1 : w1_0, w2 = g ? w2_1 : w2_0;
-    const int N = th * tw;
-    for (int o = threadIdx.x; o < tw * nv; o += blockDim.x) {
-        const int ox = o / nv, v = o - ox * nv;
+    const int N = th * tw, per = tw * nv;
+    for (int o = threadIdx.x; o < ntr * per; o += blockDim.x) {
+        const int k = o / per, o1 = o - k * per, ox = o1 / nv, v = o1 - ox * nv;
         float sum[V], mx[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) { sum[j] = 0.0f; mx[j] = -INFINITY; }
         for (int dx = 0; dx < kw; ++dx) {
-            const size_t it = (size_t)((ox * sw + dx) * nv + v) * V;
+            const size_t it = (size_t)k * nitem + (size_t)(ox * sw + dx) * nv + v;
+            float m[V];
+            unpack16<DT>(cmax[it], m);
 #pragma unroll
             for (int j = 0; j < V; j += 4) {
-                const f32x4 a = *(const f32x4*)(csum + it + j), m = *(const f32x4*)(cmax + it + j);
+                const f32x4 a = *(const f32x4*)(csum + it * V + j);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { sum[j + e] += a[e]; mx[j + e] = fmaxf(mx[j + e], m[e]); }
+                for (int e = 0; e < 4; ++e) { sum[j + e] += a[e]; mx[j + e] = fmaxf(mx[j + e], m[j + e]); }
             }
         }
-        const int n = oy * tw + ox;
+        const int n = (oy0 + k) * tw + ox;
         const float* pos = (g ? pos1 : pos0) + (long long)n * C + v * V;
         float out[V];
 #pragma unroll
@@ -500,25 +521,32 @@ template <int DT>
 int run_pool_tokens(const void* f0, int ld0, const void* f1, int ld1, const float* p0, const float* p1, void* tok, int B, int H, int W, int C,
                     int th, int tw, int kh, int kw, int sh, int sw, float a0, float b0, float a1, float b1, hipStream_t s) {
     using T = typename Elem<DT>::type;
-    const size_t rows_lds = (size_t)W * C * 2 * sizeof(float);        // fp32 column sums + maxima of one token row
-    if ((kh > sh || kw > sw) && rows_lds <= 160 * 1024) {             // overlapping windows: separable, one token row per workgroup
-        static size_t attr_bytes[ICAF_MAX_DEVICES][3] = {};      // per device and instantiation
+    constexpr int V = Elem<DT>::VEC;
+    const size_t row_lds = (size_t)W * (C / V) * (V * sizeof(float) + 16);      // one token row: fp32 column sums + packed column maxima
+    if ((kh > sh || kw > sw) && row_lds <= 160 * 1024) {             // overlapping windows: separable, TR token rows per workgroup
+        // two token rows per workgroup when both fit the LDS, share input rows (kh > sh), are loaded in one batch and still leave a workgroup per CU
+        const int tr = (2 * row_lds <= 160 * 1024 && kh > sh && kh + sh <= 12 && 2 * B * ((th + 1) / 2) >= 256) ? 2 : 1;
+        const size_t rows_lds = tr * row_lds;
+        static size_t attr_bytes[ICAF_MAX_DEVICES][3][2] = {};   // per device and instantiation
         int dev = 0;
         ICAF_HIP(hipGetDevice(&dev));
-        const int rsel = kh <= 4 ? 0 : kh <= 8 ? 1 : 2;          // rows in flight per item: 4 / 8 / 12
-        const void* fn = rsel == 0 ? (const void*)pool_tokens_rows_kernel<DT, 4> : rsel == 1 ? (const void*)pool_tokens_rows_kernel<DT, 8>
-                                                                                             : (const void*)pool_tokens_rows_kernel<DT, 12>;
-        if (rows_lds > 64 * 1024 && dev >= 0 && dev < ICAF_MAX_DEVICES && rows_lds > attr_bytes[dev][rsel]) {
+        const int nrow = kh + (tr - 1) * sh;
+        const int rsel = nrow <= 4 ? 0 : nrow <= 8 ? 1 : 2;      // rows in flight per item: 4 / 8 / 12
+        const void* fns[3][2] = {{(const void*)pool_tokens_rows_kernel<DT, 4, 1>, (const void*)pool_tokens_rows_kernel<DT, 4, 2>},
+                                 {(const void*)pool_tokens_rows_kernel<DT, 8, 1>, (const void*)pool_tokens_rows_kernel<DT, 8, 2>},
+                                 {(const void*)pool_tokens_rows_kernel<DT, 12, 1>, (const void*)pool_tokens_rows_kernel<DT, 12, 2>}};
+        const void* fn = fns[rsel][tr - 1];
+        if (rows_lds > 64 * 1024 && dev >= 0 && dev < ICAF_MAX_DEVICES && rows_lds > attr_bytes[dev][rsel][tr - 1]) {
             ICAF_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
-            attr_bytes[dev][rsel] = rows_lds;
+            attr_bytes[dev][rsel][tr - 1] = rows_lds;
         }
-        const dim3 grid((unsigned)(2 * B * th)), block(1024);
-#define ICAF_POOL_ROWS(RR)                                                                                                                  \
-    pool_tokens_rows_kernel<DT, RR><<<grid, block, rows_lds, s>>>((const T*)f0, ld0, (const T*)f1, ld1, p0, p1, (T*)tok, B, H, W, C, th, tw, kh, \
-                                                                  kw, sh, sw, a0, b0, a1, b1)
-        if (rsel == 0) ICAF_POOL_ROWS(4);
-        else if (rsel == 1) ICAF_POOL_ROWS(8);
-        else ICAF_POOL_ROWS(12);
+        const dim3 grid((unsigned)(2 * B * ((th + tr - 1) / tr))), block(1024);
+#define ICAF_POOL_ROWS(RR, TT)                                                                                                              \
+    pool_tokens_rows_kernel<DT, RR, TT><<<grid, block, rows_lds, s>>>((const T*)f0, ld0, (const T*)f1, ld1, p0, p1, (T*)tok, B, H, W, C, th, tw, \
+                                                                      kh, kw, sh, sw, a0, b0, a1, b1)
+        if (rsel == 0) { if (tr == 2) ICAF_POOL_ROWS(4, 2); else ICAF_POOL_ROWS(4, 1); }
+        else if (rsel == 1) { if (tr == 2) ICAF_POOL_ROWS(8, 2); else ICAF_POOL_ROWS(8, 1); }
+        else { if (tr == 2) ICAF_POOL_ROWS(12, 2); else ICAF_POOL_ROWS(12, 1); }
 #undef ICAF_POOL_ROWS
         ICAF_LAUNCH_CHECK();
         return ICAF_OK;

@@ -1083,7 +1083,10 @@ POOL_CASES = [(2, 128, 40, 40, 20, 20), (1, 64, 40, 40, 16, 16), (1, 64, 64, 80,
               (1, 64, 68, 84, 20, 20),
               (1, 32, 30, 33, 7, 9),      # overlapping windows, token grid not a multiple of the 2x4 block per thread
               (1, 64, 32, 40, 16, 16),    # k (2, 10) s (2, 2): the separable kernel with 4 rows in flight (config 4's P4 level)
-              (1, 32, 31, 20, 16, 16)]    # k (16, 5) s (1, 1): window taller than the 12 rows in flight -> two chunks
+              (1, 32, 31, 20, 16, 16),    # k (16, 5) s (1, 1): window taller than the 12 rows in flight -> two chunks
+              (16, 64, 40, 40, 16, 16),   # k (10, 10) s (2, 2) with >= 256 workgroups: TWO token rows per workgroup (the default workload's P4 level)
+              (32, 32, 30, 33, 7, 9),     # k (6, 9) s (4, 3): two token rows per workgroup, odd token-row count -> a short last block
+              (1, 512, 40, 40, 16, 16)]   # yolov5l's P4 level: 512 channels, one token row per workgroup fits only with the packed column maxima
 
 
 @pytest.mark.parametrize("dt", DTYPES)
