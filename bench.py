@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: this many pairs per step over all GPUs, split contiguously "
                     "(dist.shard_range: BASELINE config 3 = 256 -> 32/GPU on 8, config 5 = 128 -> 16/GPU); overrides --batch")
+    ap.add_argument("--force-gather", action="store_true", help="one rank only: initialise a 1-rank RCCL group and send every step's detection "
+                    "block through the all-gather anyway (what a rank of an N > 1 run pays for the collective and its stream, measured on one GPU)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive serving measurement (pinned host uint8 batches -> device, "
                     "overlapped with the forwards in flight; reported as `h2d_feed`, never as `value`)")
     ap.add_argument("--height", type=int, default=640)
@@ -266,8 +268,12 @@ def main():
     elif not args.tune_cache and os.path.exists(default_cache):
         ops.load_tune_cache(default_cache)
     model.use_graph = not args.no_graph
+    if args.force_gather and world == 1 and not tdist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        tdist.init_process_group(backend="nccl", rank=0, world_size=1)
     pipe = DetectionPipeline(model, B, H, W, dev, conf_thres=args.conf, iou_thres=args.iou, world=world,
-                             overlap=not args.no_overlap, depth=args.depth)
+                             overlap=not args.no_overlap, depth=args.depth, force_gather=args.force_gather and world == 1)
     plan = pipe.plan
     if args.tune_cache and rank == 0:
         ops.save_tune_cache(args.tune_cache)
@@ -420,7 +426,7 @@ def main():
                        "parallelism": f"dp{world} (pairs sharded, one all-gather of detections)",
                        "world_size_of_process_group": tdist.get_world_size() if world > 1 else 1,
                        "backend": tdist.get_backend() if world > 1 else None,
-                       "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap, "batches_in_flight": pipe.depth,
+                       "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap, "batches_in_flight": pipe.depth, "forced_one_rank_all_gather": bool(pipe.gather and world == 1),
                        "fused_paths": pipe.plans[0].fusion_report()},
             "per_rank_pairs_per_s": {"min": round(min(rank_rates), 2), "max": round(max(rank_rates), 2),
                                      "note": "each rank's own clock around K steps of its shard (value = all ranks, max-over-ranks time)"},
@@ -504,8 +510,16 @@ def main():
             fused = Model(cfg).eval()
             fused.load_state_dict(sd)
             out["cpu_baseline"] = cpu_baseline(cfg, fused.fuse().state_dict(), args, args.loops)
-        print(json.dumps(out))
-    if world > 1:
+        # ONE JSON line, and the LAST thing on stdout: RCCL prints a version banner through C stdio when its first communicator comes up
+        # (N > 1, --force-gather); flush that buffer first, or it lands after (or inside) the line when the process exits
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    if tdist.is_initialized():
         tdist.destroy_process_group()
 
 
