@@ -31,6 +31,14 @@ template <int ACT, int DT = ICAF_F32> __device__ __forceinline__ float apply_act
     else if constexpr (ACT == ICAF_ACT_GELU) return DT == ICAF_F32 ? gelu_f(v) : gelu_fast_f(v);
     else return v;
 }
+// four values at once: SiLU goes through silu4_f (packed middle steps, same bits), everything else value by value
+template <int ACT, int DT = ICAF_F32> __device__ __forceinline__ void apply_act4(const float (&x)[4], float (&y)[4]) {
+    if constexpr (ACT == ICAF_ACT_SILU) silu4_f(x, y);
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = apply_act<ACT, DT>(x[j]);
+    }
+}
 
 __device__ __forceinline__ int xcd_tile(int ntile_total) {
     // bijective remap: consecutive logical tiles stay on one XCD (blocks are dispatched round-robin over 8 XCDs)
@@ -160,7 +168,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[4 * k4 + j] = apply_act<ACT, DT>(t[j] + pv[j]) * alpha_acc;
+                for (int j = 0; j < 4; ++j) v[4 * k4 + j] = apply_act<ACT, DT>(t[j] + pv[j]) * alpha_acc;     // (write-back phase of the pre-term layers: not a hot SiLU site)
             }
             u32x4 o = pack16<ODT>(v);                      // rounded to the storage type, as the staged tile of the other path is
             typename EO::type* yp = yg2 + (long long)m * ldy + n;
@@ -252,9 +260,12 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
                         }
                     }
                 }
-                float v[4];
+                float v[4], xin[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, DT>(acc[a][b][4 * q + j] + bv[j] + pv[j]) * alpha_acc;
+                for (int j = 0; j < 4; ++j) xin[j] = acc[a][b][4 * q + j] + bv[j] + pv[j];
+                apply_act4<ACT, DT>(xin, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= alpha_acc;
                 unsigned char* dst = lds + ml * SO + nl * EO::BYTES;
                 if constexpr (EO::BYTES == 4) {
                     *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};

@@ -248,7 +248,8 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp_arg, co
                         float v[4] = {0.f, 0.f, 0.f, 0.f};
                         if (inside) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = silu_f(a1[a][4 * q + e] + b1r[a][q][e]);
+                            for (int e = 0; e < 4; ++e) v[e] = a1[a][4 * q + e] + b1r[a][q][e];
+                            silu4_f(v, v);
                         }
                         u32x2 pk;
                         if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
@@ -325,7 +326,10 @@ __device__ __forceinline__ void ctile_body(const ConvP& p, const int lsp_arg, co
                 for (int bb = 0; bb < TM; ++bb) {
                     float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT>(acc[0][bb][4 * q + j] + bq[q][j]) * p.alpha_acc[g];
+                    for (int j = 0; j < 4; ++j) v[j] = acc[0][bb][4 * q + j] + bq[q][j];
+                    apply_act4<ACT>(v, v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= p.alpha_acc[g];
                     u32x2 pk;
                     if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
                     else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }

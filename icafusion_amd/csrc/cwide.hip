@@ -291,7 +291,10 @@ __global__ __launch_bounds__(256, (CHAIN == 2 ? CwTile<CIN, STR, NSUB>::WG_PER_C
                 const int nl = wave * 32 + 8 * qd + 4 * hi;
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act<ICAF_ACT_SILU, DT>(a[bb][4 * qd + j] + bv[qd][j] + 0.0f) * scale;
+                for (int j = 0; j < 4; ++j) v[j] = a[bb][4 * qd + j] + bv[qd][j] + 0.0f;
+                silu4_f(v, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= scale;
                 u32x2 pk;
                 if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
                 else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }

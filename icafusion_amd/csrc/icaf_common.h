@@ -143,6 +143,29 @@ __device__ __forceinline__ float silu_f(float v) {
     const float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
     return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// Four values at once with the plain arithmetic on register PAIRS (v_pk_mul_f32 / v_pk_add_f32: two fp32 lanes per issue slot at the full
+// rate; the transcendentals stay scalar).  Same operations in the same order as silu_f, value by value: the same bits — 13 issue slots
+// for two values instead of 16.  (Left to itself the compiler packs the bias add and the final product but not the two middle steps.)
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ void silu4_f(const float (&x)[4], float (&y)[4]) {
+#ifdef ICAF_NO_PK_SILU
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = silu_f(x[e]);
+#else
+    const f32x2 c = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.0f, 1.0f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 v = {x[2 * h], x[2 * h + 1]};
+        const f32x2 t = v * c;
+        const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        const f32x2 d = one + e;
+        const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const f32x2 o = v * r;
+        y[2 * h] = o[0];
+        y[2 * h + 1] = o[1];
+    }
+#endif
+}
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 // GELU(erf) for the 16-bit kernels: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below half a unit of bf16 / f16),
 // one hardware exp2 + one rcp + 7 FMAs instead of libm's erff (~100 instructions; measured: 13 k cycles per [64 x 128] hidden chunk,

@@ -269,7 +269,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(c
                     for (int b = 0; b < TM; ++b) {
                         float v[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = silu_f(acc[a][b][4 * q + j] + bv[j]);
+                        for (int j = 0; j < 4; ++j) v[j] = acc[a][b][4 * q + j] + bv[j];
+                        silu4_f(v, v);
                         u32x2 pk;
                         if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
                         else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }

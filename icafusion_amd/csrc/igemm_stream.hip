@@ -71,7 +71,10 @@ struct StoreEpi {
                 }
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, DT>(acc[b][4 * qd + j] + bq[qd][j] + pv[j]) * alpha_acc;
+                for (int j = 0; j < 4; ++j) v[j] = acc[b][4 * qd + j] + bq[qd][j] + pv[j];
+                apply_act4<ACT, DT>(v, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= alpha_acc;
                 u32x2 pk;
                 if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
                 else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }

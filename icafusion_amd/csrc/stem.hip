@@ -15,6 +15,9 @@
 //   * the epilogue is the shared one (bias + SiLU in registers, LDS-staged 16-byte NHWC stores).
 #include "conv_common.h"
 #include <cstring>
+#ifdef ICAF_S2_CLK
+#include <cstdlib>          // (probe builds only: tools/probes/stem2_phases.py)
+#endif
 
 namespace icaf {
 
@@ -284,7 +287,7 @@ static_assert(S2_LHALF <= S2_HALF && S2_HALF + S2_HWD / 2 - 1 < S2_PITCH && S2_S
 static_assert(S2_NS <= 2 * 512, "two space-to-depth entries per thread");
 constexpr int S2_THREADS = 512;
 constexpr int S2_C0 = 32, S2_C1 = 64, S2_C2 = 64, S2_W1_SLICES = 5;    // K1 = 288 -> 5 slices of 128 bytes
-constexpr int S2_LDS = S2_S2D_BYTES + S2_HALO_BYTES + (3 * S2_C0 + S2_W1_SLICES * S2_C1 + S2_C2) * 128;
+constexpr int S2_LDS = S2_S2D_BYTES + S2_HALO_BYTES + (3 * S2_C0 + S2_W1_SLICES * S2_C1 + S2_C2) * 128 + (S2_C1 + S2_C2) * 4;   // + the bias vectors of stages 2 / 3
 
 struct Stem2P {
     const void* img;            // as StemP
@@ -292,6 +295,9 @@ struct Stem2P {
     int B, H, W, nstreams;
     int tiles_x, tiles_y, npatch;
     int Hs, Ws;                 // the stem's output size (H/2, W/2)
+#ifdef ICAF_S2_CLK
+    unsigned long long* clk;    // [wave 0..7][tile 0..S2_CLK_TILES)[S2_CLK_N] s_memtime stamps of workgroup 0
+#endif
     const void* w0; const float* bias0; long long w0_gs, bias0_gs; int Kp0;
     ConvP c;                    // w / bias / Kp: the 3x3 layer;  w2 / bias2 / y2 / ldy2 / Cout2: the 1x1;  Ho, Wo: output
 };
@@ -300,6 +306,12 @@ struct Stem2P {
 // 16-byte load per (channel, row) instead of two 8-byte loads: 6 vector-memory instructions for 374 threads instead of 12 for 512.
 // (Phase clocks of the 3x3 kernels put an issued vector-memory instruction at ~200 cycles of a wave's time beside MFMA work; the
 // prefetch + commit of a tile was 19 % of this kernel.)
+#ifdef ICAF_S2_CLK
+constexpr int S2_CLK_TILES = 16, S2_CLK_N = 12;
+#define S2_STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && clk_tile < S2_CLK_TILES) q.clk[(wave * S2_CLK_TILES + clk_tile) * S2_CLK_N + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S2_STAMP(i) do { } while (0)
+#endif
 template <int DT, bool U8, bool PAIR>
 __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
     using E = Elem<DT>;
@@ -312,6 +324,8 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
     unsigned char* w0b = halo + S2_HALO_BYTES;                             // 3 slices x C0 rows x 128 bytes
     unsigned char* w1b = w0b + 3 * C0 * RB;                                // 5 slices x C1 rows
     unsigned char* w2b = w1b + S2_W1_SLICES * C1 * RB;                     // 1 slice x C2 rows
+    float* bl1 = (float*)(w2b + C2 * RB);                                  // bias of the 3x3 layer (C1 floats), then of the 1x1 (C2 floats): read back
+    float* bl2 = bl1 + C1;                                                 // per tile (32 registers fewer than holding them; the stem's stays in registers)
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -400,6 +414,8 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
         dma_rows((const typename E::type*)q.w0 + stream * q.w0_gs, C0, q.Kp0, 3, w0b);
         dma_rows((const typename E::type*)p.w + stream * p.w_gs, C1, p.Kp, S2_W1_SLICES, w1b);
         dma_rows((const typename E::type*)p.w2 + stream * p.w2_gs, C2, p.Kp2, 1, w2b);
+        if (tid < C1) bl1[tid] = p.bias[stream * p.bias_gs + tid];
+        else if (tid < C1 + C2) bl2[tid - C1] = tid - C1 < p.Cout2 ? p.bias2[stream * p.bias2_gs + tid - C1] : 0.0f;
         wait_vmcnt<0>();
     };
 
@@ -417,10 +433,11 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) foff[s] = l31 * RB + (((2 * s + hi) ^ fkey) << 4);
     // ---- tile-invariant fragment addresses (see the layout note above) ---------------------------------------------------------
-    // stage 1: this wave's up to three sub-tile jobs (19 jobs over 8 waves).  With PAIR staging the LAST waves do no image loads and no
-    // patch commits, so the jobs are dealt from the last wave down (results do not depend on the dealing).
+    // stage 1: this wave's up to three sub-tile jobs (19 jobs over 8 waves), dealt from wave 0 up: waves w and w + 4 share a SIMD and VALU issue is
+    // arbitrated by age, so a third job costs least on the OLDER wave of a pair (round 6, same box: 319 -> 314 us; dealing from the last wave
+    // down — the waves that stage no image data — left the younger wave of three SIMDs alone with its third job).  Results do not depend on the dealing.
     constexpr int S2_NJOBS = (S2_NL + 31) / 32, S2_JPW = (S2_NJOBS + S2_THREADS / 64 - 1) / (S2_THREADS / 64);
-    const int job0 = PAIR ? S2_THREADS / 64 - 1 - wave : wave;
+    const int job0 = wave;
     int s1_rd[S2_JPW][3], s1_wr[S2_JPW], s1_key[S2_JPW], s1_hy[S2_JPW], s1_hx[S2_JPW];
 #pragma unroll
     for (int jj = 0; jj < S2_JPW; ++jj) {
@@ -455,12 +472,19 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
     // channels.  (Loading a bias inside the tile loop is a dependent L2 round trip per use — with one workgroup per CU
     // nothing else would cover it.)
     u32x4 fw0[9];
-    f32x4 b0r[4], b1r[4], b2r[4];
+    f32x4 b0r[4];
     int wstream = -1;
     if constexpr (PAIR) commit_pair(); else commit(v0, v1);
+#ifdef ICAF_S2_CLK
+    int clk_tile = -1;
+#endif
     while (true) {
         int stream, b, y0, x0;
         decode(cur_t, stream, b, y0, x0);
+#ifdef ICAF_S2_CLK
+        ++clk_tile;
+#endif
+        S2_STAMP(0);
         if (stream != wstream) {                   // (re)load this stream's weights (at most twice in a workgroup's life)
             lds_barrier();
             load_weights(stream);
@@ -469,45 +493,56 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) fw0[tap] = *(const u32x4*)(w0b + (tap >> 2) * C0 * RB + foff[tap & 3]);
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                b0r[qd] = *(const f32x4*)(q.bias0 + stream * q.bias0_gs + 8 * qd + 4 * hi);
-                b1r[qd] = *(const f32x4*)(p.bias + stream * p.bias_gs + wn * 32 + 8 * qd + 4 * hi);
-                b2r[qd] = *(const f32x4*)(p.bias2 + stream * p.bias2_gs + wn * 32 + 8 * qd + 4 * hi);
-            }
+            for (int qd = 0; qd < 4; ++qd) b0r[qd] = *(const f32x4*)(q.bias0 + stream * q.bias0_gs + 8 * qd + 4 * hi);
             // consume them here: otherwise the compiler's wait-count bookkeeping treats them as possibly pending at every
             // use inside the tile loop and drains the NEXT tile's prefetch with them
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) asm volatile("" : "+v"(b0r[qd]), "+v"(b1r[qd]), "+v"(b2r[qd]));
+            for (int qd = 0; qd < 4; ++qd) asm volatile("" : "+v"(b0r[qd]));
         }
         const int pn = pt + pstride;
         const bool more = pn < pend;
         nxt_t = cur_t;
         nxt_t.next();
         if (more) { if constexpr (PAIR) fetch_pair(nxt_t); else fetch(nxt_t, v0, v1); }     // next tile's image reads stay in flight during everything below
+        S2_STAMP(1);
         lds_barrier();                             // space-to-depth patch visible
+        S2_STAMP(2);
 
         // ---- stage 1: stem over the halo patch ------------------------------------------------------------------
         {
             const int sy0 = 2 * y0 - 1, sx0 = 2 * x0 - 1;
+            // The nine fragment reads of a job are issued as one burst and pinned there (sched_barrier): left alone the scheduler sinks every
+            // read to just above its MFMA and waits lgkmcnt(0) per step — a full LDS round trip (>= 64 cycles) per 32-cycle MFMA, two waves per
+            // SIMD cannot hide that.  The NEXT job's burst goes out right behind this job's MFMAs, i.e. it lands under the SiLU epilogue.
+            u32x4 fp[2][9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) fp[0][tap] = *(const u32x4*)(s2d + s1_rd[0][tap % 3] + (tap / 3) * (S2_SPITCH * 32));
+#ifdef ICAF_S2_PRIO
+            if (job0 + (S2_JPW - 1) * (S2_THREADS / 64) < S2_NJOBS) __builtin_amdgcn_s_setprio(ICAF_S2_PRIO);      // the waves with a third job
+#endif
 #pragma unroll
             for (int jj = 0; jj < S2_JPW; ++jj) {
                 if (job0 + jj * (S2_THREADS / 64) >= S2_NJOBS) break;             // (wave-uniform)
                 f32x16 a0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a0[r] = 0.0f;
-                u32x4 fp[9];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) fp[tap] = *(const u32x4*)(s2d + s1_rd[jj][tap % 3] + (tap / 3) * (S2_SPITCH * 32));
+                for (int tap = 0; tap < 9; ++tap) mma_step<DT>(a0, fw0[tap], fp[jj & 1][tap]);
+                if (jj + 1 < S2_JPW && job0 + (jj + 1) * (S2_THREADS / 64) < S2_NJOBS) {
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) mma_step<DT>(a0, fw0[tap], fp[tap]);
+                    for (int tap = 0; tap < 9; ++tap)
+                        fp[(jj + 1) & 1][tap] = *(const u32x4*)(s2d + s1_rd[jj + 1 < S2_JPW ? jj + 1 : 0][tap % 3] + (tap / 3) * (S2_SPITCH * 32));
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 const bool inside = s1_hx[jj] < S2_HWD && (unsigned)(sy0 + s1_hy[jj]) < (unsigned)q.Hs && (unsigned)(sx0 + s1_hx[jj]) < (unsigned)q.Ws;
                 if (s1_wr[jj] >= 0) {
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
                         float v[4] = {0.f, 0.f, 0.f, 0.f};
                         if (inside) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = silu_f(a0[4 * qd + e] + b0r[qd][e]);
+                            const float x[4] = {a0[4 * qd] + b0r[qd][0], a0[4 * qd + 1] + b0r[qd][1], a0[4 * qd + 2] + b0r[qd][2], a0[4 * qd + 3] + b0r[qd][3]};
+                            silu4_f(x, v);
                         }
                         u32x2 pk;
                         if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
@@ -517,56 +552,90 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
                 }
             }
         }
+        S2_STAMP(3);
+#ifdef ICAF_S2_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         lds_barrier();                             // halo patch visible; the space-to-depth patch is free
+        S2_STAMP(4);
 
         // ---- stage 2: 3x3 / stride 2 over the halo patch (ctile.hip's loop, weights resident) ---------------------
         f32x16 acc[1][1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+        f32x4 b1r[4];
+        {                                          // K = (tap, channel): 16 per MFMA step; fragment reads S2_PFD steps ahead of their MFMA, pinned (see stage 1)
+            constexpr int NK = 9 * C0 / 16, S2_PFD = 4;
+            u32x4 fpq[NK], fwq[NK];
+            auto rd2 = [&](int k) {
+                const int tap = k >> 1, ky = tap / 3, kx = tap - 3 * ky;
+                fpq[k] = *(const u32x4*)(halo + s2_rd[kx >> 1][k & 1] + (ky * S2_PITCH + (kx & 1) * S2_HALF) * 64);
+                fwq[k] = *(const u32x4*)(w1b + (k >> 2) * C1 * RB + (wn * 32) * RB + foff[k & 3]);
+            };
 #pragma unroll
-        for (int k = 0; k < 9 * C0 / 16; ++k) {    // K = (tap, channel): 16 per MFMA step
-            const int tap = k >> 1, ky = tap / 3, kx = tap - 3 * ky;
-            const u32x4 fp = *(const u32x4*)(halo + s2_rd[kx >> 1][k & 1] + (ky * S2_PITCH + (kx & 1) * S2_HALF) * 64);
-            const u32x4 fw = *(const u32x4*)(w1b + (k >> 2) * C1 * RB + (wn * 32) * RB + foff[k & 3]);
-            mma_step<DT>(acc[0][0], fw, fp);
+            for (int k = 0; k < S2_PFD; ++k) rd2(k);
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                if (k + S2_PFD < NK) rd2(k + S2_PFD);
+                if (k + S2_PFD == NK) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) b1r[qd] = *(const f32x4*)(bl1 + wn * 32 + 8 * qd + 4 * hi);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_step<DT>(acc[0][0], fwq[k], fpq[k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        S2_STAMP(5);
         {                                          // t1 tile -> LDS, rounded to the storage type (igemm CHAIN, step a)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int nl = wn * 32 + 8 * qd + 4 * hi;
                 float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[0][0][4 * qd + e] + b1r[qd][e]);
+                const float x[4] = {acc[0][0][4 * qd] + b1r[qd][0], acc[0][0][4 * qd + 1] + b1r[qd][1], acc[0][0][4 * qd + 2] + b1r[qd][2], acc[0][0][4 * qd + 3] + b1r[qd][3]};
+                silu4_f(x, v);
                 u32x2 pk;
                 if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
                 else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
                 *(u32x2*)(s2d + (wm * 32 + l31) * SO + nl * E::BYTES) = pk;
             }
         }
+        S2_STAMP(6);
         lds_barrier();
+        S2_STAMP(7);
 
         // ---- stage 3: chained 1x1 on the staged tile, then the epilogue (conv_common.h's, with the bias in registers
         //      and LDS-only barriers so that the prefetch stays in flight) -----------------------------------------------
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+        f32x4 b2r[4];
+        {
+            u32x4 fp2[C1 / 16], fw2[C1 / 16];
 #pragma unroll
-        for (int s2 = 0; s2 < C1 / 16; ++s2) {
-            const u32x4 fp2 = *(const u32x4*)(s2d + (wm * 32 + l31) * SO + ((2 * s2 + hi) << 4));
-            const u32x4 fw2 = *(const u32x4*)(w2b + (wn * 32) * RB + foff[s2]);
-            mma_step<DT>(acc[0][0], fw2, fp2);
+            for (int s2 = 0; s2 < C1 / 16; ++s2) {
+                fp2[s2] = *(const u32x4*)(s2d + (wm * 32 + l31) * SO + ((2 * s2 + hi) << 4));
+                fw2[s2] = *(const u32x4*)(w2b + (wn * 32) * RB + foff[s2]);
+            }
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) b2r[qd] = *(const f32x4*)(bl2 + wn * 32 + 8 * qd + 4 * hi);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < C1 / 16; ++s2) mma_step<DT>(acc[0][0], fw2[s2], fp2[s2]);
         }
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {           // (every wave finished stage 2 before the barrier above: halo is free)
             const int nl = wn * 32 + 8 * qd + 4 * hi;
             float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[0][0][4 * qd + e] + b2r[qd][e]);
+            const float x[4] = {acc[0][0][4 * qd] + b2r[qd][0], acc[0][0][4 * qd + 1] + b2r[qd][1], acc[0][0][4 * qd + 2] + b2r[qd][2], acc[0][0][4 * qd + 3] + b2r[qd][3]};
+            silu4_f(x, v);
             u32x2 pk;
             if constexpr (DT == ICAF_BF16) { pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]); }
             else { pk[0] = pack2_f16(v[0], v[1]); pk[1] = pack2_f16(v[2], v[3]); }
             *(u32x2*)(halo + (wm * 32 + l31) * SO + nl * E::BYTES) = pk;
         }
+        S2_STAMP(8);
         lds_barrier();
+        S2_STAMP(9);
         {
             // staged vectors -> registers, then the next tile's patch is committed BEFORE the global stores are issued:
             // the wait for the prefetch (vmcnt counts in order) then never includes this tile's stores
@@ -582,9 +651,11 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
                 yoff[it] = (gy < p.Ho && gx < p.Wo && cv * 8 < p.Cout2) ? (long long)((b * p.Ho + gy) * p.Wo + gx) * p.ldy2 + cv * 8 : -1;
             }
             if (more) { if constexpr (PAIR) commit_pair(); else commit(v0, v1); }     // (every wave passed the barrier above: the staged t1 tile is consumed)
+            S2_STAMP(10);
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (yoff[it] >= 0) *(u32x4*)(yg + yoff[it]) = sv[it];
+            S2_STAMP(11);
         }
         if (!more) break;
         pt = pn;
@@ -674,6 +745,10 @@ extern "C" int icaf_stem2(const icaf_stem2_args* a, icaf_stream_t s) {
     memset(&q, 0, sizeof(q));
     q.img = a->img; q.ctot = a->ctot; q.B = a->B; q.H = a->H; q.W = a->W; q.nstreams = a->nstreams;
     q.Hs = a->H / 2; q.Ws = a->W / 2;
+#ifdef ICAF_S2_CLK
+    q.clk = (unsigned long long*)strtoull(getenv("ICAF_S2_CLK_PTR") ? getenv("ICAF_S2_CLK_PTR") : "0", nullptr, 0);
+    if (!q.clk) return fail(ICAF_ERR_ARG, "icaf_stem2 probe build: ICAF_S2_CLK_PTR is not set");
+#endif
     q.w0 = a->w0; q.bias0 = a->bias0; q.w0_gs = a->w0_gs; q.bias0_gs = a->bias0_gs; q.Kp0 = a->Kp0;
     ConvP& p = q.c;
     p.w = a->w1; p.bias = a->bias1; p.w_gs = a->w1_gs; p.bias_gs = a->bias1_gs; p.Kp = a->Kp1;
