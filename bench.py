@@ -54,8 +54,10 @@ def parse():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--repeats", type=int, default=9, help="the timed region (K steps between barriers) is run this many times; "
+    ap.add_argument("--repeats", type=int, default=9, help="the timed region (K steps between barriers) is run at least this many times; "
                     "`value` is the median run, min / max are reported beside it")
+    ap.add_argument("--min-timed-seconds", type=float, default=3.0, help="keep repeating the timed region (same K steps each) until this much "
+                    "timed GPU work has been done: one region is K x ~2 ms, too short for a utilisation sampler to see (0 = exactly --repeats regions)")
     ap.add_argument("--no-fuse-tail", action="store_true", help="materialise DMFF's merged tensor instead of the fused-tail GEMM")
     ap.add_argument("--no-overlap", action="store_true", help="run NMS on the forward stream (no cross-batch overlap)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight, each with its own plan (buffers, hipGraph) and forward stream: the "
@@ -122,6 +124,27 @@ def dry_run(args):
     return 0 if ok and world == args.gpus else 1
 
 
+def sq_counters(workload):
+    """The committed SQ-counter summary of this workload (tools/gpu_pmc_sq.sh: two rocprofv3 --pmc passes of the same command line, merged;
+    tools/gpu_evidence.sh takes them in the same call as the bench line and installs them as profiles/pmc_sq*.json first): per kernel name
+    MFMA-pipe busy, VALU issue fraction, wave-parked fraction.  PMC counters cannot be read from inside this process."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_sq*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("kernels"):
+            return d["kernels"], os.path.basename(f)
+    return {}, None
+
+
+def binding_roof(fracs):
+    """name of the largest of the roofs a kernel (or the forward) was measured against: what it is closest to being bound by"""
+    best = max(((v, k) for k, v in fracs.items() if v is not None), default=(None, None))
+    return best[1]
+
+
 def cpu_baseline(cfg, sd, args, loops):
     """Oracle forward + oracle NMS on host cores, bounded sample (checker code used as the measured CPU port).
     `sd` is the FUSED state_dict (BatchNorm folded into the convs): the reference serves `.fuse().eval()` models
@@ -145,7 +168,7 @@ def cpu_baseline(cfg, sd, args, loops):
         if dt > 5.0:
             break
     torch.set_num_threads(best_thr)
-    bs = 4
+    bs = 4 if best_t < 1.0 else 1       # (yolov5l at 1280 x 1280 takes seconds per pair: the bounded sample is then single pairs)
     rgb, ir = synth_images(bs, args.height, args.width, seed=0)
     t_fwd = t_nms = 0.0
     n = 0
@@ -160,8 +183,20 @@ def cpu_baseline(cfg, sd, args, loops):
         t_nms += t2 - t1
         n += 1
     pairs = n * bs
+    # BASELINE configs[0]: ONE pair through forward + NMS (detect_twostream.py's frame loop), the CPU twin of `latency_b1`
+    lat = []
+    t_start = time.perf_counter()
+    while len(lat) < 5 and (not lat or (time.perf_counter() - t_start) < max(2.0, args.cpu_seconds / 4)):
+        t0 = time.perf_counter()
+        z1 = om.forward(r1, i1)[0]
+        oracle.non_max_suppression(z1.numpy(), args.conf, args.iou)
+        lat.append(time.perf_counter() - t0)
+    lat.sort()
+    b1 = lat[len(lat) // 2]
     return {"value": round(pairs / (t_fwd + t_nms), 3), "unit": "pairs/s", "cores": best_thr, "host_cpus": ncpu,
             "kind": "port", "forward_pairs_per_s": round(pairs / t_fwd, 3), "nms_ms_per_pair": round(1e3 * t_nms / pairs, 3),
+            "single_pair": {"pairs_per_s": round(1.0 / b1, 3), "latency_ms": round(1e3 * b1, 2), "samples": len(lat),
+                            "note": "BASELINE configs[0]: one pair, forward + NMS, same threads (the CPU twin of latency_b1)"},
             "sample": f"{n} batches of {bs} pairs, {args.height}x{args.width}, fp32 torch-CPU oracle forward + C/numpy NMS "
                       f"(oracle/icaf_oracle.py) on the BN-folded weights (= the reference's .fuse().eval() work), same synthetic weights/inputs recipe, "
                       f"{best_thr} threads (best of 8/16/32/64)"}
@@ -240,6 +275,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    affinity = None
+    if world > 1 and os.environ.get("ICAF_NO_PIN") != "1":      # one process per GPU: keep each rank's host threads next to its GPU
+        pr = torch.cuda.get_device_properties(local)
+        bus = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0" if hasattr(pr, "pci_bus_id") else None
+        affinity = D.pin_to_gpu_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), bus)
+        if affinity.get("pinned"):
+            torch.set_num_threads(max(1, min(8, affinity["cpus"])))
 
     tag = {"kaist": "kaist", "FLIR": "FLIR", "VEDAI": "VEDAI", "LLVIP": "LLVIP"}[args.dataset]
     yaml_name = f"yolov5{args.model}_Transfusion_{tag}.yaml"
@@ -297,13 +339,14 @@ def main():
     # run `repeats` times back to back; `value` comes from the MEDIAN run.  One region is only K x ~2.6 ms long, and a single
     # sample of it moves by several per cent with the box's clocks / whatever else the host is doing.
     runs = []
-    for _ in range(max(1, args.repeats)):
+    while len(runs) < max(1, args.repeats) or (sum(runs) < args.min_timed_seconds and len(runs) < 2000):
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             det, count = step()[:2]
+        pipe.synchronize()                      # (N > 1: also sends a gather group that K steps left incomplete)
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
@@ -319,6 +362,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    pipe.synchronize()
     torch.cuda.synchronize()
     own = n_local * args.steps / (time.perf_counter() - t0)
     rank_rates = [own]
@@ -401,13 +445,53 @@ def main():
                  "avg_launch_us_with_second_forward_in_flight": over_us, "launches_per_step": dn // reps,
                  "share_of_forward_kernel_time": round(dms / reps / total_ms, 3)})
     att = per_kernel.get("cross_attention")
+    workload = (f"{yaml_name[:-5]} + DMFF(loops={args.loops}) {args.dtype}, batch {B}/GPU, "
+                f"{H}x{W} synthetic RGB/IR pairs, seeded random weights, NMS conf {args.conf} iou {args.iou}")
+    # SQ counters of the same command line (committed summary, see sq_counters): which pipe a kernel keeps busy.  `bound` = the roof the
+    # dominant kernel sits closest to: HBM (algorithmic bytes / time / 8 TB/s), MFMA (pipe-busy fraction by the counters when there are
+    # counters, FLOPs / time / dense peak otherwise) or VALU issue (fraction of the SIMDs' cycles in which a vector instruction issues:
+    # SiLU's two transcendentals per value, address arithmetic, packing) — the front kernels of this model are VALU-bound, not HBM-bound
+    sq, sq_src = sq_counters(workload)
+    dsq = sq.get(dname, {})
+    fr_hbm, fr_mfma = gbs / PEAK_HBM_GBS, dsq.get("mfma_util", tflops / PEAK_TFLOPS[args.dtype])
+    by_roof = {"hbm": round(fr_hbm, 4), "mfma": round(fr_mfma, 4), "valu": dsq.get("valu_issue_frac")}
+    roof["bound_by_intensity"] = roof["bound"]
+    roof["bound"] = binding_roof(by_roof)
+    roof.update({"frac_of_each_roof": by_roof, "valu_issue_frac": dsq.get("valu_issue_frac"), "mfma_busy": dsq.get("mfma_util"),
+                 "wave_wait_frac": dsq.get("wave_wait_frac"), "valu_per_mfma": dsq.get("valu_per_mfma"), "sq_source": sq_src,
+                 "note": "achieved / peak / frac are the byte (or FLOP) roofline of the contract: algorithmic work per launch over the HIP-event launch time; "
+                         "`bound` names the largest of frac_of_each_roof (valu / mfma from the SQ counters of the same command line)"})
     # every kernel of the forward with its own two roofline fractions (the `roofline` object above is the first entry of this table: the kernel
     # with the largest share of the forward's kernel time)
     kernels = {k: {"ms_per_step": round(v[0] / reps, 4), "launches": v[3] // reps,
                    "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[1] else None,
                    "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1),
                    "mfma_frac": round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4) if v[1] else None,
-                   "hbm_frac": round(v[2] / (v[0] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)} for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
+                   "hbm_frac": round(v[2] / (v[0] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                   "valu_issue_frac": sq.get(k, {}).get("valu_issue_frac"), "mfma_busy": sq.get(k, {}).get("mfma_util"),
+                   "wave_wait_frac": sq.get(k, {}).get("wave_wait_frac")} for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
+    for k, v in kernels.items():
+        v["bound"] = binding_roof({"hbm": v["hbm_frac"], "mfma": v["mfma_busy"] if v["mfma_busy"] is not None else v["mfma_frac"], "valu": v["valu_issue_frac"]})
+    # the whole forward against each pipe: every kernel's busy fraction weighted by its launch time (one batch at a time, the basis of the counters)
+    kt = {k: v[0] / reps for k, v in per_kernel.items()}
+    have = [k for k in kt if k in sq and sq[k].get("valu_issue_frac") is not None]
+    pipe_busy = None
+    if have:
+        cov = sum(kt[k] for k in have)
+        pipe_busy = {"valu_busy_us": round(1e3 * sum(kt[k] * sq[k]["valu_issue_frac"] for k in have), 1),
+                     "mfma_busy_us": round(1e3 * sum(kt[k] * sq[k]["mfma_util"] for k in have), 1),
+                     "wave_wait_frac": round(sum(kt[k] * (sq[k].get("wave_wait_frac") or 0.0) for k in have) / cov, 3),
+                     "kernel_time_us": round(1e3 * total_ms, 1), "kernel_time_covered_by_counters": round(cov / total_ms, 3)}
+    # DMFF block by SURVEY 8d's formula: (linear + bmm FLOPs of the block's kernels) / (their time x the dense MFMA peak)
+    dm = [per_kernel[k] for k in ("dmff_ln_qkv", "cross_attention", "dmff_proj_mlp", "dmff_proj_mlp_reduce", "dmff_attn_mlp", "layernorm") if k in per_kernel]
+    dmff_block = None
+    if dm:
+        dms_, dfl_ = sum(v[0] for v in dm) / reps, sum(v[1] for v in dm) / reps
+        dmff_block = {"ms_per_step": round(dms_, 4), "gflop_per_step": round(dfl_ / 1e9, 2), "tflops": round(dfl_ / (dms_ * 1e-3) / 1e12, 1),
+                      "mfma_frac": round(dfl_ / (dms_ * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+                      "kernels": [k for k in ("dmff_ln_qkv", "cross_attention", "dmff_proj_mlp", "dmff_proj_mlp_reduce", "dmff_attn_mlp", "layernorm") if k in per_kernel],
+                      "attention_mfma_busy": sq.get("cross_attention", {}).get("mfma_util"),
+                      "note": "LN + QKV, crossed attention, out-proj + MLP (+ reduce) of all three levels and iterations; pooling / merge / the 1x1 fuse conv are not in it"}
 
     if rank == 0:
         pairs = (args.global_batch if strong else B * world) * args.steps
@@ -416,17 +500,19 @@ def main():
         out = {
             "metric": "RGB/IR image-pairs/sec (two-stream forward + NMS)", "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "repeats": len(runs), "value_min": round(pairs / max(runs), 2), "value_max": round(pairs / min(runs), 2),
+            "repeats": len(runs), "timed_seconds": round(sum(runs), 3), "value_min": round(pairs / max(runs), 2), "value_max": round(pairs / min(runs), 2),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{yaml_name[:-5]} + DMFF(loops={args.loops}) {args.dtype}, batch {B}/GPU, "
-                                   f"{H}x{W} synthetic RGB/IR pairs, seeded random weights, NMS conf {args.conf} iou {args.iou}",
+            "config": {"workload": workload,
                        "global_batch": args.global_batch if strong else B * world,
                        "local_batches": [D.shard_range(args.global_batch, r, world)[1] - D.shard_range(args.global_batch, r, world)[0]
                                          for r in range(world)] if strong else [B] * world,
                        "parallelism": f"dp{world} (pairs sharded, one all-gather of detections)",
                        "world_size_of_process_group": tdist.get_world_size() if world > 1 else 1,
+                       "rank0_cpu_affinity": affinity,
                        "backend": tdist.get_backend() if world > 1 else None,
                        "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap, "batches_in_flight": pipe.depth, "forced_one_rank_all_gather": bool(pipe.gather and world == 1),
+                       "all_gather": {"steps_per_collective": pipe.group, "bytes_per_rank_per_collective": int(pipe.group_block.numel() * 4) if pipe.group > 1 else int(pipe.group_block.numel() * 4 // max(1, len(pipe.runners))),
+                                      "stream": "own stream behind the group's last NMS"} if pipe.gather else None,
                        "fused_paths": pipe.plans[0].fusion_report()},
             "per_rank_pairs_per_s": {"min": round(min(rank_rates), 2), "max": round(max(rank_rates), 2),
                                      "note": "each rank's own clock around K steps of its shard (value = all ranks, max-over-ranks time)"},
@@ -440,8 +526,10 @@ def main():
                 "tflops": round(sum(v[1] for v in per_kernel.values()) / reps / (fwd_tp_ms * 1e-3) / 1e12, 1),
                 "mfma_frac": round(sum(v[1] for v in per_kernel.values()) / reps / (fwd_tp_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
                 "gbs": round(sum(v[2] for v in per_kernel.values()) / reps / (fwd_tp_ms * 1e-3) / 1e9, 1),
-                "hbm_frac": round(sum(v[2] for v in per_kernel.values()) / reps / (fwd_tp_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+                "hbm_frac": round(sum(v[2] for v in per_kernel.values()) / reps / (fwd_tp_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                "pipe_busy_one_batch_at_a_time": pipe_busy},
             "roofline": roof,
+            "dmff_block": dmff_block,
             "attention_kernel": None if att is None else {
                 "tflops": round(att[1] / (att[0] * 1e-3) / 1e12, 2), "ms_per_step": round(att[0] / reps, 4),
                 "mfma_frac_of_dense_peak": round(att[1] / (att[0] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4)},
@@ -449,6 +537,11 @@ def main():
             "plan_buffer_MB": round(plan.nbytes / 2 ** 20, 1),
             "detections_first_image": int(count.reshape(-1)[0]),
         }
+        if pipe_busy:
+            fr = out["forward_roofline"]
+            fr["valu_issue_frac"] = round(pipe_busy["valu_busy_us"] / pipe_busy["kernel_time_us"], 4)
+            fr["mfma_busy"] = round(pipe_busy["mfma_busy_us"] / pipe_busy["kernel_time_us"], 4)
+            fr["bound"] = binding_roof({"hbm": fr["hbm_frac"], "mfma": fr["mfma_busy"], "valu": fr["valu_issue_frac"]})
         if world == 1 and not args.no_latency:
             # batch-1 latency (detect_twostream.py:83-88 runs forward -> sync -> NMS -> sync per frame pair): one pair, one plan, the
             # hipGraph replay followed by NMS on the same stream, host-synchronised every step; median of 100

@@ -27,6 +27,52 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa(local, world_local, pci_bus_id=None, sysfs="/sys"):
+    """Bind this rank's host threads to the CPUs next to its GPU (one process per GPU on a 256-thread, multi-socket host: a rank whose launch
+    thread wanders to the far socket pays a cross-socket hop per hipGraphLaunch / RCCL proxy wake-up).  The GPU's NUMA node comes from sysfs
+    (`/sys/bus/pci/devices/<bus id>/numa_node` -> `/sys/devices/system/node/node<N>/cpulist`); when the platform does not say (-1, no sysfs,
+    a container without the files) the CPUs this process may use are dealt to the local ranks in equal contiguous slices instead.  Ranks whose
+    GPUs sit on the same node share that node's CPUs.  Returns a dict describing what was done (bench.py logs it)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:                                  # not Linux
+        return {"pinned": False, "reason": "no sched_getaffinity"}
+    info = {"pinned": False, "numa_node": None}
+    cpus = None
+    if pci_bus_id:
+        try:
+            bid = pci_bus_id.lower()
+            if bid.count(":") == 1:
+                bid = "0000:" + bid
+            node = int(open(os.path.join(sysfs, "bus/pci/devices", bid, "numa_node")).read())
+            if node >= 0:
+                node_cpus = _parse_cpulist(open(os.path.join(sysfs, "devices/system/node", f"node{node}", "cpulist")).read()) & set(allowed)
+                if node_cpus:
+                    cpus, info["numa_node"] = sorted(node_cpus), node
+        except (OSError, ValueError):
+            pass
+    if cpus is None:                                        # equal contiguous slices of whatever this process may run on
+        n = len(allowed)
+        cpus = allowed[local * n // world_local:(local + 1) * n // world_local] or allowed
+        info["reason"] = "GPU NUMA node unknown: equal slices of the allowed CPUs"
+    try:
+        os.sched_setaffinity(0, cpus)
+        info.update(pinned=True, cpus=len(cpus), first_cpu=cpus[0], last_cpu=cpus[-1])
+    except OSError as e:
+        info["reason"] = f"sched_setaffinity: {e}"
+    return info
+
+
 def shard_range(global_batch, rank, world):
     """Contiguous split of the global batch; the first (global_batch % world) ranks take one extra pair."""
     base, rem = divmod(global_batch, world)
@@ -70,6 +116,14 @@ def split_block(flat, world, B, max_det):
     i.e. global batch order for contiguous shards (flatten_gathered gives the (world * B, ...) tensors, allocating)."""
     n = B * max_det * 6
     blocks = flat.view(world, n + B)
+    return blocks[:, :n].view(world, B, max_det, 6), blocks[:, n:].view(torch.int32)
+
+
+def split_group_block(flat, world, group, slot, B, max_det):
+    """Views into a gathered GROUP: every rank sent `group` consecutive detection blocks in one collective (DetectionPipeline gathers once per
+    `group` steps), so `flat` is (world, group, block); returns step `slot`'s det (world, B, max_det, 6) fp32 and count (world, B) int32."""
+    n = B * max_det * 6
+    blocks = flat.view(world, group, n + B)[:, slot]
     return blocks[:, :n].view(world, B, max_det, 6), blocks[:, n:].view(torch.int32)
 
 

@@ -807,16 +807,22 @@ def detect_conv(x, w_packed, kp, bias, z, logits, raw, na, no, row_offset, strid
 class NmsRunner:
     """Pre-allocated NMS launch for a fixed (B, rows, nc) — graph-capturable; results stay on the device."""
 
-    def __init__(self, B, rows, nc, device, multi_label=False, max_det=300, want_keep=True):
+    def __init__(self, B, rows, nc, device, multi_label=False, max_det=300, want_keep=True, block=None):
         """want_keep=False skips the kept-index output (torchvision's return value; one more small launch) — the serving
-        pipeline only needs the detection rows."""
+        pipeline only needs the detection rows.  `block`: a flat fp32 tensor of B * max_det * 6 + B elements to use as the detection block
+        (the pipeline lays the blocks of consecutive steps side by side so that ONE collective moves all of them)."""
         self.B, self.rows, self.nc, self.max_det = B, rows, nc, max_det
         self.multi_label = bool(multi_label) and nc > 1
         sz = C.c_size_t(0)
         check(lib().icaf_nms_workspace_bytes(B, rows, nc, int(self.multi_label), C.byref(sz)), "nms_workspace")
         self.ws = torch.empty((max(sz.value, 16),), dtype=torch.uint8, device=device)
         from .dist import detection_block            # det + count in ONE allocation: the block the all-gather sends as it is
-        self.block, self.det, self.count = detection_block(B, max_det, device)
+        if block is None:
+            self.block, self.det, self.count = detection_block(B, max_det, device)
+        else:
+            n = B * max_det * 6
+            assert block.dtype == torch.float32 and block.is_contiguous() and block.numel() == n + B and block.device == torch.device(device)
+            self.block, self.det, self.count = block, block[:n].view(B, max_det, 6), block[n:].view(torch.int32)
         self.keep = torch.zeros((B, max_det), dtype=torch.int32, device=device) if want_keep else None
 
     def launch(self, pred, conf_thres, iou_thres, agnostic=False, classes=None, max_nms=30000, max_wh=4096.0,

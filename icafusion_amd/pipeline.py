@@ -5,7 +5,8 @@ between (detect_twostream.py:83-88, test.py:126-141).  NMS is a latency-bound jo
 image (32 of 256 CUs at batch 32), so here batch i's NMS runs concurrently with batch i+1's forward:
 
     forward stream : graph(i) -> snapshot z(i) -> graph(i+1) -> snapshot z(i+1) -> ...
-    nms stream     :              wait snapshot(i) -> candidates / sort / greedy (i) [-> all_gather(i)] -> ...
+    nms stream     :              wait snapshot(i) -> candidates / sort / greedy (i) -> ...
+    gather stream  :  (N > 1)                 wait the NMS of the group's last batch -> ONE all_gather of the group's detection blocks
 
 With `depth` > 1 (bench default 2) that many batches are in flight: batch n replays plan n % nplans (own buffers, own hipGraph) on
 forward stream n % depth, so the low-occupancy tail of one forward overlaps the full-width layers of the next (+13 % throughput on one
@@ -89,14 +90,26 @@ class DetectionPipeline:
         nslots = 2 if overlap else 1
         rows, no = self.z.shape[1], self.z.shape[2]
         ml = bool(multi_label) and no - 5 > 1
-        self.runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False) for _ in range(nslots)]
-        self.gathered = [torch.empty((world * (batch * max_det * 6 + batch),), dtype=torch.float32, device=self.device)
-                         for _ in range(nslots)] if self.gather else None
+        # The detection blocks of the slots lie SIDE BY SIDE in one allocation: with a process group the all-gather then runs once per GROUP of
+        # steps (one per in-flight slot: `depth` batches with the bench's default pipeline) on a stream of its own behind the group's last NMS —
+        # one latency-bound collective of group x 230 KB instead of `group` of them, and none of them on the NMS stream, where the RCCL kernel
+        # sat between two batches' NMS launches (one GPU, --force-gather: -3.5 % with a gather per step on the NMS stream).
+        blk = batch * max_det * 6 + batch
+        self.group = self.nplans if self.nplans > 1 else 1          # steps per collective (the one-plan pipeline alternates two slots: one step each)
+        nblocks = self.nplans if self.nplans > 1 else nslots
+        self.group_block = torch.zeros((nblocks * blk,), dtype=torch.float32, device=self.device)
+        slot_block = [self.group_block[k * blk:(k + 1) * blk] for k in range(nblocks)]
+        self.runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False, block=slot_block[k] if self.nplans == 1 else None)
+                        for k in range(nslots)]
         if self.nplans > 1:
-            self.deep_runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False) for _ in range(self.nplans)]
+            self.deep_runners = [ops.NmsRunner(batch, rows, no - 5, self.device, ml, max_det, want_keep=False, block=slot_block[k]) for k in range(self.nplans)]
             self.nms_done_deep = [torch.cuda.Event() for _ in range(self.nplans)]
-            self.deep_gathered = [torch.empty((world * (batch * max_det * 6 + batch),), dtype=torch.float32, device=self.device)
-                                  for _ in range(self.nplans)] if self.gather else None
+        # two generations of the gathered buffer: the tensors a step returned stay untouched until the gather AFTER the next one
+        self.gathered = [torch.empty((world * self.group * blk,), dtype=torch.float32, device=self.device) for _ in range(2)] if self.gather else None
+        self.gather_stream = torch.cuda.Stream(device=self.device) if (self.gather and overlap) else self.nms_stream
+        self.gather_done = torch.cuda.Event()
+        self.nms_group_done = torch.cuda.Event()
+        self.gen, self.pending, self.gathers = 0, 0, 0               # generation the NEXT gather writes; steps since the last gather; gathers issued
         self.n = 0
         self.last = None
 
@@ -171,16 +184,42 @@ class DetectionPipeline:
                 self.zbuf[i].copy_(self.z, non_blocking=True)
             self.snap_done[i].record(fs)
             ns.wait_event(self.snap_done[i])
+        if self.gather and self.gathers:
+            ns.wait_event(self.gather_done)                 # the last gather has read this slot's block
         det, count, keep = nms_device(self.zbuf[i], stream_ptr=ns.cuda_stream, runner=self.runners[i], **self.nms_args)
         out = (det[None], count[None])
         if self.gather:
-            with torch.cuda.stream(ns):
-                out = D.gather_detections(det, count, out=self.gathered[i], force_collective=True, block=self.runners[i].block)
+            out = self._gather(self.runners[i].block, 0)
         if self.overlap:
             self.nms_done[i].record(ns)
         self.n += 1
         self.last = out
         return out
+
+    def _gather(self, send, slot):
+        """Step bookkeeping of the collective: returns the (det, count) views of this step inside the generation the NEXT gather writes, and
+        issues that gather when the group is complete (or from synchronize(), for a group cut short).  `send` = what this rank contributes:
+        one slot's block (one-plan pipeline) or the whole group_block."""
+        B, max_det = self.runners[0].B, self.runners[0].max_det
+        out = D.split_group_block(self.gathered[self.gen], self.world if self.world > 1 else 1, self.group, slot, B, max_det)
+        self._send = send
+        self.pending += 1
+        if self.pending >= self.group:
+            self._issue_gather()
+        return out
+
+    def _issue_gather(self):
+        import torch.distributed as tdist
+        ns, gs = self.nms_stream, self.gather_stream
+        if gs is not ns:
+            self.nms_group_done.record(ns)
+            gs.wait_event(self.nms_group_done)              # behind the group's last NMS; the NMS stream itself goes on with the next batch
+        with torch.cuda.stream(gs):
+            tdist.all_gather_into_tensor(self.gathered[self.gen], self._send)
+        self.gather_done.record(gs)
+        self.gen ^= 1
+        self.pending = 0
+        self.gathers += 1
 
     def _step_deep(self):
         """Several plans: batch n runs plan n % nplans on forward stream n % depth (nplans is a multiple of depth: a plan keeps its stream); its NMS reads that plan's z directly (no snapshot: the
@@ -192,20 +231,27 @@ class DetectionPipeline:
         plan.run(fs.cuda_stream)
         self.fwd_done[pi].record(fs)
         ns.wait_event(self.fwd_done[pi])
+        if self.gather and self.gathers and self.pending == 0:
+            ns.wait_event(self.gather_done)                # the last gather has read the blocks this group's NMS launches overwrite
         det, count, keep = nms_device(plan.outputs[0], stream_ptr=ns.cuda_stream, runner=self.deep_runners[pi], **self.nms_args)
         out = (det[None], count[None])
         if self.gather:
-            with torch.cuda.stream(ns):
-                out = D.gather_detections(det, count, out=self.deep_gathered[pi], force_collective=True, block=self.deep_runners[pi].block)
+            out = self._gather(self.group_block, pi)
         self.nms_done_deep[pi].record(ns)
         self.n += 1
         self.last = out
         return out
 
     def synchronize(self):
+        """Everything enqueued so far has finished.  With a process group this also sends a group that is not full yet (every rank has taken
+        the same number of steps, so every rank issues the same collectives)."""
+        if self.gather and self.pending:
+            self._issue_gather()
         for fs in self.fwd_streams:
             fs.synchronize()
         self.nms_stream.synchronize()
+        if self.gather_stream is not self.nms_stream:
+            self.gather_stream.synchronize()
 
     def __call__(self, rgb, ir):
         """Convenience: copy one batch in, run it, wait, return list of (n, 6) detections per image (all ranks' images, global order)."""

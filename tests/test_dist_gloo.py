@@ -36,6 +36,20 @@ def _worker(rank, world, port, q):
     out = torch.empty((world * block.numel(),))
     det2, cnt2 = D.gather_detections(d, c, out=out, block=block)
     ok = ok and det2.data_ptr() == out.data_ptr() and all(torch.equal(x, y) for x, y in zip(D.flatten_gathered(det2, cnt2), (det_all, cnt_all)))
+    # the pipeline's grouped form: the blocks of `group` consecutive steps lie side by side and travel in ONE collective (DetectionPipeline._issue_gather)
+    group, Bl = 3, b - a
+    blk = Bl * max_det * 6 + Bl
+    gblock = torch.zeros((group * blk,))
+    for sidx in range(group):
+        _, d_s, c_s = None, gblock[sidx * blk:sidx * blk + Bl * max_det * 6].view(Bl, max_det, 6), gblock[sidx * blk + Bl * max_det * 6:(sidx + 1) * blk].view(torch.int32)
+        d_s.copy_(det_all[a:b] + 10.0 * sidx); c_s.copy_((cnt_all[a:b] + sidx) % (max_det + 1))
+    gout = torch.empty((world * group * blk,))
+    torch.distributed.all_gather_into_tensor(gout, gblock)
+    for sidx in range(group):
+        dg, cg = D.split_group_block(gout, world, group, sidx, Bl, max_det)
+        df, cf = D.flatten_gathered(dg, cg)
+        ok = ok and dg.shape == (world, Bl, max_det, 6) and cg.dtype == torch.int32 and torch.equal(df, det_all + 10.0 * sidx) \
+            and torch.equal(cf, (cnt_all + sidx) % (max_det + 1))
     q.put((rank, ok, (a, b)))
     torch.distributed.destroy_process_group()
 

@@ -1,7 +1,7 @@
 """BASELINE.json's configurations at FULL size on the MI355X, checked through size-independent properties (the CPU oracle
 would need minutes per batch here): every kernel on the path is per-sample, so a batch must equal its sub-batches bit
 for bit whatever tiles / kernels the shapes select; NMS output must be sorted, within bounds and idempotent; and a small
-slice of each full-size batch is still compared with the oracle."""
+slice (two images) of each full-size batch is compared with the oracle on the fp32 build (configs 2 / 3 / 4 / 5)."""
 import numpy as np
 import pytest
 import torch
@@ -86,6 +86,35 @@ def test_config4_s_512x640_loops3_b64_and_oracle_slice():
     for d, r in zip(dets, oracle.non_max_suppression(z[:2].cpu().numpy(), 0.25, 0.45)):
         np.testing.assert_array_equal(d.cpu().numpy(), r)           # bit-exact keep set on the same predictions
     check_nms_properties(z, 0.001, 0.5)
+
+
+def oracle_slice(yaml_name, B, H, W, seed, conf, iou, lo=0, n=2, multi_label=False):
+    """The fp32 build at the configuration's FULL batch size against the CPU oracle on images [lo, lo + n): north_star's fp32 1e-3 (relative to the
+    largest prediction), and NMS keep sets bit-exact on the same predictions.  The full batch matters: tile choices, grid sizes and the persistent
+    kernels' walks depend on it, and a slice equal to the oracle means every one of them placed those images' rows correctly."""
+    cfg, sd, m = build(yaml_name, torch.float32, seed=seed)
+    rgb, ir = synth_images(B, H, W, seed=seed)
+    z = m(rgb.to(DEV), ir.to(DEV))[0]
+    assert torch.isfinite(z).all()
+    ref = oracle.OracleModel(cfg, sd).forward(rgb[lo:lo + n], ir[lo:lo + n])[0]
+    err = (z[lo:lo + n].cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-3, err                               # north_star: fp32 1e-3
+    dets = non_max_suppression(z[lo:lo + n], conf, iou, multi_label=multi_label)
+    for d, r in zip(dets, oracle.non_max_suppression(z[lo:lo + n].cpu().numpy(), conf, iou, multi_label=multi_label)):
+        np.testing.assert_array_equal(d.cpu().numpy(), r)
+    return err
+
+
+def test_config2_s_b32_640_fp32_oracle_slice():
+    oracle_slice("yolov5s_Transfusion_kaist.yaml", 32, 640, 640, seed=12, conf=0.25, iou=0.45, lo=30)
+
+
+def test_config3_l_b32_640_fp32_oracle_slice():
+    oracle_slice("yolov5l_Transfusion_kaist.yaml", 32, 640, 640, seed=13, conf=0.25, iou=0.45, lo=17)
+
+
+def test_config5_l_vedai_1280_b16_fp32_oracle_slice():
+    oracle_slice("yolov5l_Transfusion_VEDAI.yaml", 16, 1280, 1280, seed=15, conf=0.3, iou=0.5, lo=14, multi_label=True)
 
 
 def test_config5_l_vedai_f16_1280_b16_multilabel():

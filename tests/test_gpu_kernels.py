@@ -1454,7 +1454,7 @@ def test_nms_greedy_core_against_torchvision_if_the_box_has_it():
         import torchvision                                          # noqa: F401
         from torchvision.ops import nms as tv_nms
         rec.update(torchvision_present=True, version=torchvision.__version__)
-    except Exception as e:                                          # absent (or unusable) on this image: recorded, not skipped
+    except Exception as e:                                          # absent (or unusable) on this image: recorded, then skipped (below)
         rec["import_error"] = f"{type(e).__name__}: {e}"[:200]
         tv_nms = None
     if tv_nms is not None:
@@ -1485,4 +1485,6 @@ def test_nms_greedy_core_against_torchvision_if_the_box_has_it():
     with open(os.path.join(out, "torchvision_probe.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec))
-    assert rec["all_equal"] is not False
+    if tv_nms is None:                                              # nothing was compared: a SKIP in the record of the run, not a pass
+        pytest.skip(f"torchvision is absent on this box ({rec.get('import_error')}): the greedy core stays parity-unpinned (finding written to {out}/torchvision_probe.json)")
+    assert rec["all_equal"] is True

@@ -162,31 +162,51 @@ m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 0)); m = m.to("cuda
 B, H, W = 4, 320, 320
 pipe = DetectionPipeline(m, B, H, W, "cuda:0", conf_thres=0.1, iou_thres=0.5, world=1, overlap=True, force_gather=True, depth={depth})
 runners = pipe.deep_runners if pipe.depth > 1 else pipe.runners            # the slot step k used
-gathered = pipe.deep_gathered if pipe.depth > 1 else pipe.gathered
-outs = []
-for k in range(4):
+blk = B * 300 * 6 + B
+assert pipe.group == (pipe.depth if pipe.depth > 1 else 1) and pipe.gather_stream is not pipe.nms_stream
+outs, clones = [], []
+def feed(k):
     rgb, ir = synth_images(B, H, W, seed=70 + k)
     pipe.inputs[0].copy_(rgb.cuda()); pipe.inputs[1].copy_(ir.cuda()); torch.cuda.current_stream().synchronize()
+# pass 1: synchronised after every step (a group cut short is sent by synchronize())
+for k in range(4):
+    feed(k)
+    gen = pipe.gen
     outs.append(pipe.step())
     pipe.synchronize()
     det_all, count_all = outs[-1]
-    det, count = runners[k % len(runners)].det, runners[k % len(runners)].count
+    r = runners[k % len(runners)]
     assert det_all.shape == (1, B, 300, 6) and count_all.shape == (1, B) and count_all.dtype == torch.int32
-    assert torch.equal(det_all[0], det) and torch.equal(count_all[0], count), "all-gather of one rank must return that rank's block"
-    assert det.data_ptr() == runners[k % len(runners)].block.data_ptr()     # NMS wrote into the block that travelled: no packing step
-    assert int(count.sum()) > 0
-    assert det_all.data_ptr() == gathered[k % len(gathered)].data_ptr()     # the collective wrote the pipeline's gathered buffer
+    assert torch.equal(det_all[0], r.det) and torch.equal(count_all[0], r.count), "all-gather of one rank must return that rank's block"
+    assert r.det.data_ptr() == r.block.data_ptr()                              # NMS wrote into the block that travelled: no packing step
+    slot = k % pipe.group
+    assert r.block.data_ptr() == pipe.group_block.data_ptr() + 4 * blk * (k % len(runners))     # the slots' blocks lie side by side
+    assert int(r.count.sum()) > 0
+    assert det_all.data_ptr() == pipe.gathered[gen].data_ptr() + 4 * blk * slot   # the collective wrote the pipeline's gathered buffer
+    clones.append((det_all.clone(), count_all.clone()))
+g0 = pipe.gathers
+assert g0 == 4
+# pass 2: the same four batches with no synchronisation in between: ONE collective per group of `group` steps, on the gather stream
+outs2 = []
+for k in range(4):
+    feed(k)
+    outs2.append(pipe.step())
+pipe.synchronize()
+assert pipe.gathers - g0 == 4 // pipe.group
+for k in range(4):
+    if k >= 4 - 2 * pipe.group:                     # (two generations of the gathered buffer: the last two groups are still intact)
+        assert torch.equal(outs2[k][0], clones[k][0]) and torch.equal(outs2[k][1], clones[k][1]), k
 dist.barrier(); dist.destroy_process_group()
 print("RCCL_WORLD1_OK", [int(c.sum()) for _, c in outs])
 '''
 
 
 @pytest.mark.parametrize("depth", [1, 2])
-def test_rccl_all_gather_runs_on_the_nms_stream_with_one_rank(depth):
-    """`nccl` (= RCCL) process group of world size 1: DetectionPipeline(force_gather=True) sends every step's detection block
-    through dist.all_gather_into_tensor on the NMS stream — the collective, its stream ordering against the NMS kernels and
-    the gathered buffers run on hardware although no second GPU exists (a subprocess: it owns the process group).  depth = 2 is
-    what `bench.py --gpus N` runs: two batches in flight, each with its own gathered block."""
+def test_rccl_all_gather_runs_on_its_own_stream_with_one_rank(depth):
+    """`nccl` (= RCCL) process group of world size 1: DetectionPipeline(force_gather=True) sends the detection blocks through
+    dist.all_gather_into_tensor — ONE collective per group of `depth` steps on the gather stream, behind the group's last NMS; the
+    collective, its stream ordering against the NMS kernels and the two generations of gathered buffers run on hardware although no
+    second GPU exists (a subprocess: it owns the process group).  depth = 2 is what `bench.py --gpus N` runs."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT.format(repo=REPO, depth=depth)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -304,3 +304,33 @@ def test_isa_mix_splits_kernels_and_classifies_instructions(tmp_path):
     got = m.kernels_of(str(asm))
     assert list(got) == ["k1"]
     assert dict(got["k1"]) == {"salu": 4, "waitcnt": 1, "trans": 2, "mfma": 1, "lds": 1, "vmem": 1, "barrier": 1, "valu": 1}
+
+
+def test_rank_cpu_affinity_follows_the_gpus_numa_node(tmp_path):
+    """dist.pin_to_gpu_numa (bench.py, N > 1): the CPUs of the GPU's NUMA node as sysfs reports them; equal contiguous slices of the allowed CPUs
+    when the platform does not say.  Runs in a child process: the affinity of the test runner is left alone."""
+    import subprocess
+    import sys
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip("needs two CPUs")
+    half = allowed[:len(allowed) // 2]
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text(f"{half[0]}-{half[-1]}\n")
+    unknown = tmp_path / "bus" / "pci" / "devices" / "0000:c2:00.0"
+    unknown.mkdir(parents=True)
+    (unknown / "numa_node").write_text("-1\n")
+    code = ("import json, os, sys; sys.path.insert(0, %r); from icafusion_amd import dist as D\n"
+            "a = D.pin_to_gpu_numa(0, 2, 'C1:00.0', sysfs=%r); ca = sorted(os.sched_getaffinity(0))\n"
+            "os.sched_setaffinity(0, %r)\n"
+            "b = D.pin_to_gpu_numa(1, 2, '0000:c2:00.0', sysfs=%r); cb = sorted(os.sched_getaffinity(0))\n"
+            "print(json.dumps([a, ca, b, cb]))") % (REPO, str(tmp_path), allowed, str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True)
+    import json
+    a, ca, b, cb = json.loads(r.stdout.strip().splitlines()[-1])
+    assert a["pinned"] and a["numa_node"] == 1 and ca == [c for c in half if c in allowed]
+    assert b["pinned"] and b["numa_node"] is None and cb == allowed[len(allowed) // 2:]

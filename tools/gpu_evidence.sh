@@ -9,7 +9,8 @@
 #   2. the bench line (with cpu_baseline and h2d_feed for the default workload);
 #   3. rocprofv3 --kernel-trace --stats of the same command; for the default workload also a DEPTH-1 trace (one batch at a time: its per-kernel averages are what
 #      roofline.avg_launch_us reports — the default trace is of the overlapped run);
-#   4. SQ=1 (default for `default` and c3): the SQ passes (MFMA busy + instruction mix, tools/gpu_pmc_sq.sh);
+#   4. SQ=1 (default): the SQ passes (MFMA busy, VALU issue, wave-parked fractions, instruction mix: tools/gpu_pmc_sq.sh) BEFORE the bench line, installed as
+#      profiles/pmc_sq*.json like the traffic passes, so that the line's roofline names the roof that binds from counters of the same call;
 #   5. default only: the per-layer profiles (fused and per-layer DMFF); PARITY=1: the 16-bit parity table with the small-object mAP recipe (tools/parity16.py).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
@@ -38,11 +39,10 @@ trace () {   # name, bench args ...: kernel stats of the bench command
   f=$(find /tmp/icaf_raw/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/prof_${name}_kernel_stats.csv && cut -c1-140 "$f" | sed -n 2,4p
   cd $R
 }
-sq () {      # suffix, bench args ...
+sq () {      # suffix ("" = default workload), bench args ...: both SQ passes, merged and installed as profiles/pmc_sq<_suffix>.json for the bench line that follows
   suf=$1; shift
-  cd $R && SQ_INSTS=1 bash tools/gpu_pmc_sq.sh "$@" > gpurun_out/pmc_sq_$suf.log 2>&1
-  cp gpurun_out/pmc_sq_summary.json gpurun_out/pmc_sq_summary_$suf.json; cp gpurun_out/pmc_sq_insts.json gpurun_out/pmc_sq_insts_$suf.json
-  grep "dmff\|cross_att\|stem\|ceiling" gpurun_out/pmc_sq_$suf.log | head -16
+  cd $R && SQ_INSTS=1 PMC_NAME=$suf bash tools/gpu_pmc_sq.sh "$@" > gpurun_out/pmc_sq_${suf:-default}.log 2>&1
+  grep "dmff\|cross_att\|stem\|sq summary" gpurun_out/pmc_sq_${suf:-default}.log | head -16
 }
 for w in $WORKLOADS; do
   case "$w" in
@@ -54,7 +54,7 @@ for w in $WORKLOADS; do
   esac
   if [ -z "$name" ]; then
     cd $R && bash tools/gpu_pmc.sh 2>&1 | tail -2
-    [ "${SQ:-1}" = 1 ] && sq default
+    [ "${SQ:-1}" = 1 ] && sq ""
     cd $R && timeout 900 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; line default gpurun_out/bench.json
     trace default
     trace depth1 --depth 1 --no-overlap
@@ -65,12 +65,12 @@ for w in $WORKLOADS; do
     cp $R/profiles/tune_cache_$name.json /tmp/tune_$name.json       # (a re-tune inside the call edits the copy; it is brought back as gpurun_out/tune_cache_<name>.json)
     ARGS="$ARGS --tune-cache /tmp/tune_$name.json"
     cd $R && PMC_NAME=$name bash tools/gpu_pmc.sh $ARGS 2>&1 | tail -1
-    cd $R && timeout 900 python bench.py --no-cpu-baseline $ARGS > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err; line $name gpurun_out/bench_$name.json
+    [ "${SQ:-1}" = 1 ] && sq $name $ARGS
+    cd $R && timeout 1200 python bench.py $ARGS > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err; line $name gpurun_out/bench_$name.json
     trace $name $ARGS
-    { [ "$w" = c3 ] && [ "${SQ:-1}" = 1 ]; } && sq c3 $ARGS
     if [ "$w" = c3 ] && [ "$PERS_SQ" = 1 ]; then      # the persistent long-K GEMM (opt-in, launch configuration 67) under the same counters: its own retuned cache copy
       cp $R/profiles/tune_cache_$name.json /tmp/tune_pers.json
-      ICAF_PERS_GEMM=1 ICAF_RETUNE_TILES=67 sq c3_pers --model l --batch 32 --tune-cache /tmp/tune_pers.json
+      ICAF_PERS_GEMM=1 ICAF_RETUNE_TILES=67 sq c3_pers --model l --batch 32 --tune-cache /tmp/tune_pers.json; rm -f profiles/pmc_sq_c3_pers.json
     fi
     cp /tmp/tune_$name.json gpurun_out/tune_cache_$name.json
   fi

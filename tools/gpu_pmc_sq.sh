@@ -2,11 +2,14 @@
 # MFMA-pipe utilisation per kernel from the SQ counters (one pass): SQ_VALU_MFMA_BUSY_CYCLES counts busy cycles summed
 # over all SIMDs, SQ_BUSY_CYCLES the kernel's busy cycles summed over the 32 shader engines (MI355X_MICROARCH.md).
 #   util = MFMA_BUSY / (SQ_BUSY / 32 * 1024 SIMDs)
+# PMC_NAME=<suffix>: the merged summary of both passes (with the bench line's `workload` string) is written to gpurun_out/pmc_sq_merged<_suffix>.json AND installed
+# as profiles/pmc_sq<_suffix>.json in the box's copy, so that a bench.py run later in the same call carries roofline.valu_issue_frac / mfma_busy / wave_wait_frac.
 mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+SUF=${PMC_NAME:+_$PMC_NAME}
 cd /tmp && export TMPDIR=/tmp
 RAW=/tmp/icaf_raw; mkdir -p $RAW
-rm -rf $RAW/pmc_sq
+rm -rf $RAW/pmc_sq; rm -f $R/gpurun_out/pmc_sq_summary.json $R/gpurun_out/pmc_sq_insts.json
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $RAW/pmc_sq -o pmc -- \
     python $R/bench.py --no-cpu-baseline --no-latency --no-h2d --no-graph --no-overlap --depth 1 --steps 3 --warmup 1 --repeats 1 "$@" > $R/gpurun_out/pmc_sq.json 2> $R/gpurun_out/pmc_sq.err
 tail -2 $R/gpurun_out/pmc_sq.err
@@ -63,3 +66,20 @@ json.dump({"method": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_util"]): print(f"{k:42s} valu/mfma {v['valu_per_mfma']} mfma {v['mfma_util']} valu_issue {v['valu_issue_frac']} ceiling {v['mfma_util_ceiling_if_valu_fully_overlapped']}")
 PY
 fi
+cd $R && python - "$SUF" <<'PY'
+import json, os, sys
+suf = sys.argv[1]
+a = json.load(open("gpurun_out/pmc_sq_summary.json"))
+b = json.load(open("gpurun_out/pmc_sq_insts.json")) if os.path.exists("gpurun_out/pmc_sq_insts.json") else {"kernels": {}, "method": ""}
+try:
+    w = json.load(open("gpurun_out/pmc_sq.json"))["config"]["workload"]
+except Exception:
+    w = None
+k = {}
+for name in sorted(set(a["kernels"]) | set(b["kernels"])):
+    k[name] = dict(b["kernels"].get(name, {}), **a["kernels"].get(name, {}))
+out = {"workload": w, "method": [a["method"], b["method"]], "kernels": k}
+json.dump(out, open(f"gpurun_out/pmc_sq_merged{suf}.json", "w"), indent=1, sort_keys=True)
+json.dump(out, open(f"profiles/pmc_sq{suf}.json", "w"), indent=1, sort_keys=True)
+print("sq summary for:", w)
+PY
