@@ -228,14 +228,10 @@ def h2d_feed(model, args, B, H, W, dev):
     # the copy alone (no forward behind it): what the link gives this buffer size
     cs = torch.cuda.Stream(device=dev)
     dst = pipe.plans[0].inputs[0]
-    from icafusion_amd import ops, pipeline as P
 
     def copy(k):
-        if P.FEED_WGS > 0:
-            ops.feed_copy(host[k % nbuf], dst, cs.cuda_stream, P.FEED_WGS)
-        else:
-            with torch.cuda.stream(cs):
-                dst.copy_(host[k % nbuf], non_blocking=True)
+        with torch.cuda.stream(cs):
+            dst.copy_(host[k % nbuf], non_blocking=True)
     copy(0)
     cs.synchronize()
     t0 = time.perf_counter()
@@ -248,7 +244,7 @@ def h2d_feed(model, args, B, H, W, dev):
     return {"pairs_per_s_with_h2d": round(rate, 2), "min": round(min(rates), 2), "max": round(max(rates), 2),
             "host_bytes_per_batch": nbytes, "pcie_gbs_achieved_in_loop": round(rate / B * nbytes / 1e9, 2),
             "pcie_gbs_copy_alone": round(nbytes / copy_s / 1e9, 2), "copy_alone_ms_per_batch": round(1e3 * copy_s, 3),
-            "feed": f"icaf_feed_copy, {P.FEED_WGS} workgroups" if P.FEED_WGS > 0 else "DMA engine (Tensor.copy_)",
+            "feed": "DMA engine (Tensor.copy_)",
             "streams": {"forward": [st.stream_id for st in pipe.fwd_streams], "nms": pipe.nms_stream.stream_id, "copy": [st.stream_id for st in pipe.copy_streams]},
             "note": f"pinned host uint8 (B,6,H,W) -> ONE copy on a high-priority copy stream straight into the input buffer of one of {pipe.nplans} plans "
                     f"(the one not in flight), {pipe.depth} batch(es) in flight, {nbuf} rotating host buffers; "
@@ -263,6 +259,7 @@ def main():
         sys.exit(dry_run(args))
     from icafusion_amd import dist as D
     from icafusion_amd import ops
+    from icafusion_amd.options import OPT
     from icafusion_amd.models.yolo import Model
     from icafusion_amd.synth import synth_images, synth_state_dict
     from icafusion_amd.pipeline import DetectionPipeline
@@ -513,7 +510,8 @@ def main():
                        "graph": not args.no_graph, "nms_overlapped_with_next_forward": not args.no_overlap, "batches_in_flight": pipe.depth, "forced_one_rank_all_gather": bool(pipe.gather and world == 1),
                        "all_gather": {"steps_per_collective": pipe.group, "bytes_per_rank_per_collective": int(pipe.group_block.numel() * 4) if pipe.group > 1 else int(pipe.group_block.numel() * 4 // max(1, len(pipe.runners))),
                                       "stream": "own stream behind the group's last NMS"} if pipe.gather else None,
-                       "fused_paths": pipe.plans[0].fusion_report()},
+                       "fused_paths": pipe.plans[0].fusion_report(),
+                       "plan_options": OPT.as_dict(), "plan_options_not_default": OPT.non_default()},
             "per_rank_pairs_per_s": {"min": round(min(rank_rates), 2), "max": round(max(rank_rates), 2),
                                      "note": "each rank's own clock around K steps of its shard (value = all ranks, max-over-ranks time)"},
             "forward_only_pairs_per_s": round(B / (fwd_tp_ms * 1e-3), 2),       # same batches-in-flight as `value`, no NMS

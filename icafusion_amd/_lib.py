@@ -73,11 +73,11 @@ _p, _i, _ll, _f, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 # symbol -> (restype, argtypes); must list every function declared in include/icaf.h
 SIGNATURES = {
     "icaf_last_error": (C.c_char_p, []),
+    "icaf_set_option": (_i, [C.c_char_p, _i]),
     "icaf_version": (_i, []),
     "icaf_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "icaf_preprocess_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "icaf_preprocess_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "icaf_feed_copy": (_i, [_p, _p, _ll, _i, _p]),
     "icaf_stem": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _p]),
     "icaf_stem2": (_i, [C.POINTER(Stem2Args), _p]),
     "icaf_conv2d": (_i, [C.POINTER(ConvArgs), _p]),
@@ -137,6 +137,10 @@ def lib():
             except AttributeError as e:
                 raise IcafError(f"libicaf.so does not export {name}; rebuild it") from e
             fn.restype, fn.argtypes = res, args
+        from .options import OPT                       # the library's probe knobs come from the one options object, not from its environment
+        for name, value in OPT.lib_options().items():
+            if handle.icaf_set_option(name.encode(), int(value)) != 0:
+                raise IcafError(f"icaf_set_option({name}): {handle.icaf_last_error().decode()}")
         _LIB = handle
     return _LIB
 

@@ -30,7 +30,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=
           "-Rpass-analysis=kernel-resource-usage"]
 RESOURCES = os.path.join(LIBDIR, "kernel_resources.json")
 # kernels whose K loops use counted vmcnt waits: any scratch use (spill) would race with them
-NO_SCRATCH = re.compile(r"cstream_kernel|cwide_kernel|cwpers_kernel|detect_conv_kernel|igemm_dma_kernel|igemm_stream_kernel|igemm_wreg_kernel|igemm_pers_kernel|ctile_kernel|bneck_kernel|stem_kernel|stem2_kernel|dmff_\w*kernel")
+NO_SCRATCH = re.compile(r"cstream_kernel|cwide_kernel|detect_conv_kernel|igemm_dma_kernel|igemm_stream_kernel|igemm_wreg_kernel|ctile_kernel|bneck_kernel|stem_kernel|stem2_kernel|dmff_\w*kernel")
 _REMARK = re.compile(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|"
                      r"LDS Size \[bytes/block\]|VGPRs Spill|SGPRs Spill):\s+(\S+)")
 
@@ -61,10 +61,9 @@ VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 PER_FILE = {"detect.hip": ["-ffp-contract=off"], "nms.hip": ["-ffp-contract=off"],
             "dmff.hip": VGPR_FORM, "dmff_fused.hip": VGPR_FORM}
 _VF = os.environ.get("ICAF_VGPR_FORM", "")             # A/B builds (tools/build_variant.py): "all" = the whole library in that form, "none" = no file
-if _VF == "all":
+if _VF == "all":                                       # (the file list IS the source directory: a new .hip file is never left out)
     PER_FILE = {f: [x for x in PER_FILE.get(f, []) if x not in VGPR_FORM] + VGPR_FORM
-                for f in ("api.hip", "cstream.hip", "ctile.hip", "cwide.hip", "cwpers.hip", "detect.hip", "dmff.hip", "dmff_fused.hip", "dmff_wide.hip",
-                          "igemm.hip", "igemm_stream.hip", "igemm_wreg.hip", "nms.hip", "pool.hip", "stem.hip")}
+                for f in sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))}
 elif _VF == "none":
     PER_FILE = {f: [x for x in v if x not in VGPR_FORM] for f, v in PER_FILE.items()}
 EXPORT = "-fvisibility=default"
@@ -89,6 +88,20 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+_CC_ID = {}
+
+
+def compiler_id(cc):
+    """`hipcc --version` (compiler + ROCm release): part of every object's cache key, so that a compiler upgrade — or another HIPCC — never reuses
+    stale objects and their cached register / scratch report (which gates the NO_SCRATCH check)."""
+    if cc not in _CC_ID:
+        try:
+            _CC_ID[cc] = subprocess.run([cc, "--version"], capture_output=True, text=True, check=True).stdout.strip()
+        except Exception as e:
+            _CC_ID[cc] = f"{cc}: {e}"
+    return _CC_ID[cc]
+
+
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -96,7 +109,7 @@ def build(force=False, verbose=True):
     headers.append(os.path.join(os.path.dirname(HERE), "include", "icaf.h"))
     srcs = sources()
     stamp = LIB[:-3] + ".stamp"
-    want = _digest([os.path.join(CSRC, s) for s in srcs] + headers, " ".join(COMMON) + repr(sorted(PER_FILE.items())))
+    want = _digest([os.path.join(CSRC, s) for s in srcs] + headers, " ".join(COMMON) + repr(sorted(PER_FILE.items())) + compiler_id(hipcc()))
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         if verbose:
             print(f"[icafusion_amd.build] {LIB} is up to date")
@@ -110,7 +123,7 @@ def build(force=False, verbose=True):
               ["-c", os.path.join(CSRC, src), "-o", obj]
         # per-object cache: an object is reused when its source, every header and its flags are unchanged (a kernel iteration recompiles ONE
         # file instead of fifteen: 20-200 s instead of 3.5 min); the resource remarks of the compile are kept beside it
-        key = _digest([os.path.join(CSRC, src)] + headers, " ".join(cmd[1:]))
+        key = _digest([os.path.join(CSRC, src)] + headers, " ".join(cmd[1:]) + "\n" + compiler_id(cc))
         keyf, resf = obj[:-2] + ".key", obj[:-2] + ".res.json"
         if not force and os.path.exists(obj) and os.path.exists(keyf) and os.path.exists(resf) and open(keyf).read().strip() == key:
             return obj, json.load(open(resf))

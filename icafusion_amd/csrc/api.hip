@@ -16,11 +16,23 @@ int fail(int code, const char* fmt, ...) {
     last_error() = buf;
     return code;
 }
+// Probe knobs of the library (icaf.h: icaf_set_option).  The C side reads NO environment variable: the host's one options object
+// (icafusion_amd/options.py) pushes them when the library is loaded.
+LibOptions g_opt;
 }  // namespace icaf
 
 using namespace icaf;
 
 extern "C" const char* icaf_last_error(void) { return last_error().c_str(); }
+
+extern "C" int icaf_set_option(const char* name, int value) {
+    if (!name) return fail(ICAF_ERR_ARG, "icaf_set_option: null name");
+    if (!strcmp(name, "detect_elementwise")) g_opt.detect_elementwise = value;
+    else if (!strcmp(name, "attn_qsplit")) g_opt.attn_qsplit = value;
+    else if (!strcmp(name, "sppf_vpb")) g_opt.sppf_vpb = value;
+    else return fail(ICAF_ERR_ARG, "icaf_set_option: unknown option '%s' (detect_elementwise, attn_qsplit, sppf_vpb)", name);
+    return ICAF_OK;
+}
 extern "C" int icaf_version(void) { return 100; }
 
 extern "C" int icaf_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len) {

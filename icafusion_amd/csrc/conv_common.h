@@ -195,7 +195,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[WN / 32][WM / 32], unsign
         // different instantiations (tiles) fused these products differently, so the same layer rounded differently from one
         // tile shape to the next and a batch shard stopped being bit-identical to the same rows of the full batch.  (Writing
         // the fmas out with __builtin_fmaf instead produced a 128x64 / 64-byte-pipeline kernel with wrong, run-to-run
-        // varying results at large grids — tools/probes/pre_check.py.)
+        // varying results at large grids — lab/probes/pre_check.py.)
 #pragma clang fp contract(off)
         const float sy = (float)p.pre_h / (float)p.Ho, sx = (float)p.pre_w / (float)p.Wo;
 #pragma unroll

@@ -4,7 +4,7 @@
 //   y  = alpha_res * res + SiLU(conv3x3(x) + bias)                       [+ chained 1x1:  y2 = SiLU(W2 . y + bias2)]
 //
 // These layers move 157 MB (batch 32, both backbones) for 30 GFLOP: they are HBM-bound streaming jobs, and both existing kernels run
-// them at 2x the memory floor for a different reason each (measured by ablation, tools/probes/abl_ctile.sh):
+// them at 2x the memory floor for a different reason each (measured by ablation, lab/probes/abl_ctile.sh):
 //   * igemm.hip / igemm_stream.hip gather the 3x3 window by LDS-DMA — nine times the tensor through the CU's vector-memory port,
 //     whose ~10 TB/s (whole chip) is what bounds them;
 //   * ctile.hip fetches a halo patch once (1.4x), but a workgroup's life is load patch -> wait -> K loop with a weight ring and a

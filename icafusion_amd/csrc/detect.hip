@@ -242,7 +242,7 @@ extern "C" int icaf_detect_decode(const float* p, int ldp, float* z, float* logi
     if (B < 1 || ny < 1 || nx < 1) return fail(ICAF_ERR_ARG, "icaf_detect_decode: empty level");
     // per-pixel kernel: 3 anchors, even `no` in use, 8-byte aligned pixel runs and output rows
     const bool aligned = ldp % 2 == 0 && ((uintptr_t)p & 7) == 0 && ((uintptr_t)z & 7) == 0 && (!raw || ((uintptr_t)raw & 7) == 0);
-    if (na == 3 && aligned && (long long)B * ny * nx < (1ll << 31) && !getenv("ICAF_DETECT_ELEMENTWISE")) {
+    if (na == 3 && aligned && (long long)B * ny * nx < (1ll << 31) && !g_opt.detect_elementwise) {
         if (no == 6) return launch_detect_pixel<3, 6>(p, ldp, z, logits, raw, B, ny, nx, rows_total, row_offset, stride, anc, S(s));
         if (no == 8) return launch_detect_pixel<3, 8>(p, ldp, z, logits, raw, B, ny, nx, rows_total, row_offset, stride, anc, S(s));
         if (no == 14) return launch_detect_pixel<3, 14>(p, ldp, z, logits, raw, B, ny, nx, rows_total, row_offset, stride, anc, S(s));

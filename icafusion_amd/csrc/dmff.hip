@@ -488,8 +488,8 @@ static int launch_attn(const void* qkv, void* out, int B, int N, int C, int DK, 
     const long long wgs1 = (long long)2 * B * heads;                  // workgroups with one split
     if (wgs1 * qsplit < 512) qsplit = (int)((512 + wgs1 - 1) / wgs1);
     if (qsplit > qs_max) qsplit = qs_max;
-    {   // A/B switch (timing studies): ICAF_ATTN_QSPLIT=n forces n query splits per head (1 = a workgroup stages a head's K / V^T once for ALL its query tiles)
-        static const int forced = [] { const char* e = getenv("ICAF_ATTN_QSPLIT"); return e ? atoi(e) : 0; }();
+    {   // A/B switch (timing studies): icaf_set_option("attn_qsplit", n) forces n query splits per head (1 = a workgroup stages a head's K / V^T once for ALL its query tiles)
+        const int forced = g_opt.attn_qsplit;
         if (forced > 0) qsplit = forced < nqt ? forced : nqt;
     }
     const float scale_l2e = (float)((1.0 / sqrt((double)DK)) * 1.4426950408889634);

@@ -41,7 +41,7 @@ struct DmffP {
     int B, N, C, heads, dk, Kp, Kp4, hid, ldy;
     float eps_a, eps_m, scale_l2e;
     float c_res_a[2], c_acc_a[2], c_res_m[2], c_acc_m[2];
-    long long* dbg;           // optional: workgroup (0, 0, 0) records s_memtime at its phase boundaries (tools/probes/dmff_phases.py)
+    long long* dbg;           // optional: workgroup (0, 0, 0) records s_memtime at its phase boundaries (lab/probes/dmff_phases.py)
 };
 
 constexpr int FT = 256;              // threads per workgroup (4 wavefronts)

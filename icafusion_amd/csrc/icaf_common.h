@@ -13,6 +13,9 @@ namespace icaf {
 // ---- error plumbing -------------------------------------------------------------------------------------
 std::string& last_error();
 int fail(int code, const char* fmt, ...);
+// probe knobs set through icaf_set_option (api.hip); 0 = the library's own choice
+struct LibOptions { int detect_elementwise = 0, attn_qsplit = 0, sppf_vpb = 0; };
+extern LibOptions g_opt;
 
 #define ICAF_HIP(expr)                                                                        \
     do {                                                                                      \

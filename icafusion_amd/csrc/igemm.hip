@@ -33,7 +33,7 @@ namespace icaf {
 
 // RB = bytes of K per LDS row per slice (64 or 128), NS = ring depth.  With RB = 128 every DMA lane group fetches a
 // whole 128-byte cache line of one pixel / weight row: the LDS-DMA feed rate from L2 measured on MI355X is 14-21 TB/s
-// for full lines against 8 TB/s for 64-byte half lines (tools/probes/dma_bw_probe.hip), and that feed rate — not the
+// for full lines against 8 TB/s for 64-byte half lines (lab/probes/dma_bw_probe.hip), and that feed rate — not the
 // MFMA pipe — is what bounds these small-tile GEMMs.
 // MODE selects the pixel-operand address generator (the K order, hence the result, is the same for all three):
 //   0  generic: every lane walks its own (ky, kx, cin) position — needed when a K slice straddles filter taps
@@ -462,26 +462,18 @@ int launch_cstream(const icaf_conv_args* a, const ConvP& p, hipStream_t s);
 int cwide_check(const icaf_conv_args* a, const ConvP& p, int shape);
 int launch_cwide(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
 const char* cwide_tag(int shape);
-// cwpers.hip
-int cwpers_check(const icaf_conv_args* a, const ConvP& p, int shape);
-int launch_cwpers(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
-const char* cwpers_tag(int shape);
 // igemm_wreg.hip
 int wreg_check(const icaf_conv_args* a, const ConvP& p, int shape);
 int launch_wreg(const icaf_conv_args* a, const ConvP& p, int shape, hipStream_t s);
 const char* wreg_tag(int shape);
-// igemm_pers.hip
-int pers_check(const icaf_conv_args* a, const ConvP& p);
-int launch_pers(const icaf_conv_args* a, const ConvP& p, hipStream_t s);
 
 //   40 + shape: 3x3 direct convolution from an LDS halo tile (ctile.hip); 50 + shape: persistent streaming GEMM for 1x1 layers
 //   (igemm_stream.hip); 60 + shape: weight operand fed from registers (igemm_wreg.hip); an explicit request that the layer cannot
 //   satisfy is an error (the autotuner skips it), it is never chosen silently.  71: persistent 3x3 with a resident filter (cstream.hip);
-//   80 + shape: 3x3 (stride 1 / 2) from a resident halo patch with the weights streamed per wave into registers (cwide.hip);
-//   90 + shape: its persistent form (cwpers.hip).  67: persistent, balanced 256-channel implicit GEMM for the long-K layers (igemm_pers.hip).
+//   80 + shape: 3x3 (stride 1 / 2) from a resident halo patch with the weights streamed per wave into registers (cwide.hip).
 static int pick_tile(const icaf_conv_args* a, const ConvP& p) {
     const bool dma_ok = p.x_bytes != 0;
-    if (a->tile > 40 && a->tile < 100) return a->tile;
+    if (a->tile > 40 && a->tile < 90) return a->tile;
     if (a->tile >= 1 && a->tile <= 34 && a->tile % 10 >= 1 && a->tile % 10 <= 4) {
         const int pipe = a->tile / 10;
         return (pipe != 1 && !dma_ok) ? a->tile % 10 + 10 : a->tile;
@@ -631,6 +623,7 @@ static int launch_tile(const ConvP& p, int groups, int cfg, hipStream_t s) {
 static int validate(const icaf_conv_args* a) {
     if (!a || !a->x || !a->w || !a->y) return fail(ICAF_ERR_ARG, "icaf_conv2d: null pointer");
     if (a->groups < 1 || a->groups > 2) return fail(ICAF_ERR_ARG, "icaf_conv2d: groups must be 1 or 2");
+    if (a->tile < 0 || a->tile >= 90) return fail(ICAF_ERR_ARG, "icaf_conv2d: unknown launch configuration %d", a->tile);
     const int vec = a->dtype == ICAF_F32 ? 4 : 8;
     if (a->dtype < 0 || a->dtype > 2) return fail(ICAF_ERR_ARG, "icaf_conv2d: bad dtype %d", a->dtype);
     if (a->out_dtype != a->dtype && a->out_dtype != ICAF_F32) return fail(ICAF_ERR_ARG, "icaf_conv2d: out_dtype must equal dtype or be fp32");
@@ -709,10 +702,8 @@ extern "C" int icaf_conv2d(const icaf_conv_args* a, icaf_stream_t s) {
     hipStream_t hs = S(s);
     if (a->x2 && tile != 81 && tile != 82) return fail(ICAF_ERR_UNSUPPORTED, "icaf_conv2d: x2 (C3 tail) is built for launch configurations 81 / 82 only (tile %d)", tile);
     if (tile == 71) return launch_cstream(a, p, hs);        // persistent 3x3 with the filter resident in LDS (64 -> 64 channels)
-    if (tile > 90) return launch_cwpers(a, p, tile - 90, hs); // the same, persistent: double-buffered patch, rolling weight stream (cwpers.hip)
     if (tile > 80) return launch_cwide(a, p, tile - 80, hs);  // 3x3 (stride 1 / 2) from a resident halo patch, weights streamed into registers
     if (tile > 70) return fail(ICAF_ERR_ARG, "unknown tile id %d", tile);
-    if (tile == 67) return launch_pers(a, p, hs);             // persistent, balanced spans of 256-channel tiles, one workgroup per CU (igemm_pers.hip)
     if (tile > 60) return launch_wreg(a, p, tile - 60, hs);
     if (tile > 50) return launch_stream(a, p, tile - 50, hs);
     if (tile > 40) return launch_ctile(a, p, tile - 40, hs);
@@ -757,12 +748,6 @@ extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int b
         snprintf(buf, buf_len, "cstream_%s_8x16n64", dn[a->dtype]);
         return ICAF_OK;
     }
-    if (tile > 90) {
-        st = cwpers_check(a, p, tile - 90);
-        if (st) return st;
-        snprintf(buf, buf_len, "cwpers_%s_%s", dn[a->dtype], cwpers_tag(tile - 90));
-        return ICAF_OK;
-    }
     if (tile > 80) {
         st = cwide_check(a, p, tile - 80);
         if (st) return st;
@@ -770,12 +755,6 @@ extern "C" int icaf_conv2d_kernel_name(const icaf_conv_args* a, char* buf, int b
         return ICAF_OK;
     }
     if (tile > 70) return fail(ICAF_ERR_ARG, "unknown tile id %d", tile);
-    if (tile == 67) {
-        st = pers_check(a, p);
-        if (st) return st;
-        snprintf(buf, buf_len, "igemm_pers_%s_256x256", dn[a->dtype]);
-        return ICAF_OK;
-    }
     if (tile > 60) {
         st = wreg_check(a, p, tile - 60);
         if (st) return st;

@@ -77,27 +77,6 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char*
     }
 }
 
-// ---- host -> device feed copy (the dataloader's pinned uint8 batch into a plan's input buffer) ----------------------
-// A few resident workgroups stream the batch over PCIe with plain loads from the mapped host allocation: each lane keeps FEED_U 16-byte
-// loads in flight (PCIe read latency is microseconds: nwg * 256 * 16 * FEED_U bytes outstanding cover it), stores go straight to HBM.
-// The copy then is ordinary wave traffic with a dispatch priority, instead of an SDMA transfer that the forwards in flight slow down.
-constexpr int FEED_U = 8;
-__global__ __launch_bounds__(256) void feed_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long long nvec) {
-    const long long step = (long long)gridDim.x * 256 * FEED_U;
-    long long base = (long long)blockIdx.x * 256 * FEED_U + threadIdx.x;
-    for (; base + (FEED_U - 1) * 256 < nvec; base += step) {         // whole chunks: FEED_U loads issued back to back, then FEED_U stores
-        u32x4 v[FEED_U];
-#pragma unroll
-        for (int u = 0; u < FEED_U; ++u) v[u] = __builtin_nontemporal_load(src + base + u * 256);
-#pragma unroll
-        for (int u = 0; u < FEED_U; ++u) __builtin_nontemporal_store(v[u], dst + base + u * 256);
-    }
-    for (int u = 0; u < FEED_U; ++u)                                   // the last, partial chunk (at most one lane set reaches it)
-        if (base + u * 256 < nvec) dst[base + u * 256] = src[base + u * 256];
-}
-__global__ __launch_bounds__(64) void feed_tail_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int n) {
-    if ((int)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
-}
 
 // ---- SPPF: y1 = maxpool_k(x), y2 = maxpool_k(y1), y3 = maxpool_k(y2), stride 1, -inf padding ----------------------
 // Chained k-pools equal direct pools with windows k, 2k-1, 3k-2 clipped at the border, so one pass over the
@@ -357,26 +336,6 @@ extern "C" int icaf_preprocess_u8(const unsigned char* img, void* out, int dtype
     return ICAF_OK;
 }
 
-extern "C" int icaf_feed_copy(const void* host, void* dev, long long nbytes, int nwg, icaf_stream_t s) {
-    if (!host || !dev || nbytes < 0) return fail(ICAF_ERR_ARG, "icaf_feed_copy: null pointer / negative size");
-    if (nwg < 1 || nwg > 1024) return fail(ICAF_ERR_ARG, "icaf_feed_copy: nwg %d outside [1, 1024]", nwg);
-    if (((uintptr_t)host | (uintptr_t)dev) & 15) return fail(ICAF_ERR_ARG, "icaf_feed_copy: both pointers must be 16-byte aligned");
-    void* mapped = nullptr;                       // the device-side address of the pinned allocation (the same address under unified addressing)
-    if (hipHostGetDevicePointer(&mapped, const_cast<void*>(host), 0) != hipSuccess || !mapped) {
-        (void)hipGetLastError();
-        return fail(ICAF_ERR_ARG, "icaf_feed_copy: host pointer is not pinned, device-mapped memory");
-    }
-    const long long nvec = nbytes / 16;
-    if (nvec) {
-        const long long per = 256LL * FEED_U;
-        const int grid = (int)std::min<long long>(nwg, (nvec + per - 1) / per);
-        hipLaunchKernelGGL(feed_copy_kernel, dim3(grid), dim3(256), 0, S(s), (const u32x4*)mapped, (u32x4*)dev, nvec);
-    }
-    if (nbytes & 15)
-        hipLaunchKernelGGL(feed_tail_kernel, dim3(1), dim3(64), 0, S(s), (const unsigned char*)mapped + nvec * 16, (unsigned char*)dev + nvec * 16, (int)(nbytes & 15));
-    ICAF_LAUNCH_CHECK();
-    return ICAF_OK;
-}
 
 extern "C" int icaf_sppf_pool(const void* x, int ldx, void* y1, void* y2, void* y3, int ldy, int dtype, int B, int H, int W, int C,
                               int k, icaf_stream_t s) {
@@ -386,9 +345,9 @@ extern "C" int icaf_sppf_pool(const void* x, int ldx, void* y1, void* y2, void* 
     if (C % vec || ldx % vec || ldy % vec || !(k & 1)) return fail(ICAF_ERR_ARG, "icaf_sppf_pool: C/ld must be multiples of %d and k odd", vec);
     const int nv = C / vec;
     // channel vectors per workgroup: the largest group whose plane fits.  A cap of 2 (twice the workgroups) is faster in isolation
-    // (tools/probes/sppf_vpb.py, 64 x 20x20 x 256 bf16: 32.7 -> 29.3 us) and slower in the forward (35 -> 40 us, input not cache-resident)
+    // (lab/probes/sppf_vpb.py, 64 x 20x20 x 256 bf16: 32.7 -> 29.3 us) and slower in the forward (35 -> 40 us, input not cache-resident)
     int vpb = 0, cap = 8;
-    if (const char* e = getenv("ICAF_SPPF_VPB")) cap = atoi(e) > 0 ? atoi(e) : cap;       // probe knob
+    if (g_opt.sppf_vpb > 0) cap = g_opt.sppf_vpb;                                         // probe knob (icaf_set_option)
     for (int c : {8, 4, 2, 1})
         if (c <= cap && nv % c == 0 && (size_t)H * W * c * 32 <= 60 * 1024) { vpb = c; break; }
     if (vpb) {

@@ -16,7 +16,7 @@
 #include "conv_common.h"
 #include <cstring>
 #ifdef ICAF_S2_CLK
-#include <cstdlib>          // (probe builds only: tools/probes/stem2_phases.py)
+#include <cstdlib>          // (probe builds only: lab/probes/stem2_phases.py)
 #endif
 
 namespace icaf {

@@ -10,12 +10,12 @@ There is deliberately no PyTorch / CPU fallback: calling a module with CPU tenso
 libicaf.so raises.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
 
 from .. import ops
+from ..options import OPT
 from ..engine import ImageIn, Plan, concat_view, from_act, to_act
 
 BN_EPS_DEFAULT = 1e-5
@@ -335,13 +335,13 @@ class Conv(HipModule):
                 and kn.kernel_size == (1, 1) and kn.stride == (1, 1) and kn.groups == 1 and kn.in_channels == k.out_channels
                 and max(k.out_channels, kn.out_channels) <= self.chain_max_width)
 
-    chain_tail = os.environ.get("ICAF_C3_TAIL", "1") != "0"      # A/B switch: a C3's cv3 rides on its last Bottleneck's 3x3 (a class default, as fuse_decode)
+    chain_tail = OPT.c3_tail      # A/B switch: a C3's cv3 rides on its last Bottleneck's 3x3 (a class default, as fuse_decode)
 
     def chain_ok_tail(self, plan, cv3):
         """Can the C3's cv3 (1x1 SiLU over cat(m, cv2)) ride on this 3x3 layer — the block's last Bottleneck.cv2 — so that neither m nor
         the concatenation reach HBM?  (icaf_conv2d: x2; built in cwide.hip for 128 -> 128 layers with 256 output channels of cv3)"""
         k, k3 = self.conv, cv3.conv
-        return (self.chain_tail and ops.CWIDE and plan.dtype in (torch.bfloat16, torch.float16) and isinstance(self.act, nn.SiLU)
+        return (self.chain_tail and OPT.cwide and plan.dtype in (torch.bfloat16, torch.float16) and isinstance(self.act, nn.SiLU)
                 and isinstance(cv3.act, nn.SiLU) and (k.kernel_size, k.stride, _pair(k.padding), k.groups) == ((3, 3), (1, 1), (1, 1), 1)
                 and (k.in_channels, k.out_channels) == (128, 128) and k3.kernel_size == (1, 1) and k3.stride == (1, 1) and k3.groups == 1
                 and _pair(k3.padding) == (0, 0) and k3.in_channels == 2 * k.out_channels and k3.out_channels == 256)
@@ -748,7 +748,7 @@ class CrossTransformerBlock(HipModule):
                             alpha_acc=alpha_acc, alpha_res=alpha_res, groups=2, group_strides=gs, name=name))
 
     # 16-bit types: one iteration = icaf_dmff_ln_qkv + icaf_dmff_attn_mlp (2 launches) instead of 7 (ICAF_DMFF_FUSE=0: A/B switch)
-    fuse_block = os.environ.get("ICAF_DMFF_FUSE", "1") != "0"
+    fuse_block = OPT.dmff_fuse
     # The two-launch kernels (dmff_fused.hip: LN + QKV, then attention + out-projection + LN + MLP in ONE workgroup) are built for C <= 512 and
     # USED up to this width.  Round 2 measured them ahead at C <= 128 only (111 vs 145 us for the seven per-layer launches at P3; at C = 256 /
     # 512 one workgroup per CU cannot hide its own latencies: 166 vs 141, 430 vs 153 us); round 3 moved C = 256 / 512 to the three-launch form
@@ -756,11 +756,11 @@ class CrossTransformerBlock(HipModule):
     # GEMM pass) and the stand-alone attention kernel got the rewritten inner loop: P3 block 88 us (two launches) vs 78 us (three), whole
     # bench 15,003 / 15,061 vs 15,181 pairs/s on one box — so the default is 64 and every yolov5s level runs three launches.
     # ICAF_DMFF_FUSE_MAX_C=128 restores the two-launch form at P3 (A/B, tests).
-    fuse_max_c = int(os.environ.get("ICAF_DMFF_FUSE_MAX_C", "64"))
+    fuse_max_c = OPT.dmff_fuse_max_c
     # fp32 plans keep the per-layer launches (the goldens then cover them); True runs the fp32 INSTANTIATION of the fused kernels where
     # it exists: the same templates the 16-bit path runs, held to the reference's fp32 goldens (tests/test_gpu_dmff_fused.py) — the two-launch
     # form at C <= fuse_max_c <= 128, and (round 5) the THREE-launch form every yolov5s level runs by default, at C = 128 (dmff_wide.hip)
-    fuse_fp32 = os.environ.get("ICAF_DMFF_FUSE_FP32", "0") == "1"
+    fuse_fp32 = OPT.dmff_fuse_fp32
 
     def fusable(self, plan, C, N):
         hid, h = self.mlp_vis[0].out_features, self.crossatt.h
@@ -771,9 +771,9 @@ class CrossTransformerBlock(HipModule):
                 and (plan.device.type == "cuda" or C <= 512))
 
     # wide levels, 16-bit types: three launches per iteration (ICAF_DMFF_WIDE=0: the seven per-layer launches, A/B switch)
-    fuse_wide = os.environ.get("ICAF_DMFF_WIDE", "1") != "0"
-    res32 = os.environ.get("ICAF_DMFF_RES32", "1") != "0"       # loops > 1: the token stream between iterations in fp32 (A/B switch)
-    wide_max_c = int(os.environ.get("ICAF_DMFF_WIDE_MAX_C", "512"))
+    fuse_wide = OPT.dmff_wide
+    res32 = OPT.dmff_res32        # loops > 1: the token stream between iterations in fp32 (A/B switch)
+    wide_max_c = OPT.dmff_wide_max_c
 
     def wide_fusable(self, plan, C):
         hid, h = self.mlp_vis[0].out_features, self.crossatt.h
@@ -935,7 +935,7 @@ class Detect(HipModule):
     export = False
     # 16-bit plans: a level's 1x1 conv and its decode run as ONE launch (icaf_detect_conv; ICAF_DETECT_FUSE=0: A/B switch).  A class
     # default: un-pickled reference checkpoints never run this constructor.
-    fuse_decode = os.environ.get("ICAF_DETECT_FUSE", "1") != "0"
+    fuse_decode = OPT.detect_fuse
 
     def __init__(self, nc=80, anchors=(), ch=()):
         super().__init__()

@@ -6,12 +6,12 @@ one kernel on a stream or returns a `Launch` record that does so later (used by 
 PyTorch only provides device memory and streams here — none of its operators run on the hot path.
 """
 import ctypes as C
-import os
 import weakref
 
 import torch
 
 from . import _lib
+from .options import OPT
 from ._lib import BneckArgs, ConvArgs, DmffArgs, Stem2Args, check, lib, F32, BF16, F16, ACT_NONE, ACT_SILU, ACT_GELU  # noqa: F401
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
@@ -101,17 +101,10 @@ def pack_conv_weight(w4d, dt, cin_pad=None):
 
 
 _FRAG_CACHE = {}              # id(packed tensor) -> (weakref to it, fragment-major copy); entries die with the packed tensor
-TAIL_8X16_MINPIX = int(os.environ.get("ICAF_TAIL_8X16_MINPIX", 200_000))     # conv_candidates: C3 tail, see there
-CWIDE = os.environ.get("ICAF_CWIDE", "1") != "0"               # A/B switch: resident-patch / streamed-weights 3x3 kernel (cwide.hip) as a tuner candidate
-CSTREAM = os.environ.get("ICAF_CSTREAM", "1") != "0"           # A/B switch: persistent resident-filter 3x3 kernel as a tuner candidate
-WREG_GEMM = os.environ.get("ICAF_WREG_GEMM", "1") != "0"       # A/B switch: weights-from-registers kernels as tuner candidates
-# The persistent long-K GEMM (launch configuration 67, igemm_pers.hip) as a tuner candidate: OFF by default.  Isolated, it beats the round-4 choices on
-# the paired 3x3 256 -> 256 layers of yolov5l (132 -> 119 us) and on long-K 1x1 layers (-12 ... -16 %), and a forward run alone gets 1 - 2.6 % shorter; but
-# its one workgroup per CU (148 KB of LDS) cannot share a CU with the second forward in flight, and the bench's throughput mode LOSES with it (same box, whole
-# bench: yolov5l shard 3,813 -> 3,778, VEDAI shard 986 -> 975, default workload 16,140 -> 15,995 pairs/s).  ICAF_PERS_GEMM=1 offers it (one batch at a time).
-PERS_GEMM = os.environ.get("ICAF_PERS_GEMM", "0") != "0"
-PERS_MIN_K = int(os.environ.get("ICAF_PERS_MIN_K", "512"))      # ... offered to layers with at least this many K elements (eight 64-element slices)
-WREG64_MAXPIX = int(os.environ.get("ICAF_WREG64_MAXPIX", str(128 * 1024)))     # launches with at most this many pixels are offered the 64-pixel wreg tiles
+# (execution switches — which kernels the tuner may offer a layer, retune requests — live in options.PlanOptions; read as OPT.<field>)
+# (Round 5's persistent long-K GEMM — launch configuration 67, igemm_pers.hip — and the persistent halo-patch 3x3 — 90 + shape, cwpers.hip — were removed
+#  in round 6: the first won isolated and lost every benchmarked workload with two forwards in flight (yolov5l shard 3,813 -> 3,778 pairs/s), the second
+#  lost everywhere; no committed tune cache named either.  `git log -- icafusion_amd/csrc/igemm_pers.hip` has them; docs/HISTORY.md section 16 the numbers.)
 
 
 def frag_weights(w_packed):
@@ -183,9 +176,9 @@ def conv2d(x, w_packed, kp, bias, y, kh, kw, sh, sw, ph, pw, cin, cout, act, res
     a.alpha_res[0], a.alpha_res[1] = float(ar[0]), float(ar[1])
     a.tile = tile
     wf = None
-    cw_layer = bool(CWIDE and act == ACT_SILU and cwide_shapes(kh, kw, sh, sw, ph, pw, cin, cout))                               # cwide.hip
+    cw_layer = bool(OPT.cwide and act == ACT_SILU and cwide_shapes(kh, kw, sh, sw, ph, pw, cin, cout))                               # cwide.hip
     if (x.dtype != torch.float32 and y.dtype == x.dtype and (cin * 2) % 128 == 0 and kp % 64 == 0 and pre is None
-            and ((WREG_GEMM and chain is None and cout > 64) or cw_layer)):
+            and ((OPT.wreg_gemm and chain is None and cout > 64) or cw_layer)):
         wf = frag_weights(w_packed)                   # igemm_wreg.hip: weight operand from registers (tile ids 61 / 62)
         a.wf, a.wf_gs = wf.data_ptr(), (wf.stride(0) if w_packed.dim() == 3 else 0)
     if pre is not None:               # fp32 coarse map (B, h, w, >= cout) added, bilinearly resized, before the activation
@@ -256,11 +249,8 @@ def bottleneck(x, w1_packed, kp1, bias1, w2_packed, kp2, bias2, y, c, add, shape
 
 
 _TUNE_CACHE = {}
-RETUNE_TILES = {int(t) for t in os.environ.get("ICAF_RETUNE_TILES", "").split(",") if t.strip()}     # e.g. "63,64": see autotune_conv
-RETUNE_PRE = os.environ.get("ICAF_RETUNE_PRE", "0") == "1"       # every configuration of the pre-activation-term launches gets its chance against the cached one
 _RETUNED = set()
 CTILE_SHAPES = {1: (32, 1), 2: (64, 1), 3: (64, 1), 4: (64, 2), 5: (128, 1)}     # shape id -> (BN, stride), ctile.hip
-STREAM_GEMM = os.environ.get("ICAF_STREAM_GEMM", "1") != "0"      # A/B switch for the persistent 1x1 kernel as a tuner candidate
 CONV_PIPELINES = (0, 1, 2)        # LDS-DMA 64 B x3, register-staged, LDS-DMA 128 B x2 (3 = 128 B x3: never won)
 
 
@@ -268,14 +258,14 @@ def cwide_shapes(kh, kw, sh, sw, ph, pw, cin, cout):
     """Tile ids (80 + shape) of cwide.hip that are built for this 3x3 layer: resident halo patch, weights streamed into registers."""
     if (kh, kw, ph, pw) != (3, 3, 1, 1) or sh != sw or cout % 128:
         return []
-    # 80 + shape: one tile per workgroup (cwide.hip); 90 + shape: persistent, double-buffered patch (cwpers.hip)
+    # 80 + shape: one tile per workgroup
     if sh == 1:
-        return [81, 82, 91, 95] if (cin == 128 and cout == 128) else []  # 8 x 16 / 8 x 8 output pixels per workgroup; persistent 8 x 16 (8 waves) / 8 x 8 (4 waves, 3 per CU)
+        return [81, 82] if (cin == 128 and cout == 128) else []          # 8 x 16 / 8 x 8 output pixels per workgroup
     if sh == 2:
         if cin == 64:
-            return [83, 85, 92, 96]                                      # stride 2, 64 -> 128 k: 8 x 16 / 8 x 8 / persistent 8 x 16 / persistent 8 x 8
+            return [83, 85]                                              # stride 2, 64 -> 128 k: 8 x 16 / 8 x 8
         if cin == 128:
-            return [84, 94] + ([93] if cout % 256 == 0 else [])          # stride 2, 128 -> 128 k: 8 x 8; persistent 8 x 8 with 128 / 256 channels per workgroup
+            return [84]                                                  # stride 2, 128 -> 128 k: 8 x 8
     return []
 
 
@@ -289,27 +279,27 @@ def conv_candidates(a):
     the 3x3 halo-patch kernel; chained / pre-term launches only have the configurations that are built for them."""
     cands = []
     cs_ok = ((a.kh, a.kw, a.sh, a.sw, a.ph, a.pw) == (3, 3, 1, 1, 1, 1) and a.Cin == 64 and a.Cout <= 64 and a.Cout % 8 == 0 and a.dtype != F32
-             and a.out_dtype == a.dtype and a.act == ACT_SILU and not a.pre and CSTREAM)
+             and a.out_dtype == a.dtype and a.act == ACT_SILU and not a.pre and OPT.cstream)
     cw = (cwide_shapes(a.kh, a.kw, a.sh, a.sw, a.ph, a.pw, a.Cin, a.Cout)
-          if (a.dtype != F32 and a.wf and a.out_dtype == a.dtype and a.act == ACT_SILU and not a.pre and CWIDE) else [])
+          if (a.dtype != F32 and a.wf and a.out_dtype == a.dtype and a.act == ACT_SILU and not a.pre and OPT.cwide) else [])
     if a.w2 and a.x2:                  # C3 tail (the chained cv3 reads [tile | x2]): cwide.hip's 8 x 16 / 8 x 8 forms only
         # Below ~200 k pixels per stream (the 40 x 40 maps of yolov5s at batch 32 / 64: one round of 8 x 16 tiles for the chip) only the 8 x 8
         # form is offered: isolated timings prefer 8 x 16 there (2 workgroups of 252 registers and 70 KB per CU), but with a second forward in
         # flight that form starves the co-running kernels — same-box A/B of the whole bench: 15,858 with 8 x 16 against 16,082 without the tail and
         # 16,091 with 8 x 8 (3 workgroups of 168 registers and 35 KB).  The 80 x 80 / 160 x 160 maps of yolov5l have 4 - 16 x the tiles: tuned.
-        cands = ([82] if a.B * a.Ho * a.Wo < TAIL_8X16_MINPIX else [81, 82]) if CWIDE else []
+        cands = ([82] if a.B * a.Ho * a.Wo < OPT.tail_8x16_minpix else [81, 82]) if OPT.cwide else []
     elif a.w2:                         # chained 1x1: one N tile covering both layers, LDS-DMA pipelines 0 / 2
         t = 2 if max(a.Cout, a.Cout2) <= 64 else 1
         cands = [t, t + 20]
         if cw and a.Cout == 128 and a.Cout2 <= 128 and a.Cout2 % 32 == 0:
-            cands += [c for c in cw if c not in (93, 95)]                    # resident halo patch, weights (and the chained 1x1's) streamed into registers (cwide.hip)
+            cands += cw                                                      # resident halo patch, weights (and the chained 1x1's) streamed into registers (cwide.hip)
         if cs_ok and a.Cout == 64 and a.Cout2 <= 64:
             cands.append(71)                 # persistent 3x3 with the filter (and the chained 1x1) resident in LDS (cstream.hip)
     elif a.pre:                          # pre-activation term: built for tiles 128x128 / 128x64 on the LDS-DMA pipelines 0 / 2
         cands = [t + 10 * pipe for pipe in (0, 2) for t in (1, 2) if not (t == 1 and (a.out_dtype == F32 or a.Cout <= 64))]
         if a.dtype != F32 and a.out_dtype == a.dtype and a.Cout >= 128 and (a.Cin * 2) % 128 == 0:
             cands.append(28)                 # the 8-wavefront 128x128 tile carries the pre term as well
-        if (a.dtype != F32 and a.out_dtype == a.dtype and (a.Cin * 2) % 128 == 0 and a.Cout % 8 == 0 and STREAM_GEMM and a.act == ACT_SILU
+        if (a.dtype != F32 and a.out_dtype == a.dtype and (a.Cin * 2) % 128 == 0 and a.Cout % 8 == 0 and OPT.stream_gemm and a.act == ACT_SILU
                 and (a.kh, a.kw, a.sh, a.sw, a.ph, a.pw) == (1, 1, 1, 1, 0, 0) and a.groups == 1):
             cands.append(52)                 # ... and so does the persistent streaming GEMM (1x1 SiLU layers)
             if a.Cout > 64:
@@ -327,7 +317,7 @@ def conv_candidates(a):
             cands.append(28)
         if a.Cout >= 256:
             cands.append(26)
-    if (a.dtype != F32 and a.out_dtype == a.dtype and not a.pre and not a.w2 and (a.Cin * 2) % 128 == 0 and a.Cout % 8 == 0 and STREAM_GEMM):
+    if (a.dtype != F32 and a.out_dtype == a.dtype and not a.pre and not a.w2 and (a.Cin * 2) % 128 == 0 and a.Cout % 8 == 0 and OPT.stream_gemm):
         cands.append(52)                     # persistent streaming implicit GEMM (igemm_stream.hip): 128 x 64 tile ...
         if a.Cout > 64:
             cands.append(51)                 # ... and 128 x 128; a launch the shape rules out returns an error and is skipped
@@ -335,7 +325,7 @@ def conv_candidates(a):
         cands.append(71)
     if cw and not a.w2:
         cands += cw
-    if a.wf and WREG_GEMM and not a.pre and not a.w2:
+    if a.wf and OPT.wreg_gemm and not a.pre and not a.w2:
         cands.append(61)                     # weights fed from registers (igemm_wreg.hip): 128 x 128 ...
         if a.Cout > 128 and -(-a.Cout // 256) * 256 <= -(-a.Cout // 128) * 128:
             cands.append(62)                 # ... and 128 x 256 (its last channel tile must stay inside the packed Np = Cout rounded up to 128: wreg_check)
@@ -344,9 +334,7 @@ def conv_candidates(a):
             cands.append(64)                 # 128 x 256 with four waves: two workgroups per CU
         if a.Cout > 256 and a.Cout % 512 == 0 and a.act != ACT_GELU:
             cands.append(63)                 # 128 x 512 with eight waves
-        if a.Cout % 256 == 0 and a.kh * a.kw * a.Cin >= PERS_MIN_K and a.kh * a.kw <= 16 and not (a.act == ACT_GELU and a.kh * a.kw > 1) and PERS_GEMM:
-            cands.append(67)                 # round 5: persistent, balanced spans of 256-channel tiles, one eight-wave workgroup per CU (igemm_pers.hip)
-        if a.B * a.Ho * a.Wo * a.groups <= WREG64_MAXPIX:  # few pixels (the 20 x 20 / 40 x 40 rows at batch 32): 64-pixel tiles double the workgroups
+        if a.B * a.Ho * a.Wo * a.groups <= OPT.wreg64_maxpix:  # few pixels (the 20 x 20 / 40 x 40 rows at batch 32): 64-pixel tiles double the workgroups
             cands.append(66)                 # 64 x 128, four waves x 32 channels
             if a.Cout > 128 and a.Cout % 256 == 0:
                 cands.append(65)             # 64 x 256, four waves x 64 channels
@@ -374,7 +362,7 @@ def autotune_conv(launch, stream_ptr, reps=3, context=()):
         # for THIS launch and the library's own check for that configuration accepts it; otherwise it is dropped and the launch re-tuned.
         if tile_valid(launch, _TUNE_CACHE[sig], cands):
             cached = _TUNE_CACHE[sig]
-            fresh = [c for c in cands if (c in RETUNE_TILES or (RETUNE_PRE and a.pre)) and c != cached]
+            fresh = [c for c in cands if (c in OPT.retune_tiles or (OPT.retune_pre and a.pre)) and c != cached]
             if not fresh or sig in _RETUNED:
                 a.tile = cached
                 return a.tile
@@ -476,14 +464,6 @@ def preprocess_u8(img, out, mode, c0=0, name="preprocess_u8"):
     nb = nstreams * B * 3 * H * W + o.numel() * o.element_size()
     return Launch(lib().icaf_preprocess_u8, (img.data_ptr(), o.data_ptr(), dtype_code(o.dtype), B, Ctot, c0, 3, nstreams,
                                              H, W, cpad, mode), keep=(img, out), name=name, nbytes=nb)
-
-
-def feed_copy(host, dst, stream_ptr, nwg=16):
-    """The dataloader's PINNED uint8 batch -> a device buffer of the same size, by `nwg` resident workgroups reading host memory over PCIe
-    (icaf_feed_copy) on the given stream — the reference's `img.to(device, non_blocking=True)` (test.py:116) without the DMA engine."""
-    assert not host.is_cuda and host.is_pinned() and host.is_contiguous(), "feed_copy takes a pinned, contiguous host tensor"
-    assert dst.is_cuda and dst.is_contiguous() and dst.numel() * dst.element_size() == host.numel() * host.element_size()
-    check(lib().icaf_feed_copy(host.data_ptr(), dst.data_ptr(), host.numel() * host.element_size(), int(nwg), stream_ptr), "feed_copy")
 
 
 def stem(img, w_packed, kp, bias, y, cout, name="stem"):
@@ -696,15 +676,13 @@ def dmff_wide_ln_qkv(x, qkv, packs, ln, coef, eps, B, N, heads, name="dmff_ln_qk
     """LayerNorm + the six Linear(C, C) projections, wide levels (icaf_dmff_wide_ln_qkv)."""
     wp = _wide_packs(packs)
     a = _dmff_args(x, qkv, None, wp, ln, coef, eps, B, N, heads)
-    a.reserved = DMFF_QKV_NPASS                      # output-channel passes per workgroup: 0 = automatic (icaf.h)
+    a.reserved = OPT.dmff_qkv_npass                      # output-channel passes per workgroup: 0 = automatic (icaf.h)
     rows, Cc = x.shape[1], x.shape[2]
     es = x.element_size()
     return Launch(lib().icaf_dmff_wide_ln_qkv, (C.byref(a),), keep=(a, x, qkv, wp, packs, ln), name=name, flops=2.0 * 2 * rows * Cc * 3 * Cc,
                   nbytes=2 * (rows * Cc * es + 3 * Cc * Cc * es + rows * 3 * Cc * es))
 
 
-DMFF_QKV_NPASS = int(os.environ.get("ICAF_DMFF_QKV_NPASS", "0"))   # A/B switch: passes per workgroup of the wide LN + QKV kernel (0 = automatic)
-DMFF_KSPLIT = int(os.environ.get("ICAF_DMFF_KSPLIT", "0"))       # A/B switch: 0 = automatic, 1 = never split the hidden columns, 2 / 4 = force
 
 
 def dmff_wide_ksplit(N, C_, hidden):
@@ -715,8 +693,8 @@ def dmff_wide_ksplit(N, C_, hidden):
     (tests/test_gpu_fullsize.py; yolov5l's P4 — C = 512, N = 256, one tile per CU at batch 32 — measured slower with the split anyway)."""
     if C_ < 256:
         return 1                                     # icaf_dmff_wide_proj_mlp_split is built for the 256-channel passes (C = 256 / 512) only
-    if DMFF_KSPLIT:
-        return DMFF_KSPLIT if hidden % (256 * DMFF_KSPLIT) == 0 else 1
+    if OPT.dmff_ksplit:
+        return OPT.dmff_ksplit if hidden % (256 * OPT.dmff_ksplit) == 0 else 1
     return 2 if (9 * C_ * C_ * 2 > 3 * 2 ** 20 and N <= 128 and hidden % 512 == 0) else 1
 
 

@@ -20,12 +20,11 @@ keep output buffers) and its gathered block, so the tensors step n returned stay
 slot — and two pipelines of the same shape never share buffers.  Results of step i are valid after `synchronize()`.
 PyTorch streams / events are used as plumbing only; every kernel on both streams is ours (plus RCCL).
 """
-import os
-
 import torch
 
 from . import dist as D
 from . import ops
+from .options import OPT
 from .utils.general import nms_device
 
 
@@ -33,12 +32,15 @@ from .utils.general import nms_device
 # depth * (1 + EXTRA_PLANS) steps earlier.  With chain graphs (see HOST_FED_BRANCHES) one extra set is enough — one process each, same box:
 # 4 plans 14,745 / 14,983 pairs/s, 6 plans 14,605 (and 6 plans pin 11 GB for yolov5s batch 32); with branched graphs it took 6 plans to reach
 # 13,400 (4 plans: 10,742)
-EXTRA_PLANS = max(1, int(os.environ.get("ICAF_PIPE_EXTRA_PLANS", "1")))
-COPY_STREAMS = max(1, int(os.environ.get("ICAF_PIPE_COPY_STREAMS", "1")))      # a batch's host -> device copy in this many slices, one high-priority stream each
-COPY_PRIO = int(os.environ.get("ICAF_PIPE_COPY_PRIO", "-1"))     # the copy stream(s) on a high-priority queue: 15,600 / 15,501 pairs/s against 15,288 / 15,369 at normal priority
-HOST_FED_BRANCHES = os.environ.get("ICAF_PIPE_BRANCHES", "0") == "1"       # keep the hipGraph's parallel branches in host-fed pipelines (measured slower)
-# > 0: a pinned host batch is brought over by that many resident workgroups reading host memory (ops.feed_copy), not by the DMA engine
-FEED_WGS = int(os.environ.get("ICAF_FEED_WGS", "0"))
+# (Memory: a host-fed pipeline therefore holds depth * (1 + EXTRA_PLANS) COMPLETE plans — intermediates, hipGraph, NMS runner each: 2.0 GB per plan for
+#  yolov5s batch 32 at 640 x 640, ~40 GB for yolov5l batch 16 at 1280 x 1280, i.e. 160 GB for the four plans of a depth-2 yolov5l VEDAI pipeline.  That
+#  fits the 288 GB of an MI355X and nothing smaller; Model.plan_cache_bytes cannot evict plans a pipeline holds.)
+EXTRA_PLANS = max(1, OPT.pipe_extra_plans)
+COPY_STREAMS = max(1, OPT.pipe_copy_streams)      # a batch's host -> device copy in this many slices, one high-priority stream each
+COPY_PRIO = OPT.pipe_copy_prio                    # the copy stream(s) on a high-priority queue: 15,600 / 15,501 pairs/s against 15,288 / 15,369 at normal priority
+HOST_FED_BRANCHES = OPT.pipe_branches             # keep the hipGraph's parallel branches in host-fed pipelines (measured slower)
+# (round 5's icaf_feed_copy — resident workgroups reading the pinned batch over PCIe instead of the DMA engine — measured 2 x slower inside the
+#  serving loop and was removed in round 6)
 
 
 class DetectionPipeline:
@@ -139,7 +141,7 @@ class DetectionPipeline:
     def submit_u8(self, img6):
         """One uint8 (B, 6, H, W) batch — pinned host memory (the reference's dataloader output, test.py:116) or a device tensor — through
         the pipeline.  The copy runs on the pipeline's COPY stream straight into the input buffer of plan n % nplans: the plan that ran
-        nplans (= 2 * depth) steps ago, so the copy only waits for a forward that has long finished — NOT for one of the `depth` forwards in flight (a
+        nplans (= depth * (1 + EXTRA_PLANS)) steps ago, so the copy only waits for a forward that has long finished — NOT for one of the `depth` forwards in flight (a
         copy into the input of a plan that is still running could not start before that forward had ended: 9,960 pairs/s where the forward
         alone does 15,600; round 4's extra staging buffers + device-to-device hop: 13,059 of 16,238).  The host buffer must stay untouched
         until its copy has run (rotate >= nplans + 2 pinned buffers, or wait for the events in `pipe.copied[n % pipe.nplans]`, one per copy stream)."""
@@ -156,11 +158,8 @@ class DetectionPipeline:
                 cs.wait_event(self.fwd_done[pi])                  # this plan's previous forward (nplans steps ago) has consumed its input
             if img6.is_cuda:
                 cs.wait_stream(torch.cuda.current_stream(self.device))
-            if FEED_WGS > 0 and not img6.is_cuda and img6.is_pinned():
-                ops.feed_copy(img6[lo:hi], dst[lo:hi], cs.cuda_stream, FEED_WGS)     # resident workgroups read the pinned batch over PCIe
-            else:
-                with torch.cuda.stream(cs):
-                    dst[lo:hi].copy_(img6[lo:hi], non_blocking=True)
+            with torch.cuda.stream(cs):
+                dst[lo:hi].copy_(img6[lo:hi], non_blocking=True)
             if img6.is_cuda:
                 img6.record_stream(cs)
             self.copied[pi][k].record(cs)

@@ -35,6 +35,11 @@ enum { ICAF_ACT_NONE = 0, ICAF_ACT_SILU = 1, ICAF_ACT_GELU = 2 };
 enum { ICAF_OK = 0, ICAF_ERR_ARG = -1, ICAF_ERR_HIP = -2, ICAF_ERR_UNSUPPORTED = -3 };
 
 const char* icaf_last_error(void);
+/* Probe knobs of the library, set by the host's one options object (icafusion_amd/options.py) when the library is loaded — the library reads no
+ * environment variable: "detect_elementwise" (!= 0: icaf_detect_decode by the one-thread-per-element kernel), "attn_qsplit" (n > 0: query splits per
+ * head of icaf_cross_attention), "sppf_vpb" (n > 0: cap on the channel vectors per workgroup of icaf_sppf_pool); 0 = the library's own choice.
+ * ICAF_ERR_ARG for an unknown name.  None of them changes a result. */
+int icaf_set_option(const char* name, int value);
 int icaf_version(void);
 /* device facts used by the host for grid sizing / reporting: CU count, LDS bytes per workgroup, gcnArchName */
 int icaf_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
@@ -53,12 +58,6 @@ int icaf_preprocess_nchw(const float* img, void* out, int dtype, int B, int C, i
  * [c0 + s*C, c0 + (s+1)*C) and is written to out[s][b] (nstreams*B images), value = (float)u8 / 255.0f. */
 int icaf_preprocess_u8(const unsigned char* img, void* out, int dtype, int B, int Ctot, int c0, int C, int nstreams,
                        int H, int W, int Cpad, int mode, icaf_stream_t s);
-
-/* The batch's way onto the device (reference test.py:116 / detect_twostream.py:76: `img.to(device, non_blocking=True)` of the dataloader's
- * pinned uint8 batch): `nwg` resident workgroups read the PINNED, device-mapped host allocation over PCIe and store into HBM — a kernel on
- * the caller's (high-priority) copy stream, not a DMA-engine transfer.  host, dev 16-byte aligned; host must come from hipHostMalloc
- * (torch's pin_memory()); ICAF_ERR_ARG otherwise. */
-int icaf_feed_copy(const void* host, void* dev, long long nbytes, int nwg, icaf_stream_t s);
 
 /* Staging + stem convolution in one persistent kernel: the 6x6 / stride 2 / pad 2 Conv(+BN+SiLU) of yaml rows 0 and 10
  * (models/common.py:48-60) computed straight from the NCHW images (fp32 [nstreams*B][3][H][W], or img_u8 != 0: the
@@ -121,8 +120,7 @@ typedef struct icaf_conv_args {
     float alpha_res[2];
     int tile; /* 0 = auto; otherwise force a launch configuration (tuning / tests; a configuration the layer does not satisfy is an error,
                * never replaced silently).  1-4 (+10 / 20 / 30 per pipeline), 25 / 26 / 28 / 29: igemm.hip tiles; 40 + shape: ctile.hip;
-               * 51 / 52: igemm_stream.hip; 61 - 66: igemm_wreg.hip; 67: igemm_pers.hip (persistent long-K GEMM, Cout in whole 256-channel tiles);
-               * 71: cstream.hip; 80 + shape: cwide.hip; 90 + shape: cwpers.hip.
+               * 51 / 52: igemm_stream.hip; 61 - 66: igemm_wreg.hip; 71: cstream.hip; 80 + shape (81 - 85): cwide.hip.
                * Every configuration of a layer produces the same bits (same K order, MFMA step, epilogue expressions). */
     /* Optional pre-activation term, bilinearly resized (align_corners=False) from a coarse fp32 map:
      *   y = alpha_res*res + alpha_acc * act( A.W + bias + bilinear(pre)[b][ho][wo][n] )
@@ -147,7 +145,7 @@ typedef struct icaf_conv_args {
     int chain_keep; /* != 0: y IS written as well; only then may `res` be set: the chained 1x1 consumes y as stored, residual
                      * included (a Bottleneck's 3x3 + shortcut followed by the next Bottleneck's 1x1, models/common.py:193-194) */
     /* Optional second copy of the packed weights in FRAGMENT-MAJOR order (NULL = none), read by the launch configurations that feed
-     * the weight operand from registers (igemm_wreg.hip, cwide.hip, cwpers.hip: tile ids 61 / 62, 81-85, 91-96): [Np / 32][Kp / 16][64 lanes][8 elements], lane
+     * the weight operand from registers (igemm_wreg.hip, cwide.hip: tile ids 61 - 66, 81 - 85): [Np / 32][Kp / 16][64 lanes][8 elements], lane
      * (hi * 32 + r) of block (nb, ks) holding w[nb * 32 + r][ks * 16 + hi * 8 .. + 8] of the K-major matrix above; wf_gs = group
      * stride in elements.  16-bit types (icafusion_amd.ops.frag_weights builds it once per layer). */
     const void* wf;

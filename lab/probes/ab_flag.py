@@ -1,5 +1,5 @@
 """A/B one class-level plan flag on the bench plan (yolov5s bf16, batch 32, 640x640, committed tune cache + in-situ tuning of
-new signatures):  python tools/probes/ab_flag.py Bottleneck.fuse_widths "(32, 64)" "(32,)" """
+new signatures):  python lab/probes/ab_flag.py Bottleneck.fuse_widths "(32, 64)" "(32,)" """
 import os
 import sys
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")

@@ -1,5 +1,5 @@
 """Forward time + per-launch times of the bench plan (yolov5s bf16, batch 32, 640x640, committed tune cache) as JSON on stdout.
-Run it under different ICAF_LIB settings on ONE box to A/B kernel variants:  tools/build_variant.py, tools/probes/ab_diff.py."""
+Run it under different ICAF_LIB settings on ONE box to A/B kernel variants:  tools/build_variant.py, lab/probes/ab_diff.py."""
 import json
 import os
 import sys

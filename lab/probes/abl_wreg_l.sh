@@ -3,5 +3,5 @@
 cd $GRAFT_REPO_ROOT
 export ICAF_PROBE_MODEL=l
 L="7:64 16:64 19:64,62,61 37:64 40:64,63 75:64 38:61,64"
-python tools/probes/time_layer.py $L 2>/dev/null | tail -1
-for a in 1 2 4 7; do ICAF_LIB=$GRAFT_REPO_ROOT/icafusion_amd/lib/libicaf_wabl$a.so python tools/probes/time_layer.py 7:64 16:64 19:64 37:64 40:64 75:64 38:61 2>/dev/null | tail -1; done
+python lab/probes/time_layer.py $L 2>/dev/null | tail -1
+for a in 1 2 4 7; do ICAF_LIB=$GRAFT_REPO_ROOT/icafusion_amd/lib/libicaf_wabl$a.so python lab/probes/time_layer.py 7:64 16:64 19:64 37:64 40:64 75:64 38:61 2>/dev/null | tail -1; done

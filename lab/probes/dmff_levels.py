@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch times of one CrossTransformerBlock iteration at the three yolov5s levels (batch 32, bf16), for each launch structure:
-per-layer (7), two launches (ln_qkv + attn_mlp), three launches (ln_qkv + attention + proj_mlp).  python tools/probes/dmff_levels.py"""
+per-layer (7), two launches (ln_qkv + attn_mlp), three launches (ln_qkv + attention + proj_mlp).  python lab/probes/dmff_levels.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

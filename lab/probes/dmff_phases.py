@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase breakdown of icaf_dmff_attn_mlp (shader-clock stamps of workgroup (0,0,0)): staging of the first K / V^T pair, attention
-(4 rounds incl. staging), out-projection, LayerNorm, MLP, output.  python tools/probes/dmff_phases.py  (GPU box)"""
+(4 rounds incl. staging), out-projection, LayerNorm, MLP, output.  python lab/probes/dmff_phases.py  (GPU box)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

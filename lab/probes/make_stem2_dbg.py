@@ -3,8 +3,8 @@
 1 no prefetch / commit, 2 no stage 1, 4 no stage 2, 8 no stage 3, 16 no global stores — results are then garbage, the time
 of the remaining stages is what is measured):
 
-    python tools/probes/make_stem2_dbg.py
-    gpurun -- 'export ICAF_LIB=$PWD/icafusion_amd/lib/libicaf_dbg.so; for d in 0 1 2 4 8 16 30 31; do ICAF_STEM2_DBG=$d python tools/probes/stem2_ablation.py; done'
+    python lab/probes/make_stem2_dbg.py
+    gpurun -- 'export ICAF_LIB=$PWD/icafusion_amd/lib/libicaf_dbg.so; for d in 0 1 2 4 8 16 30 31; do ICAF_STEM2_DBG=$d python lab/probes/stem2_ablation.py; done'
 """
 import os
 import subprocess

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase clocks of nms_walk_kernel (image 0) on the bench workload's predictions: build nms.hip with -DICAF_NMS_DEBUG into
-libicaf_nmsdbg.so and run  ICAF_LIB=icafusion_amd/lib/libicaf_nmsdbg.so python tools/probes/nms_phases.py"""
+libicaf_nmsdbg.so and run  ICAF_LIB=icafusion_amd/lib/libicaf_nmsdbg.so python lab/probes/nms_phases.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, yaml

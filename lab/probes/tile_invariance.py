@@ -1,5 +1,5 @@
 """Every launch configuration (tile x pipeline) of every conv launch of a plan must produce bit-identical output: run each
-candidate on the launch's real input and compare.  python tools/probes/tile_invariance.py [s|l] [batch]"""
+candidate on the launch's real input and compare.  python lab/probes/tile_invariance.py [s|l] [batch]"""
 import os, sys
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, R)
 import torch, yaml

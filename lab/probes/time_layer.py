@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time single conv launches of the bench plan (yolov5s — ICAF_PROBE_MODEL=l: yolov5l — bf16, batch 32, 640x640) under given launch configurations:
-    python tools/probes/time_layer.py idx:tile[,tile...] [idx:tile,...] ...        (ICAF_LIB selects the library build)
+    python lab/probes/time_layer.py idx:tile[,tile...] [idx:tile,...] ...        (ICAF_LIB selects the library build)
 prints microseconds per launch (median of 5 x 10 back-to-back launches) - for same-box A/B of kernel variants."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 // Issue cost of plain / packed / transcendental fp32 VALU instructions on gfx950, one or two waves per SIMD:
-//   hipcc --offload-arch=gfx950 -O3 tools/probes/valu_rate_probe.hip -o tools/probes/valu_rate_probe && gpurun -- tools/probes/valu_rate_probe
+//   hipcc --offload-arch=gfx950 -O3 lab/probes/valu_rate_probe.hip -o lab/probes/valu_rate_probe && gpurun -- lab/probes/valu_rate_probe
 // One workgroup of 256 (1 wave / SIMD) or 512 (2 waves / SIMD) threads on one CU runs ITER x 32 independent instructions of one kind
 // (8 independent chains, so dependency latency is covered); s_memtime around the loop -> cycles per wave-instruction per SIMD.
 #include <hip/hip_runtime.h>

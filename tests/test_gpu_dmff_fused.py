@@ -161,9 +161,9 @@ def test_wide_block_hidden_split_equals_unsplit(shape, ksplit, monkeypatch):
     rv, ri = oracle.cross_transformer(tq[0].reshape(B, N, C), tq[1].reshape(B, N, C), sd, "b", heads, loops)
     ref = torch.stack((rv.reshape(B * N, C), ri.reshape(B * N, C)))
     # (res32 off: the fp32 token stream of loops > 1 is not built for every split — this test is about the split alone)
-    monkeypatch.setattr(ops, "DMFF_KSPLIT", 1)
+    monkeypatch.setattr(ops.OPT, "dmff_ksplit", 1)
     base, _ = run_block(blk, tok, B, N, torch.bfloat16, True, max_c=128, res32=False)
-    monkeypatch.setattr(ops, "DMFF_KSPLIT", ksplit)
+    monkeypatch.setattr(ops.OPT, "dmff_ksplit", ksplit)
     got, names_k = run_block(blk, tok, B, N, torch.bfloat16, True, max_c=128, res32=False)
     again, _ = run_block(blk, tok, B, N, torch.bfloat16, True, max_c=128, res32=False)
     assert ("dmff_proj_mlp_reduce" in names_k) == (ksplit > 1)

@@ -267,9 +267,7 @@ CWIDE_CASES = [
 ]
 
 
-# (the four-wave persistent form, tile id 95, has no chained variant: those combinations are not generated)
-CWIDE_PARAMS = [pytest.param(c, t, id=f"{i}-{n}") for i, c in enumerate(CWIDE_CASES)
-                for t, n in ((81, "8x16"), (82, "8x8"), (91, "persistent"), (95, "persistent8x8")) if not (c[5] and t == 95)]
+CWIDE_PARAMS = [pytest.param(c, t, id=f"{i}-{n}") for i, c in enumerate(CWIDE_CASES) for t, n in ((81, "8x16"), (82, "8x8"))]
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
@@ -406,14 +404,6 @@ CWIDE_S2_CASES = [
     (4, 80, 80, 128, 256, 2, 0, 84),         # backbone 80 -> 40, both backbones, two channel blocks
     (3, 80, 80, 128, 128, 1, 0, 84),         # head down-sampling 80 -> 40
     (2, 37, 45, 128, 128, 1, 64, 84),        # ragged, chained narrower 1x1
-    (16, 160, 160, 64, 128, 2, 128, 92),     # persistent forms: many tiles per workgroup ...
-    (3, 63, 75, 64, 128, 1, 0, 92),          # ... ragged map, fewer tiles than workgroups on some XCDs
-    (16, 80, 80, 128, 256, 2, 0, 93),        # 256 channels per workgroup
-    (2, 37, 45, 128, 512, 1, 0, 93),         # two channel blocks of 256
-    (8, 80, 80, 128, 128, 1, 0, 94),
-    (16, 160, 160, 64, 128, 2, 128, 96),     # four wavefronts, two workgroups per CU
-    (3, 63, 75, 64, 128, 1, 0, 96),
-    (2, 37, 45, 128, 128, 1, 64, 94),
 ]
 
 
@@ -528,69 +518,6 @@ def test_conv_weights_from_registers_kernel(case, dt):
         if use_res:
             ref = ref + 1.25 * q(rs[g], dt)
         close(from_act(outs[0][g] if G == 2 else outs[0]), ref, dt, f"wreg {case} group {g}")
-
-
-PERS_CASES = [
-    # B, H, W, cin, cout, k, stride, act, use_res, groups: launch configuration 67 (igemm_pers.hip) — one persistent eight-wave workgroup per CU
-    (3, 20, 20, 256, 256, 3, 1, ops.ACT_SILU, True, 2),       # paired, residual, K = 36 slices; 37.5 blocks per stream over 128 spans: TM = 0 / 1 chunks, ragged last block
-    (8, 96, 96, 64, 256, 3, 1, ops.ACT_SILU, False, 1),       # 2304 blocks over 256 spans = 9 each: TWO chunks per workgroup (5 + 4), K = 9 slices (odd: one padding step)
-    (4, 80, 80, 128, 512, 3, 2, ops.ACT_SILU, False, 2),      # stride 2, two channel tiles, paired: 200 blocks over 64 spans (TM = 3 / 4), K = 18 slices
-    (2, 64, 64, 128, 256, 3, 1, ops.ACT_SILU, True, 1),       # 256 blocks over 256 spans: TM = 1 everywhere, residual
-    (16, 40, 40, 512, 512, 1, 1, ops.ACT_SILU, False, 1),     # 1x1, K = 8 slices, 800 blocks over 128 spans: TM = 6 / 7
-    (2, 33, 31, 320, 256, 1, 1, ops.ACT_NONE, True, 1),       # 1x1, K = 5 slices (odd: padding step), linear, residual, ragged M (2046 rows)
-    (2, 10, 10, 256, 1024, 1, 1, ops.ACT_GELU, False, 2),     # an MLP's fc1 (GELU epilogue), four channel tiles, paired: 7 blocks over 32 spans
-    (1, 9, 9, 512, 256, 1, 1, ops.ACT_SILU, False, 1),        # 81 pixels: 3 blocks for 256 workgroups (most spans empty)
-    (6, 80, 80, 128, 256, 3, 1, ops.ACT_SILU, True, 2),       # paired, 1200 blocks per stream over 128 spans = 9.4: chunks 5 + 4 / 5 + 5, residual, K = 18
-    (1, 13, 13, 320, 256, 3, 2, ops.ACT_NONE, False, 1),      # K = 45 slices (odd), stride 2, linear, 49 pixels
-]
-
-
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("case", PERS_CASES)
-def test_conv_persistent_long_k_kernel(case, dt):
-    """igemm_pers.hip (launch configuration 67: balanced spans of 32-pixel blocks, chunks of up to 256 pixels, one K-slice stream across chunk
-    boundaries, per-wave epilogue) BIT-EXACT vs the implicit-GEMM kernel and close to torch: span / chunk arithmetic (empty spans, one and two
-    chunks per workgroup, every TM), the zero-slice padding of odd K depths, stride 2, residuals, the paired launch, several channel tiles."""
-    B, H, W, cin, cout, k, st, act, use_res, G = case
-    p_ = k // 2
-    Ho, Wo = (H + 2 * p_ - k) // st + 1, (W + 2 * p_ - k) // st + 1
-    xs = [rnd((B, cin, H, W), 261 + g) for g in range(G)]
-    ws = [rnd((cout, cin, k, k), 263 + g, 1.0 / math.sqrt(cin * k * k)) for g in range(G)]
-    bs = [rnd((cout,), 265 + g, 0.2) for g in range(G)]
-    rs = [rnd((B, cout, Ho, Wo), 267 + g) for g in range(G)] if use_res else None
-    stk = (lambda t: torch.stack(t).contiguous()) if G == 2 else (lambda t: t[0])
-    xa = stk([to_act(x, dt) for x in xs])
-    packs = [ops.pack_conv_weight(w.to(DEV), dt) for w in ws]
-    wp, kp = stk([p0[0] for p0 in packs]), packs[0][1]
-    bp = stk([ops.pack_bias(b.to(DEV), cout) for b in bs])
-    ra = stk([to_act(r, dt) for r in rs]) if use_res else None
-    ldy = cout + 8
-    outs = []
-    for tile in (67, 2):
-        ybuf = torch.full((G, B, Ho, Wo, ldy) if G == 2 else (B, Ho, Wo, ldy), 7.0, dtype=dt, device=DEV)
-        y = ybuf[..., :cout]
-        run(ops.conv2d(xa, wp, kp, bp, y, k, k, st, st, p_, p_, cin, cout, act, res=ra, alpha_acc=0.75, alpha_res=1.25, tile=tile))
-        assert float((ybuf[..., cout:] - 7.0).abs().max()) == 0.0, "conv wrote outside its channel slice"
-        outs.append(y.clone())
-    assert torch.equal(outs[0], outs[1]), f"persistent kernel != igemm, max diff {(outs[0].float() - outs[1].float()).abs().max().item()}"
-    for g in range(G):
-        ref = F.conv2d(q(xs[g], dt), q(ws[g], dt), bs[g], st, p_)
-        ref = {ops.ACT_NONE: lambda t: t, ops.ACT_SILU: F.silu, ops.ACT_GELU: F.gelu}[act](ref) * 0.75
-        if use_res:
-            ref = ref + 1.25 * q(rs[g], dt)
-        close(from_act(outs[0][g] if G == 2 else outs[0]), ref, dt, f"pers {case} group {g}")
-
-
-def test_conv_persistent_kernel_rejects_what_it_is_not_built_for():
-    """Launch configuration 67 is an explicit request: a layer outside its build (Cout not in whole 256-channel tiles, fp32, a 3x3 GELU layer) is an
-    error with a reason — the tuner skips it — never a silent fall-back."""
-    x = torch.zeros((1, 8, 8, 128), dtype=torch.bfloat16, device=DEV)
-    for cout, act, k, dt in ((384, ops.ACT_SILU, 1, torch.bfloat16), (256, ops.ACT_GELU, 3, torch.bfloat16), (256, ops.ACT_SILU, 1, torch.float32)):
-        w = torch.zeros((cout, 128, k, k), device=DEV)
-        wp, kp = ops.pack_conv_weight(w, dt)
-        y = torch.zeros((1, 8, 8, cout), dtype=dt, device=DEV)
-        with pytest.raises(ops._lib.IcafError):
-            run(ops.conv2d(x.to(dt), wp, kp, ops.pack_bias(torch.zeros(cout, device=DEV), cout), y, k, k, 1, 1, k // 2, k // 2, 128, cout, act, tile=67))
 
 
 def test_frag_weights_layout():

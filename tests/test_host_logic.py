@@ -155,8 +155,6 @@ def test_pmc_summary_kernel_names_match_bench_names():
         "void icaf::igemm_wreg_kernel<2, 4, 0, 1, 1, 64>(icaf::ConvP, void const*, long long)": "igemm_wreg_f16_64x128",
         "void icaf::igemm_wreg_kernel<1, 4, 1, 1, 2, 64>(icaf::ConvP, void const*, long long)": "igemm_wreg_bf16_64x256",
         "void icaf::igemm_wreg_kernel<1, 8, 1, 1, 2, 128>(icaf::ConvP, void const*, long long)": "igemm_wreg_bf16_128x512",
-        "void icaf::igemm_pers_kernel<1, 1, 2>(icaf::ConvP, void const*, long long, int)": "igemm_pers_bf16_256x256",
-        "void icaf::igemm_pers_kernel<2, 0, 1>(icaf::ConvP, void const*, long long, int)": "igemm_pers_f16_256x256",
         "void icaf::detect_conv_kernel<1, 3, 6>(icaf::ConvP, icaf::DetectEpi<3, 6>)": "detect_conv+decode",
         "void icaf::detect_decode_kernel<true>(float const*, int, float*)": "detect_decode",
         "void icaf::upsample_kernel<true>(unsigned int __vector(4) const*, int)": "upsample_nearest",
@@ -175,8 +173,6 @@ def test_pmc_summary_kernel_names_match_bench_names():
         "void icaf::cwide_kernel<1, 128, 1, 2, true>(icaf::ConvP, icaf::CwGeom, void const*, long long)": "cwide_bf16_8x8n128",
         "void icaf::cwide_kernel<2, 64, 2, 2, true>(icaf::ConvP, icaf::CwGeom, void const*, long long)": "cwide_f16_8x8n128s2c64",
         "void icaf::cwide_kernel<1, 128, 2, 2, false>(icaf::ConvP, icaf::CwGeom, void const*, long long)": "cwide_bf16_8x8n128s2",
-        "void icaf::cwpers_kernel<1, 128, 2, 1, 8, 8, false>(icaf::ConvP, icaf::CpGeom, void const*, long long)": "cwpers_bf16_8x8n256s2",
-        "void icaf::cwpers_kernel<1, 128, 1, 1, 4, 4, false>(icaf::ConvP, icaf::CpGeom, void const*, long long)": "cwpers_bf16_8x8n128w4",
         "void icaf::dmff_wide_ln_qkv_kernel<1>(icaf::WideP)": "dmff_ln_qkv",
         "void icaf::dmff_wide_proj_mlp_kernel<2, 2>(icaf::WideP)": "dmff_proj_mlp",
     }
@@ -334,3 +330,25 @@ def test_rank_cpu_affinity_follows_the_gpus_numa_node(tmp_path):
     a, ca, b, cb = json.loads(r.stdout.strip().splitlines()[-1])
     assert a["pinned"] and a["numa_node"] == 1 and ca == [c for c in half if c in allowed]
     assert b["pinned"] and b["numa_node"] is None and cb == allowed[len(allowed) // 2:]
+
+
+def test_plan_options_are_one_object_filled_from_one_variable():
+    """options.PlanOptions: every execution switch is a field; ICAF_OPTIONS (field=value, comma-separated) fills them, the legacy per-switch variables
+    still work, an unknown name is an error (a misspelt switch must not silently run the default), and the library's probe knobs go through
+    icaf_set_option — the C side reads no environment variable."""
+    from icafusion_amd.options import PlanOptions
+    d = PlanOptions()
+    assert d.non_default() == {} and d.dmff_fuse and d.retune_tiles == frozenset()
+    o = PlanOptions.from_env({"ICAF_OPTIONS": "dmff_fuse=0,retune_tiles=63:64, pipe_copy_prio=0", "ICAF_DMFF_WIDE": "0", "ICAF_RETUNE_TILES": "61,62"})
+    assert o.non_default() == {"dmff_fuse": False, "dmff_wide": False, "retune_tiles": [63, 64], "pipe_copy_prio": 0}      # ICAF_OPTIONS wins over a legacy name
+    with pytest.raises(ValueError):
+        PlanOptions.from_env({"ICAF_OPTIONS": "dmff_fuze=0"})
+    assert set(o.lib_options()) == {"detect_elementwise", "attn_qsplit", "sppf_vpb"}
+    l = _lib.lib()
+    assert l.icaf_set_option(b"attn_qsplit", 0) == 0 and l.icaf_set_option(b"no_such_knob", 1) != 0 and b"unknown option" in l.icaf_last_error()
+    src = os.path.join(REPO, "icafusion_amd")
+    for root, _, files in os.walk(src):                      # one place: no other module of the package reads an ICAF_* switch from the environment
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")) and f not in ("options.py", "build.py", "_lib.py"):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"environ[^\n]*ICAF_|getenv\(\"ICAF_(?!S2_CLK)", text), f

@@ -122,12 +122,12 @@ def test_fragment_major_weight_copy_layout():
 
 
 def test_resident_patch_kernel_shape_table():
-    """ops.cwide_shapes: which cwide.hip / cwpers.hip launch configurations exist for a 3x3 layer (the tuner only offers these)."""
+    """ops.cwide_shapes: which cwide.hip launch configurations exist for a 3x3 layer (the tuner only offers these)."""
     from icafusion_amd import ops
     s = ops.cwide_shapes
-    assert s(3, 3, 1, 1, 1, 1, 128, 128) == [81, 82, 91, 95]
-    assert s(3, 3, 2, 2, 1, 1, 64, 128) == [83, 85, 92, 96] and s(3, 3, 2, 2, 1, 1, 64, 256) == [83, 85, 92, 96]
-    assert s(3, 3, 2, 2, 1, 1, 128, 128) == [84, 94] and s(3, 3, 2, 2, 1, 1, 128, 256) == [84, 94, 93]
+    assert s(3, 3, 1, 1, 1, 1, 128, 128) == [81, 82]
+    assert s(3, 3, 2, 2, 1, 1, 64, 128) == [83, 85] and s(3, 3, 2, 2, 1, 1, 64, 256) == [83, 85]
+    assert s(3, 3, 2, 2, 1, 1, 128, 128) == [84] and s(3, 3, 2, 2, 1, 1, 128, 256) == [84]
     for bad in ((1, 1, 1, 1, 0, 0, 128, 128), (3, 3, 1, 1, 1, 1, 128, 64), (3, 3, 1, 1, 1, 1, 256, 256), (3, 3, 1, 1, 0, 0, 128, 128),
                 (3, 3, 2, 1, 1, 1, 64, 128), (3, 3, 2, 2, 1, 1, 32, 128), (3, 3, 1, 1, 1, 1, 64, 128)):
         assert s(*bad) == []
@@ -138,7 +138,7 @@ def test_resident_patch_kernel_shape_table():
 
 def test_c3_tail_launch_configurations_follow_the_map_size():
     """ops.conv_candidates for a C3 tail (cv3 chained behind the last Bottleneck's 3x3, icaf_conv_args.x2): only cwide.hip's two forms, and below
-    TAIL_8X16_MINPIX pixels per stream only the 8 x 8 form (the 8 x 16 form wins isolated timings there and loses the bench: docs/HISTORY.md section 15);
+    OPT.tail_8x16_minpix pixels per stream only the 8 x 8 form (the 8 x 16 form wins isolated timings there and loses the bench: docs/HISTORY.md section 15);
     the tuner signature keeps tails apart from chain_keep launches of the same shape."""
     from types import SimpleNamespace
 

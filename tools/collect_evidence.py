@@ -12,14 +12,15 @@ CFG = {"c3": "c3_l_bf16_b32_640", "c4": "c4_s_bf16_b64_512x640_loops3", "c5": "c
 pairs = [("bench.json", f"{tag}_bench_s_bf16_b32.json"), ("prof_default_kernel_stats.csv", f"{tag}_bench_s_bf16_b32_kernel_stats.csv"),
          ("prof_depth1_kernel_stats.csv", f"{tag}_bench_s_bf16_b32_depth1_kernel_stats.csv"),
          ("layer_profile.txt", f"{tag}_layer_profile_s_bf16_b32.txt"), ("layer_profile_plain.txt", f"{tag}_layer_profile_s_bf16_b32_dmff_per_layer.txt"),
-         ("pmc_sq_summary_default.json", f"{tag}_pmc_sq_mfma_util.json"), ("pmc_sq_insts_default.json", f"{tag}_pmc_sq_insts.json"),
-         ("pmc_sq_summary_c3.json", f"{tag}_pmc_sq_mfma_util_{CFG['c3']}.json"), ("pmc_sq_insts_c3.json", f"{tag}_pmc_sq_insts_{CFG['c3']}.json"),
-         ("pmc_sq_summary_c3_pers.json", f"{tag}_pmc_sq_mfma_util_{CFG['c3']}_with_igemm_pers.json"),
-         ("pmc_sq_insts_c3_pers.json", f"{tag}_pmc_sq_insts_{CFG['c3']}_with_igemm_pers.json"),
-         ("pmc_summary.json", "pmc_traffic.json"), ("parity_16bit.json", "parity_16bit.json")]
+         # the SQ passes (merged: MFMA busy, VALU issue, wave-parked fractions, instruction mix): the CURRENT summary bench.py reads + the round's copy
+         ("pmc_sq_merged.json", "pmc_sq.json"), ("pmc_sq_merged.json", f"{tag}_pmc_sq.json"),
+         ("pmc_summary.json", "pmc_traffic.json"), ("parity_16bit.json", "parity_16bit.json"),
+         ("bench_fp32.json", f"{tag}_bench_s_fp32_b32.json"), ("bench_driver_form.json", f"{tag}_bench_driver_form.json"),
+         ("bench_force_gather.json", f"{tag}_bench_force_gather.json")]
 for k, n in CFG.items():
     pairs += [(f"bench_{n}.json", f"{tag}_bench_{n}.json"), (f"prof_{n}_kernel_stats.csv", f"{tag}_bench_{n}_kernel_stats.csv"),
-              (f"pmc_summary_{n}.json", f"pmc_traffic_{n}.json")]
+              (f"pmc_summary_{n}.json", f"pmc_traffic_{n}.json"), (f"pmc_sq_merged_{n}.json", f"pmc_sq_{n}.json"), (f"pmc_sq_merged_{n}.json", f"{tag}_pmc_sq_{n}.json"),
+              (f"layer_profile_{n}.txt", f"{tag}_layer_profile_{n}.txt")]
 done = []
 for src, dst in pairs:
     s = os.path.join(G, src)

@@ -59,7 +59,7 @@ for w in $WORKLOADS; do
     trace default
     trace depth1 --depth 1 --no-overlap
     cd $R && timeout 300 python tools/layer_profile.py --autotune > gpurun_out/layer_profile.txt 2>/dev/null; head -1 gpurun_out/layer_profile.txt
-    cd $R && ICAF_DMFF_FUSE=0 timeout 300 python tools/layer_profile.py --autotune > gpurun_out/layer_profile_plain.txt 2>/dev/null; head -1 gpurun_out/layer_profile_plain.txt
+    cd $R && ICAF_OPTIONS=dmff_fuse=0 timeout 300 python tools/layer_profile.py --autotune > gpurun_out/layer_profile_plain.txt 2>/dev/null; head -1 gpurun_out/layer_profile_plain.txt
     [ "$PARITY" = 1 ] && { timeout 1200 python tools/parity16.py --out gpurun_out/parity_16bit.json > gpurun_out/parity16.log 2>&1; tail -1 gpurun_out/parity16.log | cut -c1-200; }
   else
     cp $R/profiles/tune_cache_$name.json /tmp/tune_$name.json       # (a re-tune inside the call edits the copy; it is brought back as gpurun_out/tune_cache_<name>.json)
@@ -68,10 +68,6 @@ for w in $WORKLOADS; do
     [ "${SQ:-1}" = 1 ] && sq $name $ARGS
     cd $R && timeout 1200 python bench.py $ARGS > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err; line $name gpurun_out/bench_$name.json
     trace $name $ARGS
-    if [ "$w" = c3 ] && [ "$PERS_SQ" = 1 ]; then      # the persistent long-K GEMM (opt-in, launch configuration 67) under the same counters: its own retuned cache copy
-      cp $R/profiles/tune_cache_$name.json /tmp/tune_pers.json
-      ICAF_PERS_GEMM=1 ICAF_RETUNE_TILES=67 sq c3_pers --model l --batch 32 --tune-cache /tmp/tune_pers.json; rm -f profiles/pmc_sq_c3_pers.json
-    fi
     cp /tmp/tune_$name.json gpurun_out/tune_cache_$name.json
   fi
 done

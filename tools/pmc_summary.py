@@ -34,9 +34,6 @@ def short(name):
         tn, bm = int(m.group(3) or 1), int(m.group(4) or 128)
         tag = {(4, 1, 128): "128x128", (8, 1, 128): "128x256", (8, 2, 128): "128x512", (4, 2, 128): "128x256w4", (4, 2, 64): "64x256", (4, 1, 64): "64x128"}.get((nwv, tn, bm), f"{bm}x{32 * nwv * tn}")
         return f"igemm_wreg_{_DN[dt]}_{tag}"                                    # (= wreg_tag() of igemm_wreg.hip, what bench.py reports)
-    m = re.match(r"icaf::igemm_pers_kernel<(\d+), \d+, \d+>", name)            # persistent long-K GEMM (DT, ACT, MODE)
-    if m:
-        return f"igemm_pers_{_DN[int(m.group(1))]}_256x256"
     m = re.match(r"icaf::cstream_kernel<(\d+), (true|false)>", name)              # persistent 3x3, filter resident in LDS
     if m:
         return f"cstream_{_DN[int(m.group(1))]}_8x16n64"                        # (with or without the chained 1x1: one name, as bench.py reports it)
@@ -44,10 +41,6 @@ def short(name):
     if m:
         dt, cin, st, nsub = map(int, m.groups())
         return f"cwide_{_DN[dt]}_8x{16 if nsub == 4 else 8}n128" + ("s2" if st == 2 else "") + ("c64" if cin == 64 else "")
-    m = re.match(r"icaf::cwpers_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, \w+)*>", name)
-    if m:
-        dt, cin, st, tws, ncg, nw = map(int, m.groups())
-        return f"cwpers_{_DN[dt]}_8x{8 * tws}n{32 * ncg}" + ("s2" if st == 2 else "") + ("c64" if cin == 64 else "") + ("w4" if nw == 4 else "")
     if name.startswith("icaf::detect_conv_kernel<"):
         return "detect_conv+decode"
     m = re.match(r"icaf::igemm_kernel<(\d+), (\d+), (\d+), (\d+),", name)
