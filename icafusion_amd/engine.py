@@ -40,6 +40,7 @@ class Plan:
         # on their own capture stream, i.e. as a parallel branch of the hipGraph: small latency-bound kernels (DMFF of
         # the shallow levels) fill the CUs the backbone's tails leave idle.  Eager replay ignores branches.
         self.branches = {}
+        self.notes = {}         # plan-build facts that launch names do not show (fusion_report reads them)
 
     # -- buffers ------------------------------------------------------------------------------------------
     def act(self, B, H, W, C, dtype=None, pair=False):
@@ -137,7 +138,11 @@ class Plan:
                 "bottleneck_fused": sum(1 for x in names if x.startswith("bottleneck")), "c3_tails": sum(1 for x in names if x.endswith("+cv3")),
                 "chained_1x1": sum(1 for x in names if x.endswith("+1x1") and not x.startswith("stem")),
                 "dmff_blocks": dmff.strip("+") or "none", "dmff_levels_three_launch": n("dmff_proj_mlp"), "dmff_levels_per_layer": n("mlp_fc1"),
-                "detect": "conv+decode fused" if n("detect_conv+decode") else "conv, decode"}
+                "detect": "conv+decode fused" if n("detect_conv+decode") else "conv, decode",
+                # loops > 1: which DMFF levels (by C) carry the residual token stream in fp32 from one iteration to the next, and which round it to
+                # the storage type twice per iteration (not built: the two-launch form, C = 512 without a hidden split, the per-layer form) — a mixed
+                # configuration is visible here instead of in a parity margin
+                "dmff_fp32_token_stream": self.notes.get("dmff_fp32_token_stream")}
 
     def timed_run(self, stream_ptr=None):
         """Run launch by launch with a HIP event pair around every kernel; returns [(name, ms, flops, bytes)]."""

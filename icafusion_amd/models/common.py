@@ -801,6 +801,8 @@ class CrossTransformerBlock(HipModule):
                 nxt = final_out if (final_out is not None and it == nloops - 1) else plan.tokens(2, rows, C)
                 plan.add(ops.dmff_attn_mlp(tok, qkv, nxt, p, ln, coef, p["eps"], B, N, self.crossatt.h))
                 tok = nxt
+            if nloops > 1 and plan.dtype != torch.float32:
+                plan.notes.setdefault("dmff_fp32_token_stream", {})[f"C={C}"] = False
             return tok
         if self.wide_fusable(plan, C):
             # wide levels (C = 256 / 512): LayerNorm + QKV, attention, out-projection + LayerNorm + MLP — three launches; x_att, the
@@ -815,6 +817,8 @@ class CrossTransformerBlock(HipModule):
             # margin of the 3-iteration configuration (0.91 x the reference's own bf16 error)
             r32 = self.res32 and nloops > 1 and plan.dtype != torch.float32 and ks in (1, 2) and not (C == 512 and ks == 1)      # (not built: dmff_wide.hip)
             t32 = [plan.empty((2, rows, C), torch.float32) for _ in range(2)] if r32 else None
+            if nloops > 1:
+                plan.notes.setdefault("dmff_fp32_token_stream", {})[f"C={C}"] = bool(r32)
             for it in range(nloops):
                 plan.add(ops.dmff_wide_ln_qkv(tok, qkv, p, ln, coef, p["eps"], B, N, self.crossatt.h))
                 plan.add(ops.cross_attention(qkv, att, B, N, self.crossatt.h))
@@ -825,6 +829,8 @@ class CrossTransformerBlock(HipModule):
                     plan.add(l)
                 tok = nxt
             return tok
+        if nloops > 1 and plan.dtype != torch.float32:
+            plan.notes.setdefault("dmff_fp32_token_stream", {})[f"C={C}"] = False
         for it in range(nloops):
             n1 = plan.tokens(2, rows, C)
             plan.add(ops.layernorm(tok, n1, ln["a1w"], ln["a1b"], ln["a2w"], ln["a2b"], p["eps"][0], name="ln_attn"))
