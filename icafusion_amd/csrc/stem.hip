@@ -263,7 +263,16 @@ __global__ __launch_bounds__(NTHREADS) void stem_kernel(const StemP q) {
 //            tile staged in LDS exactly as igemm's CHAIN stages it;
 //   stage 3  the chained 1x1 (K = 64) and the shared epilogue writing only y.
 // Every stage repeats the K order, MFMA step and rounding points of the kernel it replaces, so y is bit-identical to
-// icaf_stem -> icaf_conv2d(chained) (tested).  LDS: 28 KiB + 45 KiB patches + 60 KiB weights = 133 KiB, one workgroup
+// icaf_stem -> icaf_conv2d(chained) (tested).
+//
+// Round 6, what bounds it (lab/probes/valu_rate_probe.hip, stem2_phases.py, -DICAF_S2_FAKEJOBS): instruction ISSUE.  One wave issues
+// a plain VALU instruction every 5.4 cycles and a transcendental every 8.75; two waves per SIMD (all this kernel's 247 registers allow) reach 2.7 / 6.5 per
+// SIMD, four would reach 1.8 / 4.8.  The launch issues ~88 k instructions per SIMD (57.5 M VALU of which 14.3 M v_exp / v_rcp — SiLU's two
+// transcendentals per value — 13.8 M SALU, 9.1 M LDS, 4.4 M MFMA per launch): ~320 k cycles at those rates against 470 k measured.  A producer /
+// consumer split of the waves (stage 1 on waves 0-3, stages 2 + 3 on waves 4-7, two halo patches, two barriers per tile instead of five) was built,
+// bit-identical on first run, and measured SLOWER (352 vs 330 us alone): with 19 stage-1 jobs on four waves a producer wave issues five jobs back to
+// back at ~1,900 cycles each and the tile waits for it — the work per SIMD is the same ~9 SiLU units either way, and the two-barrier schedule only
+// exchanged barrier waits for a longer critical wave.  (commit f26bb5f: "stem2, producer / consumer form".)  LDS: 28 KiB + 45 KiB patches + 60 KiB weights = 133 KiB, one workgroup
 // per CU; the patch walk is XCD-aware like the stem's.
 constexpr int S2_TH = 4, S2_TW = 32;                                   // tile of the 3x3/s2 layer's output pixels
 constexpr int S2_HH = 2 * S2_TH + 1, S2_HWD = 2 * S2_TW + 1;           // stem-output halo patch: 9 x 65 pixels
@@ -308,7 +317,7 @@ struct Stem2P {
 // prefetch + commit of a tile was 19 % of this kernel.)
 #ifdef ICAF_S2_CLK
 constexpr int S2_CLK_TILES = 16, S2_CLK_N = 12;
-#define S2_STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && clk_tile >= 0 && clk_tile < S2_CLK_TILES) q.clk[(wave * S2_CLK_TILES + clk_tile) * S2_CLK_N + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define S2_STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && clk_tile < S2_CLK_TILES) q.clk[(wave * S2_CLK_TILES + clk_tile) * S2_CLK_N + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define S2_STAMP(i) do { } while (0)
 #endif
@@ -668,420 +677,6 @@ __global__ __launch_bounds__(S2_THREADS) void stem2_kernel(const Stem2P q) {
 }
 
 
-// ===============================================================================================================
-// stem2, producer / consumer form (round 6): the SAME arithmetic as stem2_kernel, dealt to two teams of four wavefronts
-// ===============================================================================================================
-// stem2_kernel runs its four stages one after the other with all eight waves in each, five workgroup barriers per tile.  Its phase clocks and a
-// job-count probe (lab/probes/stem2_phases.py, -DICAF_S2_FAKEJOBS) say where the time goes: after every barrier the two waves of a SIMD start the
-// same segment together — both issue their MFMA chain (the matrix pipe is shared: VALU idle), then both their SiLU epilogue (VALU shared: matrix
-// pipe idle).  A second round of stage-1 jobs in that lock-step costs 2,150 cycles per SIMD, a THIRD round, once the two waves have drifted apart,
-// 925.  So: fewer barriers, and two waves per SIMD that never do the same thing at the same time —
-//   * waves 0-3, the PRODUCERS, own stage 1: the stem GEMM + SiLU over the 9 x 65 stem pixels of tile t + 1 (19 jobs of 32 pixels, five per wave
-//     back to back, the next job's fragment reads in flight under the current job's epilogue), written to halo patch (t + 1) & 1;
-//   * waves 4-7, the CONSUMERS, own stages 2 and 3 of tile t: wave c = output row c of the tile x all 64 channels (two accumulators, one patch
-//     fragment feeds two MFMAs), then the SiLU, the chained 1x1 (its weights in registers) from a staging row that is PRIVATE to the wave — halo
-//     row 2 c + 1 of the patch it has just consumed, the one row no other wave reads; a wave's LDS operations execute in order: no barrier — and
-//     the row's stores;
-//   * waves w and w + 4 share a SIMD: a VALU-bound producer beside a consumer that alternates MFMA chains and epilogues;
-//   * two halo patches (2 x 45 KiB: the stem's weights moved to registers and the staging tiles into the consumed patch to make room), so the
-//     teams meet at TWO barriers per tile: one after the image patch of tile t + 1 has been committed to LDS (all pair threads), one at the end.
-// Per-pixel results are the same expressions in the same order as stem2_kernel (and therefore as icaf_stem -> icaf_conv2d): bit-identical, tested.
-constexpr int S2P_NB = S2_C0 + S2_C1 + S2_C2;                            // bias floats per stream: stem | 3x3 | 1x1 (both streams stay resident)
-constexpr int S2P_LDS = S2_S2D_BYTES + 2 * S2_HALO_BYTES + S2_W1_SLICES * S2_C1 * 128 + 2 * S2P_NB * 4;
-static_assert(S2P_LDS <= 160 * 1024, "stem2 producer / consumer form: LDS");
-static_assert(S2_TW * (S2_C1 * 2 + 16) <= S2_PITCH * 64, "a consumer's staging row fits one halo row");
-
-template <int DT, bool U8, bool PAIR>
-__global__ __launch_bounds__(S2_THREADS) void stem2pc_kernel(const Stem2P q) {
-    using E = Elem<DT>;
-    static_assert(DT != ICAF_F32, "16-bit types");
-    constexpr int RB = 128, C0 = S2_C0, C1 = S2_C1, C2 = S2_C2;
-    constexpr int SO = C1 * E::BYTES + 16;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    unsigned char* s2d = lds;
-    unsigned char* halo0 = lds + S2_S2D_BYTES;                             // halo patch b at halo0 + b * S2_HALO_BYTES
-    unsigned char* w1b = halo0 + 2 * S2_HALO_BYTES;                        // 5 slices x C1 rows x 128 bytes
-    float* bl = (float*)(w1b + S2_W1_SLICES * C1 * RB);                    // [stream][stem 32 | 3x3 64 | 1x1 64] bias floats
-
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool consumer = wave >= 4;
-    const int tw = wave & 3;                                               // index inside the team; consumers: output row of the tile
-    const ConvP& p = q.c;
-
-    auto decode = [&](const TileWalk& t, int& stream, int& b, int& y0, int& x0) {
-        stream = t.img >= q.B;
-        b = t.img - (stream ? q.B : 0);
-        y0 = t.ty * S2_TH;
-        x0 = t.tx * S2_TW;
-    };
-    // ---- image patch: global -> registers (one tile ahead) -> LDS.  As stem2_kernel: every thread of the workgroup takes part ---------------
-    auto entry_rc = [&](int e, int& sr, int& sc) {
-        sr = e / S2_SPITCH;
-        const int rem = e - sr * S2_SPITCH, pl = rem >= S2_SHALF;
-        sc = 2 * (rem - pl * S2_SHALF) + pl;
-    };
-    int sr0, sc0, sr1, sc1;
-    entry_rc(tid, sr0, sc0);
-    entry_rc(min(tid + S2_THREADS, S2_NS - 1), sr1, sc1);
-    if (sc0 >= S2_SC) sr0 = -0x10000;
-    if (sc1 >= S2_SC) sr1 = -0x10000;
-    RawEntry<U8> v0, v1;
-    auto fetch_single = [&](const TileWalk& t) {
-        int stream, b, y0, x0;
-        decode(t, stream, b, y0, x0);
-        load_entry<U8>(q, stream, b, 2 * y0 - 2 + sr0, 2 * x0 - 2 + sc0, v0);
-        load_entry<U8>(q, stream, b, 2 * y0 - 2 + sr1, 2 * x0 - 2 + sc1, v1);
-    };
-    auto commit_single = [&]() {
-        store_entry<DT, U8>(s2d, tid, v0);
-        if (tid + S2_THREADS < S2_NS) store_entry<DT, U8>(s2d, tid + S2_THREADS, v1);
-    };
-    constexpr int S2_NPAIR = S2_SR * S2_SPAIRS;                            // 374
-    const int psr = tid / S2_SPAIRS, pk = tid - psr * S2_SPAIRS;
-    float4 pr[PAIR ? 6 : 1];
-    bool pin0 = false, pin1 = false;
-    auto fetch_pair = [&](const TileWalk& t) {
-        if (tid >= S2_NPAIR) return;
-        int stream, b, y0, x0;
-        decode(t, stream, b, y0, x0);
-        const int hh = q.H >> 1, hw = q.W >> 1;
-        const int gy = 2 * y0 - 2 + psr, gx = 2 * x0 - 2 + 2 * pk;
-        const bool iny = (unsigned)gy < (unsigned)hh;
-        pin0 = iny && (unsigned)gx < (unsigned)hw && 2 * pk < S2_SC;
-        pin1 = iny && (unsigned)(gx + 1) < (unsigned)hw && 2 * pk + 1 < S2_SC;
-        const int cy = min(max(gy, 0), hh - 1), cx = min(max(gx, 0), hw - 2);
-        const long long plane = (long long)q.H * q.W;
-        const unsigned off = (unsigned)(2 * cy) * (unsigned)q.W + (unsigned)(2 * cx);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float* base = (const float*)q.img + ((long long)(stream * q.B + b) * 3 + c) * plane;
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy) pr[PAIR ? c * 2 + dy : 0] = *(const float4*)(base + off + (unsigned)(dy * q.W));
-        }
-    };
-    auto commit_pair = [&]() {
-        if (tid >= S2_NPAIR) return;
-        if constexpr (!U8) {
-            RawEntry<false> e0, e1;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const float4 v = pr[PAIR ? i : 0];
-                e0.r[i] = float2{v.x, v.y};
-                e1.r[i] = float2{v.z, v.w};
-            }
-            e0.in = pin0; e1.in = pin1;
-            store_entry<DT, false>(s2d, psr * S2_SPITCH + pk, e0);
-            store_entry<DT, false>(s2d, psr * S2_SPITCH + S2_SHALF + pk, e1);
-        }
-    };
-    auto fetch = [&](const TileWalk& t) { if constexpr (PAIR) fetch_pair(t); else fetch_single(t); };
-    auto commit = [&]() { if constexpr (PAIR) commit_pair(); else commit_single(); };
-
-    // ---- the consumers' LDS-resident data: the 3x3 layer's weights (igemm's swizzle, 8 rows per DMA instruction) and both bias vectors; every
-    //      wave of the workgroup issues its share of the copy; the biases of BOTH streams are resident from the prologue on ------------------------
-    auto load_consumer_lds = [&](int stream) {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)((const typename E::type*)p.w + stream * p.w_gs), 0, (unsigned)(C1 * p.Kp * 2), 0x00020000);
-        const int rs8 = lane >> 3, per = C1 >> 3;
-        for (int t = wave; t < S2_W1_SLICES * per; t += S2_THREADS / 64) {
-            const int c = t / per, j = t - c * per;
-            const int sl = (lane & 7) ^ (((j & 1) << 2) | (rs8 >> 1));
-            const unsigned voff = ((unsigned)(j * 8 + rs8) * (unsigned)p.Kp + (unsigned)(c * 64 + sl * 8)) * 2u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(w1b + (c * C1 + j * 8) * RB), 16, voff, 0, 0, 0);
-        }
-        wait_vmcnt<0>();
-    };
-
-    // ---- this workgroup's tiles (XCD-contiguous walk, as stem2_kernel) ------------------------------------------------------------------
-    const int xcd = blockIdx.x & 7, per_xcd = (q.npatch + 7) >> 3, pstride = gridDim.x >> 3;
-    const int pend = min((xcd + 1) * per_xcd, q.npatch);
-    const int pt0 = xcd * per_xcd + (blockIdx.x >> 3);
-    if (pt0 >= pend) return;
-    const int ntile = (pend - pt0 + pstride - 1) / pstride;
-    TileWalk t_cur, t_nxt, t_ftc;                                          // tile k (consumers), k + 1 (producers), k + 2 (image prefetch)
-    t_cur.init(pt0, pstride, q.tiles_x, q.tiles_y);
-    t_nxt = t_cur;
-
-    const int fkey = (l31 >> 1) & 7;
-    int foff[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) foff[s] = l31 * RB + (((2 * s + hi) ^ fkey) << 4);
-
-    // prologue: patch of tile 0 -> LDS, patch of tile 1 in flight
-    fetch(t_cur);
-    commit();
-    t_ftc = t_cur;
-    if (ntile > 1) { t_nxt.next(); t_ftc = t_nxt; fetch(t_nxt); }
-    int wstream;
-    {
-        int b, y0, x0;
-        decode(t_cur, wstream, b, y0, x0);
-        if (tid < 2 * S2P_NB) {
-            const int st = tid >= S2P_NB && q.nstreams > 1, i = tid - (tid >= S2P_NB ? S2P_NB : 0);
-            bl[tid] = i < C0 ? q.bias0[st * q.bias0_gs + i] : i < C0 + C1 ? p.bias[st * p.bias_gs + i - C0]
-                                                                          : (i - C0 - C1 < p.Cout2 ? p.bias2[st * p.bias2_gs + i - C0 - C1] : 0.0f);
-        }
-        load_consumer_lds(wstream);
-    }
-    // The tile loop starts at k = -1: an iteration whose only work is the producers' stage 1 of tile 0 (its patch was committed above).
-
-    if (!consumer) {
-        // =========================================================== PRODUCERS =============================================================
-        constexpr int NJOBS = (S2_NL + 31) / 32, JPW = (NJOBS + 3) / 4;        // 19 jobs, five per wave
-        u32x4 fw0[9];
-        int pstream = -1;
-        auto load_stem_weights = [&](int stream) {                              // fragments straight from the K-major matrix: row l31, K = 16 tap + 8 hi
-            int lo = l31 * q.Kp0 + 8 * hi;
-            asm volatile("" : "+v"(lo));            // (a path taken twice in a workgroup's life: its addresses are NOT to be hoisted into registers of the tile loop)
-            const typename E::type* w0 = (const typename E::type*)q.w0 + stream * q.w0_gs + lo;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) fw0[tap] = *(const u32x4*)(w0 + 16 * tap);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) asm volatile("" : "+v"(fw0[tap]));
-            pstream = stream;
-        };
-        // fragment addresses of a job's lane: tap (0, kx) of its stem pixel; tap row ky: + ky * S2_SPITCH entries
-        // (l31v: the lane index behind an opaque copy made once per TILE — computed from l31 itself, the addresses of all five jobs are loop
-        //  invariants and get hoisted into ~45 registers of the tile loop, which then spills)
-        auto rd_addr = [&](int job, int l31v, int (&rd)[3]) {
-            const int lidx = (job << 5) + l31v, lc = lidx < S2_NL ? lidx : 0;
-            const int hy = (lc * 993) >> 16, rem = lc - hy * S2_LPITCH, pl = rem >= S2_LHALF, i = rem - pl * S2_LHALF;      // lc / 66 (exact below 1024)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int sc = 2 * i + pl + kx;
-                const int e = hy * S2_SPITCH + (sc & 1) * S2_SHALF + (sc >> 1);
-                rd[kx] = ((e << 1) + (hi ^ ((e >> 3) & 1))) << 4;
-            }
-        };
-        for (int k = -1; k < ntile; ++k) {
-#ifdef ICAF_S2_CLK
-            const int clk_tile = k;
-#endif
-            S2_STAMP(0);
-            if (k >= 0) {
-                int stream, b, y0, x0;
-                decode(t_cur, stream, b, y0, x0);
-                if (stream != wstream) {           // the consumers' stream changes (workgroup-uniform: every wave takes part in the copy and its barriers)
-                    lds_barrier();
-                    load_consumer_lds(stream);
-                    lds_barrier();
-                    wstream = stream;
-                }
-                if (k + 1 < ntile) commit();       // patch of tile k + 1 -> LDS
-                if (k + 2 < ntile) { t_ftc.next(); fetch(t_ftc); }
-            }
-            S2_STAMP(1);
-            lds_barrier();                         // (a) patch k + 1 visible (k = -1: the prologue's patch, the weights, the biases)
-            S2_STAMP(2);
-            if (k + 1 < ntile) {
-                // ---- stage 1 of tile k + 1 -> halo patch (k + 1) & 1 ------------------------------------------------------------------------
-                const TileWalk& t = k < 0 ? t_cur : t_nxt;
-                unsigned char* halo = halo0 + ((k + 1) & 1) * S2_HALO_BYTES;
-                int stream, b, y0, x0;
-                decode(t, stream, b, y0, x0);
-                if (stream != pstream) load_stem_weights(stream);
-                const float* b0 = bl + stream * S2P_NB + 4 * hi;                // the stem's bias: 16 floats per lane, read back per job
-                const int sy0 = 2 * y0 - 1, sx0 = 2 * x0 - 1;
-                u32x4 fp[2][9];
-                int rd[3];
-                int l31v = l31;
-                asm volatile("" : "+v"(l31v));
-                rd_addr(tw, l31v, rd);
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) fp[0][tap] = *(const u32x4*)(s2d + rd[tap % 3] + (tap / 3) * (S2_SPITCH * 32));
-#pragma unroll
-                for (int jj = 0; jj < JPW; ++jj) {
-                    const int job = tw + 4 * jj;
-                    if (job >= NJOBS) break;                                    // (wave-uniform)
-                    f32x16 a0;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) a0[r] = 0.0f;
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) mma_step<DT>(a0, fw0[tap], fp[jj & 1][tap]);
-                    if (jj + 1 < JPW && job + 4 < NJOBS) {                      // the next job's fragments travel under this job's epilogue
-                        rd_addr(job + 4, l31v, rd);
-#pragma unroll
-                        for (int tap = 0; tap < 9; ++tap) fp[(jj + 1) & 1][tap] = *(const u32x4*)(s2d + rd[tap % 3] + (tap / 3) * (S2_SPITCH * 32));
-                    }
-                    f32x4 b0v[4];
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) b0v[qd] = *(const f32x4*)(b0 + 8 * qd);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int lidx = (job << 5) + l31v, lc = lidx < S2_NL ? lidx : 0;
-                    const int hy = (lc * 993) >> 16, rem = lc - hy * S2_LPITCH, pl = rem >= S2_LHALF, i = rem - pl * S2_LHALF, hx = 2 * i + pl;
-                    const int idx = hy * S2_PITCH + pl * S2_HALF + i;
-                    const int wr = (lidx < S2_NL && hx < S2_HWD) ? (idx << 6) + (hi << 3) : -1;      // (the phantom odd slot of a row is never stored: see stem2_kernel)
-                    const int key = (idx >> 2) & 3;
-                    const bool inside = hx < S2_HWD && (unsigned)(sy0 + hy) < (unsigned)q.Hs && (unsigned)(sx0 + hx) < (unsigned)q.Ws;
-                    if (wr >= 0) {
-#pragma unroll
-                        for (int qd = 0; qd < 4; ++qd) {
-                            float v[4] = {0.f, 0.f, 0.f, 0.f};
-                            if (inside) {
-                                const float x[4] = {a0[4 * qd] + b0v[qd][0], a0[4 * qd + 1] + b0v[qd][1], a0[4 * qd + 2] + b0v[qd][2], a0[4 * qd + 3] + b0v[qd][3]};
-                                silu4_f(x, v);
-                            }
-                            u32x2 pk2;
-                            if constexpr (DT == ICAF_BF16) { pk2[0] = pack2_bf16(v[0], v[1]); pk2[1] = pack2_bf16(v[2], v[3]); }
-                            else { pk2[0] = pack2_f16(v[0], v[1]); pk2[1] = pack2_f16(v[2], v[3]); }
-                            *(u32x2*)(halo + wr + ((qd ^ key) << 4)) = pk2;
-                        }
-                    }
-                }
-            }
-            S2_STAMP(6);
-            lds_barrier();                         // (b) halo patch k + 1 complete, halo patch k consumed
-            S2_STAMP(7);
-            if (k >= 0) { t_cur = t_nxt; t_nxt.next(); }
-        }
-    } else {
-        // =========================================================== CONSUMERS =============================================================
-        constexpr int NK = 9 * C0 / 16;                                         // 18 MFMA steps of K = 16
-        u32x4 fw2[2][C1 / 16];
-        int cstream = -1;
-        auto load_conv_weights = [&](int stream) {                              // the chained 1x1: row a * 32 + l31 of its K-major matrix, K = 16 s + 8 hi
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                int lo = (a * 32 + l31) * p.Kp2 + 8 * hi;
-                asm volatile("" : "+v"(lo));
-                const typename E::type* w2 = (const typename E::type*)p.w2 + stream * p.w2_gs + lo;
-#pragma unroll
-                for (int s2 = 0; s2 < C1 / 16; ++s2) fw2[a][s2] = *(const u32x4*)(w2 + 16 * s2);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int s2 = 0; s2 < C1 / 16; ++s2) asm volatile("" : "+v"(fw2[a][s2]));
-            cstream = stream;
-        };
-        // the lane's output pixel (row tw, column l31): entry of tap (0, 0) and of tap (0, 2), each with the two 16-byte channel slots of a K step
-        int s2_rd[2][2];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const int idx = tw * 2 * S2_PITCH + l31 + d;
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) s2_rd[d][h2] = ((idx << 2) + (((h2 * 2 + hi) ^ (idx >> 2)) & 3)) << 4;
-        }
-        lds_barrier();                             // (a) of iteration k = -1
-        lds_barrier();                             // (b) of iteration k = -1: halo patch 0 complete
-        for (int k = 0; k < ntile; ++k) {
-#ifdef ICAF_S2_CLK
-            const int clk_tile = k;
-#endif
-            S2_STAMP(0);
-            int stream, b, y0, x0;
-            decode(t_cur, stream, b, y0, x0);
-            if (stream != wstream) {
-                lds_barrier();
-                load_consumer_lds(stream);
-                lds_barrier();
-                wstream = stream;
-            }
-            if (stream != cstream) load_conv_weights(stream);
-            if (k + 1 < ntile) commit();
-            if (k + 2 < ntile) { t_ftc.next(); fetch(t_ftc); }
-            S2_STAMP(1);
-            lds_barrier();                         // (a)
-            S2_STAMP(2);
-            unsigned char* halo = halo0 + (k & 1) * S2_HALO_BYTES;
-            unsigned char* stg = halo + (2 * tw + 1) * (S2_PITCH * 64);       // staging row: the halo row only this wave reads, free once its stage-2 reads have landed
-            // ---- stage 2: 3x3 / stride 2 over the halo patch, both channel halves of this wave's row ---------------------------------------
-            f32x16 acc[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
-            {
-                constexpr int PFD = 3;
-                u32x4 fpq[NK], fwq[2][NK];
-                auto rd2 = [&](int k2) {
-                    const int tap = k2 >> 1, ky = tap / 3, kx = tap - 3 * ky;
-                    fpq[k2] = *(const u32x4*)(halo + s2_rd[kx >> 1][k2 & 1] + (ky * S2_PITCH + (kx & 1) * S2_HALF) * 64);
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) fwq[a][k2] = *(const u32x4*)(w1b + (k2 >> 2) * C1 * RB + (a * 32) * RB + foff[k2 & 3]);
-                };
-#pragma unroll
-                for (int k2 = 0; k2 < PFD; ++k2) rd2(k2);
-#pragma unroll
-                for (int k2 = 0; k2 < NK; ++k2) {
-                    if (k2 + PFD < NK) rd2(k2 + PFD);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma_step<DT>(acc[0], fwq[0][k2], fpq[k2]);
-                    mma_step<DT>(acc[1], fwq[1][k2], fpq[k2]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            S2_STAMP(3);
-            // t1 row -> the wave's staging tile, rounded to the storage type (igemm CHAIN, step a)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int nl = a * 32 + 8 * qd + 4 * hi;
-                    const f32x4 bv = *(const f32x4*)(bl + stream * S2P_NB + C0 + nl);
-                    float v[4];
-                    const float x[4] = {acc[a][4 * qd] + bv[0], acc[a][4 * qd + 1] + bv[1], acc[a][4 * qd + 2] + bv[2], acc[a][4 * qd + 3] + bv[3]};
-                    silu4_f(x, v);
-                    u32x2 pk2;
-                    if constexpr (DT == ICAF_BF16) { pk2[0] = pack2_bf16(v[0], v[1]); pk2[1] = pack2_bf16(v[2], v[3]); }
-                    else { pk2[0] = pack2_f16(v[0], v[1]); pk2[1] = pack2_f16(v[2], v[3]); }
-                    *(u32x2*)(stg + l31 * SO + nl * E::BYTES) = pk2;
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wave: its LDS operations execute in order; this orders the compiler's view)
-            S2_STAMP(4);
-            // ---- stage 3: chained 1x1 on the staged row ---------------------------------------------------------------------------------------
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
-            {
-                u32x4 fp2[C1 / 16];
-#pragma unroll
-                for (int s2 = 0; s2 < C1 / 16; ++s2) fp2[s2] = *(const u32x4*)(stg + l31 * SO + ((2 * s2 + hi) << 4));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s2 = 0; s2 < C1 / 16; ++s2) {
-                    mma_step<DT>(acc[0], fw2[0][s2], fp2[s2]);
-                    mma_step<DT>(acc[1], fw2[1][s2], fp2[s2]);
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int nl = a * 32 + 8 * qd + 4 * hi;
-                    const f32x4 bv = *(const f32x4*)(bl + stream * S2P_NB + C0 + C1 + nl);
-                    float v[4];
-                    const float x[4] = {acc[a][4 * qd] + bv[0], acc[a][4 * qd + 1] + bv[1], acc[a][4 * qd + 2] + bv[2], acc[a][4 * qd + 3] + bv[3]};
-                    silu4_f(x, v);
-                    u32x2 pk2;
-                    if constexpr (DT == ICAF_BF16) { pk2[0] = pack2_bf16(v[0], v[1]); pk2[1] = pack2_bf16(v[2], v[3]); }
-                    else { pk2[0] = pack2_f16(v[0], v[1]); pk2[1] = pack2_f16(v[2], v[3]); }
-                    *(u32x2*)(stg + l31 * SO + nl * E::BYTES) = pk2;
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            S2_STAMP(5);
-            // ---- the row leaves: 32 pixels x 8 vectors of 16 bytes, four per lane -----------------------------------------------------------------
-            {
-                typename E::type* __restrict__ yg = (typename E::type*)p.y2 + stream * p.y2_gs;
-                const int gy = y0 + tw, cv = lane & 7;
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int row = (lane >> 3) + 8 * it, gx = x0 + row;
-                    const u32x4 sv = *(const u32x4*)(stg + row * SO + cv * 16);
-                    if (gy < p.Ho && gx < p.Wo && cv * 8 < p.Cout2) *(u32x4*)(yg + (long long)((b * p.Ho + gy) * p.Wo + gx) * p.ldy2 + cv * 8) = sv;
-                }
-            }
-            S2_STAMP(6);
-            lds_barrier();                         // (b)
-            S2_STAMP(7);
-            t_cur = t_nxt;
-            t_nxt.next();
-        }
-    }
-}
-
 }  // namespace icaf
 
 using namespace icaf;
@@ -1142,13 +737,8 @@ static int launch_stem2(const Stem2P& q, hipStream_t s) {
     ICAF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     int grid = cus < q.npatch ? cus : q.npatch;     // 122 KiB of LDS: one workgroup per CU
     grid = (grid + 7) & ~7;                         // the tile walk is per XCD (8 of them)
-#ifdef ICAF_S2_PC
-    ICAF_LDS_OPTIN((stem2pc_kernel<DT, U8, PAIR>), S2P_LDS);
-    stem2pc_kernel<DT, U8, PAIR><<<dim3((unsigned)grid), dim3(S2_THREADS), S2P_LDS, s>>>(q);
-#else
     ICAF_LDS_OPTIN((stem2_kernel<DT, U8, PAIR>), S2_LDS);
     stem2_kernel<DT, U8, PAIR><<<dim3((unsigned)grid), dim3(S2_THREADS), S2_LDS, s>>>(q);
-#endif
     ICAF_LAUNCH_CHECK();
     return ICAF_OK;
 }
