@@ -61,6 +61,23 @@ for w in $WORKLOADS; do
     cd $R && timeout 300 python tools/layer_profile.py --autotune > gpurun_out/layer_profile.txt 2>/dev/null; head -1 gpurun_out/layer_profile.txt
     cd $R && ICAF_OPTIONS=dmff_fuse=0 timeout 300 python tools/layer_profile.py --autotune > gpurun_out/layer_profile_plain.txt 2>/dev/null; head -1 gpurun_out/layer_profile_plain.txt
     [ "$PARITY" = 1 ] && { timeout 1200 python tools/parity16.py --out gpurun_out/parity_16bit.json > gpurun_out/parity16.log 2>&1; tail -1 gpurun_out/parity16.log | cut -c1-200; }
+    # the same workload on the fp32 build (the one held to north_star's 1e-3): what meeting that tolerance costs
+    cd $R && timeout 900 python bench.py --dtype f32 --no-h2d --no-cpu-baseline --min-timed-seconds 1.5 > gpurun_out/bench_fp32.json 2> gpurun_out/bench_fp32.err; line fp32 gpurun_out/bench_fp32.json
+    # what a rank of an N > 1 run pays for the collective (one rank, RCCL group of one): plain / forced, twice, interleaved
+    for r in 1 2; do for g in "" "--force-gather"; do
+      timeout 300 python bench.py --no-cpu-baseline --no-latency --no-h2d --min-timed-seconds 1.5 $g 2> /dev/null | tail -1 > gpurun_out/bench_fg_${r}${g:+_gather}.json
+      python -c "import json; d=json.load(open('gpurun_out/bench_fg_${r}${g:+_gather}.json')); print('force-gather' if '$g' else 'plain       ', d['value'], d['value_min'], d['value_max'])"
+    done; done
+    python - <<'PY'
+import json
+r = {k: [json.load(open(f"gpurun_out/bench_fg_{i}{s}.json"))["value"] for i in (1, 2)] for k, s in (("plain", ""), ("force_gather", "_gather"))}
+r["ratio"] = round(sum(r["force_gather"]) / sum(r["plain"]), 4)
+r["all_gather"] = json.load(open("gpurun_out/bench_fg_1_gather.json"))["config"]["all_gather"]
+json.dump(r, open("gpurun_out/bench_force_gather.json", "w"), indent=1)
+print("force-gather / plain =", r["ratio"])
+PY
+    # the driver's exact command, last
+    cd $R && timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_driver_form.json 2> gpurun_out/bench_driver_form.err; line driver_form gpurun_out/bench_driver_form.json
   else
     cp $R/profiles/tune_cache_$name.json /tmp/tune_$name.json       # (a re-tune inside the call edits the copy; it is brought back as gpurun_out/tune_cache_<name>.json)
     ARGS="$ARGS --tune-cache /tmp/tune_$name.json"
@@ -68,6 +85,7 @@ for w in $WORKLOADS; do
     [ "${SQ:-1}" = 1 ] && sq $name $ARGS
     cd $R && timeout 1200 python bench.py $ARGS > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err; line $name gpurun_out/bench_$name.json
     trace $name $ARGS
+    cd $R && timeout 300 python tools/layer_profile.py --autotune $ARGS > gpurun_out/layer_profile_$name.txt 2>/dev/null; head -1 gpurun_out/layer_profile_$name.txt
     cp /tmp/tune_$name.json gpurun_out/tune_cache_$name.json
   fi
 done

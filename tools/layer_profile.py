@@ -21,15 +21,23 @@ ap.add_argument("--reps", type=int, default=7)
 ap.add_argument("--sweep", action="store_true", help="time every igemm launch with each tile config")
 ap.add_argument("--autotune", action="store_true")
 ap.add_argument("--tune-cache", default=None, help="tile choices to load instead of profiles/tune_cache.json (implies --autotune)")
+# bench.py's spelling of a workload (tools/gpu_evidence.sh passes the same argument string to both)
+ap.add_argument("--height", type=int, default=0); ap.add_argument("--width", type=int, default=0)
+ap.add_argument("--loops", type=int, default=1); ap.add_argument("--dataset", default="kaist")
+ap.add_argument("--conf", type=float, default=0.0, help="(ignored: no NMS here)")
 a = ap.parse_args()
+H, W = a.height or a.size, a.width or a.size
 dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
-cfg = yaml.safe_load(open(os.path.join(ROOT, "models", "transformer", f"yolov5{a.model}_Transfusion_kaist.yaml")))
-m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 0)); m = m.to("cuda:0"); m.compute_dtype = dt
+cfg = yaml.safe_load(open(os.path.join(ROOT, "models", "transformer", f"yolov5{a.model}_Transfusion_{a.dataset}.yaml")))
+m = Model(cfg).eval(); m.load_state_dict(synth_state_dict(m, 0))
+for i in (20, 21, 22):
+    m.model[i].crosstransformer[0].loops = a.loops
+m = m.to("cuda:0"); m.compute_dtype = dt
 m.autotune = a.autotune or bool(a.tune_cache)
 if m.autotune:        # the committed igemm configuration choices: the same kernels bench.py launches
     ops.load_tune_cache(a.tune_cache or os.path.join(ROOT, "profiles", "tune_cache.json"))
-plan = m.plan_for(a.batch, a.size, a.size, "cuda:0")
-rgb, ir = synth_images(a.batch, a.size, a.size, 0)
+plan = m.plan_for(a.batch, H, W, "cuda:0")
+rgb, ir = synth_images(a.batch, H, W, 0)
 plan.inputs[0].copy_(rgb.cuda()); plan.inputs[1].copy_(ir.cuda())
 plan.run(); torch.cuda.synchronize()
 runs = [[x[1] for x in plan.timed_run()] for _ in range(a.reps)]
