@@ -58,8 +58,10 @@ def demangle(names):
 # feed VALU arithmetic directly (softmax, GELU) otherwise pay one v_accvgpr_read per accumulator element and tile — the attention loop
 # spent 32 of ~118 issue slots per score tile on them (attn_core.h) — and AGPR-allocated accumulators round the register budget up.
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+# (ctile.hip, round 6: the fused Bottleneck + cv3 kernel issues 112 v_accvgpr_read per wave for its seven accumulators and sits at VALU issue 0.70:
+#  115 registers and no AGPRs instead of 100 + 64, 135 -> 133 us; the other convolution files already compile to VGPR accumulators or do not move)
 PER_FILE = {"detect.hip": ["-ffp-contract=off"], "nms.hip": ["-ffp-contract=off"],
-            "dmff.hip": VGPR_FORM, "dmff_fused.hip": VGPR_FORM}
+            "dmff.hip": VGPR_FORM, "dmff_fused.hip": VGPR_FORM, "ctile.hip": VGPR_FORM}
 _VF = os.environ.get("ICAF_VGPR_FORM", "")             # A/B builds (tools/build_variant.py): "all" = the whole library in that form, "none" = no file
 if _VF == "all":                                       # (the file list IS the source directory: a new .hip file is never left out)
     PER_FILE = {f: [x for x in PER_FILE.get(f, []) if x not in VGPR_FORM] + VGPR_FORM
