@@ -819,6 +819,8 @@ class CrossTransformerBlock(HipModule):
             t32 = [plan.empty((2, rows, C), torch.float32) for _ in range(2)] if r32 else None
             if nloops > 1:
                 plan.notes.setdefault("dmff_fp32_token_stream", {})[f"C={C}"] = bool(r32)
+            # (the LAST iteration writes y32 too although nothing reads it — 2 * rows * C * 4 bytes, 3 % of the launch's traffic at P3: the kernels' R32
+            #  instantiation writes both token streams or neither, and a third instantiation for one launch in `loops` was not worth its compile time)
             for it in range(nloops):
                 plan.add(ops.dmff_wide_ln_qkv(tok, qkv, p, ln, coef, p["eps"], B, N, self.crossatt.h))
                 plan.add(ops.cross_attention(qkv, att, B, N, self.crossatt.h))
